@@ -1,0 +1,199 @@
+"""Pin the CPU oracle (oracle/nerf_oracle.py) to the golden vectors the
+reference itself produced (tests/golden/make_golden.py).  CPU only.
+
+Tolerance: the oracle repeats the reference's ATen operator sequence on the
+same torch build, so agreement is expected to be exact; the asserts allow
+1e-6 absolute / 1e-6 relative for fp32 round-off from threading-dependent
+GEMM blocking.  NaNs must match in position (disp is NaN where acc == 0).
+"""
+import numpy as np
+import pytest
+import torch
+
+from nerf_shared_amd import synth
+from oracle import nerf_oracle as O
+
+VD = dict(D=8, W=256, output_ch=5, skips=(4,), use_viewdirs=True, multires=10, multires_views=4)
+NOVD = dict(D=8, W=256, output_ch=5, skips=(4,), use_viewdirs=False, multires=10, multires_views=4)
+
+
+def close(a, b, atol=1e-6, rtol=1e-6):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
+    np.testing.assert_allclose(np.nan_to_num(a, nan=0.0), np.nan_to_num(b, nan=0.0), atol=atol, rtol=rtol)
+
+
+def model(seed, sharpen, **arch):
+    return O.state_dict_to_torch(synth.make_state_dict(seed, sharpen, **arch)), O.Arch(**arch)
+
+
+def test_g1_embedder(golden):
+    g = golden("g1_embedder")
+    x = torch.from_numpy(g["x"])
+    for L in (10, 4, 15, 6):
+        y = O.embed(x, L)
+        assert y.shape[-1] == 3 + 6 * L
+        np.testing.assert_array_equal(y.numpy(), g["L%d" % L])
+    np.testing.assert_array_equal(O.embed(x, 10, -1).numpy(), g["identity"])
+
+
+def test_g2_nerf(golden):
+    g = golden("g2_nerf")
+    pts, vd = torch.from_numpy(g["pts"]), torch.from_numpy(g["viewdirs"])
+    for tag, seed, sharpen in (("s0", 0, 1.0), ("s1", 1, 3.0)):
+        sd, arch = model(seed, sharpen, **VD)
+        close(O.nerf_forward(sd, arch, pts, vd), g["vd_" + tag])
+        close(O.get_density(sd, arch, pts), g["density_" + tag])
+        sd2, arch2 = model(seed, sharpen, **NOVD)
+        out = O.nerf_forward(sd2, arch2, pts, None)
+        assert out.shape[-1] == 5
+        close(out, g["novd_" + tag])
+    small = dict(D=4, W=128, output_ch=4, skips=(1,), use_viewdirs=True, multires=6, multires_views=2)
+    close(O.nerf_forward(*model(5, 3.0, **small), pts, vd), g["small_s1"])
+    wide = dict(VD, multires=15, multires_views=6)
+    close(O.nerf_forward(*model(6, 3.0, **wide), pts, vd), g["wide_s1"])
+
+
+def test_g2_chunk_invariance(golden):
+    g = golden("g2_nerf")
+    rng2 = np.random.default_rng(203)
+    big = rng2.uniform(-3, 3, size=(1100, 64, 3)).astype(np.float32)
+    bvd = rng2.normal(size=(1100, 3)).astype(np.float32)
+    bvd /= np.linalg.norm(bvd, axis=-1, keepdims=True)
+    sd, arch = model(1, 3.0, **VD)
+    full = O.nerf_forward(sd, arch, torch.from_numpy(big), torch.from_numpy(bvd)).reshape(-1, 4)
+    close(full[::int(g["big_stride"])], g["big_subset"], atol=2e-6)
+
+
+def test_g3_raw2outputs(golden):
+    g = golden("g3_raw2outputs")
+    raw, z, rd = (torch.from_numpy(g[k]) for k in ("raw", "z_vals", "rays_d"))
+    names = ("rgb", "disp", "acc", "weights", "depth")
+    for white in (True, False):
+        res = O.raw2outputs(raw, z, rd, white)
+        for n, v in zip(names, res):
+            close(v, g["%s_white%d" % (n, white)])
+    assert np.isnan(g["disp_white1"][5]) and g["acc_white1"][5] == 0.0
+    np.testing.assert_array_equal(g["rgb_white1"][5], np.ones(3, np.float32))
+    noise = O.pytest_uniform(raw[..., 3].shape) * 1.0
+    for n, v in zip(names, O.raw2outputs(raw, z, rd, True, noise)):
+        close(v, g["%s_noise" % n])
+    res = O.raw2outputs(*(torch.from_numpy(g[k]) for k in ("raw_192", "z_vals_192", "rays_d_192")), True)
+    for n, v in zip(names, res):
+        close(v, g["%s_192" % n])
+
+
+def test_g4_sample_pdf(golden):
+    g = golden("g4_sample_pdf")
+    bins, w = torch.from_numpy(g["bins"]), torch.from_numpy(g["weights"])
+    for N in (64, 128):
+        close(O.sample_pdf(bins, w, N, det=True), g["det_N%d" % N])
+        close(O.sample_pdf(bins, w, N, det=True, u=O.pytest_u_for_sample_pdf(bins.shape[0], N, True)),
+              g["detpytest_N%d" % N])
+        close(O.sample_pdf(bins, w, N, det=False, u=O.pytest_u_for_sample_pdf(bins.shape[0], N, False)),
+              g["rand_N%d" % N])
+    known = O.sample_pdf(torch.from_numpy(g["known_bins"]), torch.from_numpy(g["known_weights"]), 8, det=True)
+    close(known, g["known_det8"])
+    np.testing.assert_allclose(known.numpy()[0],
+                               [2.0, 3.2143, 3.4286, 3.6429, 3.8571, 5.1429, 5.5714, 6.0], atol=1e-4)
+
+
+G5_CASES = {
+    "det_s0": (dict(), VD, (0, 10, 1.0), False),
+    "det_s1": (dict(), VD, (1, 11, 3.0), False),
+    "perturb_s1": (dict(perturb=1.0), VD, (1, 11, 3.0), True),
+    "lindisp_s1": (dict(lindisp=True), VD, (1, 11, 3.0), False),
+    "coarseonly_s1": (dict(N_importance=0), VD, (1, None, 3.0), False),
+    "nofine_s1": (dict(), VD, (1, None, 3.0), False),
+    "black_noise_s1": (dict(white_bkgd=False, raw_noise_std=1.0, perturb=1.0), VD, (1, 11, 3.0), True),
+    "novd_s1": (dict(use_viewdirs=False), NOVD, (2, 12, 3.0), False),
+    "fern_s1": (dict(N_importance=64, ndc=True, near=0.0, far=1.0, white_bkgd=False,
+                     raw_noise_std=1.0, perturb=1.0), VD, (1, 11, 3.0), True),
+}
+G5_BASE = dict(perturb=0.0, N_importance=128, N_samples=64, use_viewdirs=True, white_bkgd=True,
+               raw_noise_std=0.0, ndc=False, lindisp=False, near=2.0, far=6.0)
+G5_KEYS = ("rgb_map", "disp_map", "acc_map", "raw", "weights", "z_vals", "rgb0", "disp0", "acc0", "z_std")
+
+
+@pytest.mark.parametrize("tag", sorted(G5_CASES))
+def test_g5_render_rays(golden, tag):
+    g = golden("g5_render_rays")
+    over, arch, (sc, sf, sharpen), pytest_flag = G5_CASES[tag]
+    cfg = O.RenderCfg(**dict(G5_BASE, **over))
+    coarse = model(sc, sharpen, **arch)
+    fine = model(sf, sharpen, **arch) if sf is not None else None
+    ret = O.render_rays(cfg, torch.from_numpy(g[tag + "__batch"]), coarse, fine,
+                        retraw=True, retweights=True, pytest=pytest_flag)
+    for k in G5_KEYS:
+        if tag + "__" + k in g:
+            close(ret[k], g[tag + "__" + k], atol=2e-6, rtol=2e-6)
+        else:
+            assert k not in ret
+
+
+def test_g6_rays(golden):
+    g = golden("g6_rays")
+    c2w = torch.from_numpy(synth.LEGO_C2W)
+    ro, rd = O.get_rays(4, 6, g["small_K"], c2w)
+    close(ro, g["small_rays_o"], 0, 0)
+    close(rd, g["small_rays_d"], 0, 0)
+    ro_np, rd_np = synth.rays_np(4, 6, g["small_K"], synth.LEGO_C2W)
+    close(rd_np.reshape(4, 6, 3), g["small_rays_d_np"].astype(np.float32), 1e-6, 0)  # reference twin is float64
+    c2w4 = torch.eye(4)
+    c2w4[:3, :4] = c2w
+    ro, rd = O.get_rays(4, 6, g["small_K"], c2w4)
+    close(ro, g["small4_rays_o"], 0, 0)
+    close(rd, g["small4_rays_d"], 0, 0)
+    K = synth.lego_intrinsics(400, 400)
+    ro, rd = O.get_rays(400, 400, K, c2w)
+    close(rd.reshape(-1, 3)[g["lego_corners"]], g["lego_rays_d"], 0, 0)
+    close(ro.reshape(-1, 3)[g["lego_corners"]], g["lego_rays_o"], 0, 0)
+    _, rd_np = synth.rays_np(400, 400, K, synth.LEGO_C2W, g["lego_corners"])
+    close(rd_np, g["lego_rays_d_np"].astype(np.float32), 1e-6, 0)
+    H, W, focal = g["ndc_HWf"]
+    o2, d2 = O.ndc_rays(int(H), int(W), float(focal), 1.0, torch.from_numpy(g["ndc_in_o"]), torch.from_numpy(g["ndc_in_d"]))
+    close(o2, g["ndc_out_o"], 0, 0)
+    close(d2, g["ndc_out_d"], 0, 0)
+
+
+def test_g7_render(golden):
+    g = golden("g7_render")
+    cfg = O.RenderCfg(**G5_BASE)
+    coarse, fine = model(1, 3.0, **VD), model(11, 3.0, **VD)
+    rgb, disp, acc, extras = O.render(cfg, 16, 16, g["K"], coarse, fine, chunk=100,
+                                      c2w=torch.from_numpy(g["c2w"]), retraw=True)
+    close(rgb, g["pose_rgb"], 2e-6)
+    close(disp, g["pose_disp"], 2e-6, 2e-6)
+    close(acc, g["pose_acc"], 2e-6)
+    assert sorted(extras) == sorted(k[len("pose_extra_"):] for k in g if k.startswith("pose_extra_"))
+    for k, v in extras.items():
+        close(v, g["pose_extra_" + k], 2e-6, 2e-6)
+    rgb, disp, acc, extras = O.render(cfg, 16, 16, g["K"], coarse, fine, chunk=32768,
+                                      rays=torch.from_numpy(g["rays_in"]), retraw=False)
+    close(rgb, g["rays_rgb"], 2e-6)
+    assert "raw" not in extras
+    for k, v in extras.items():
+        close(v, g["rays_extra_" + k], 2e-6, 2e-6)
+    cfgn = O.RenderCfg(**dict(G5_BASE, ndc=True, near=0.0, far=1.0, N_importance=64, white_bkgd=False))
+    rgb, disp, acc, extras = O.render(cfgn, 12, 16, g["ndc_K"], coarse, fine, chunk=77,
+                                      c2w=torch.from_numpy(g["ndc_c2w"]), retraw=False)
+    close(rgb, g["ndc_rgb"], 2e-6)
+    close(disp, g["ndc_disp"], 2e-6, 2e-6)
+    close(acc, g["ndc_acc"], 2e-6)
+
+
+def test_g8_psnr_crop(golden):
+    g = golden("g8_psnr_crop")
+    H = W = 800
+    K = synth.lego_intrinsics(H, W)
+    ro, rd = synth.rays_np(H, W, K, synth.LEGO_C2W, g["pixel_index"])
+    rays = torch.from_numpy(np.stack([ro, rd], 0))
+    cfg = O.RenderCfg(**G5_BASE)
+    coarse, fine = model(1, 3.0, **VD), model(11, 3.0, **VD)
+    rgb, disp, acc, extras = O.render(cfg, H, W, K, coarse, fine, chunk=4096, rays=rays, retraw=False)
+    close(rgb, g["rgb_s1"], 2e-6)
+    close(extras["rgb0"], g["rgb0_s1"], 2e-6)
+    psnr = float(O.mse2psnr(O.img2mse(rgb, torch.from_numpy(g["rgb_s1"])) + 1e-20))
+    assert psnr > 100.0
