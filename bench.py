@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- rays/sec of the render hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one pass of Renderer.render_batch over a resident [rays, 11] batch:
+Lego half-res geometry (400x400 = 160 000 rays per GPU), 64 coarse + 128 fine
+samples, 8x256 viewdirs MLP x 2 (coarse + fine, random-init seeds 0/10),
+4096-ray chunks, perturb=0, white background (BASELINE.json configs[1]).
+Rays are generated into HBM before the timed region; outputs stay in HBM.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): weak scaling.
+The view is 400 x (400 N) pixels; rank r renders flat pixel range r of it and the
+finished [rays, 5] rows are gathered to rank 0 inside the timed step (the one real
+exchange of the path).
+
+The JSON line also carries
+  roofline     -- the fused bf16 field kernel (fine-pass launches dominate):
+                  algorithmic FLOP (1 186 816 per point) / device time
+                  from hipEvents recorded around every launch on its stream
+                  (nerf_amd_profile_*), against the 2.5 PFLOP/s dense bf16 MFMA peak.
+  cpu_baseline -- the CPU oracle (torch-CPU restatement of the reference, "port")
+                  timed on this box's host cores on a bounded sample of the same
+                  workload (one 4096-ray batch, 64+128), rank 0, N=1 only.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+os.environ.setdefault("NERF_AMD_QUIET", "1")
+
+FLOP_PER_POINT = 1186816            # 2 x 593 408 MAC, viewdirs 8x256 MLP
+PEAK_BF16_TFLOPS = 2500.0           # dense bf16 MFMA peak, MI355X_MICROARCH.md
+H, W_PER_GPU, CHUNK = 400, 400, 4096
+N_SAMPLES, N_IMPORTANCE = 64, 128
+ARCH = dict(D=8, W=256, output_ch=5, skips=[4], use_viewdirs=True, multires=10, multires_views=4)
+RCFG = dict(perturb=0.0, N_importance=N_IMPORTANCE, N_samples=N_SAMPLES, use_viewdirs=True, white_bkgd=True,
+            raw_noise_std=0.0, ndc=False, lindisp=False, near=2.0, far=6.0)
+
+
+def cpu_baseline(torch, synth):
+    """Oracle on host cores: one 4096-ray 64+128 batch, 1 warm-up + best of 2."""
+    from oracle import nerf_oracle as O
+    import numpy as np
+    threads = torch.get_num_threads()
+    K = synth.lego_intrinsics(H, W_PER_GPU)
+    ro, rd = synth.rays_np(H, W_PER_GPU, K, synth.LEGO_C2W, np.arange(80000, 80000 + CHUNK))
+    batch = torch.from_numpy(synth.ray_batch_np(ro, rd, 2.0, 6.0, True))
+    models = []
+    for seed in (0, 10):
+        sd = synth.make_state_dict(seed, 1.0, **{**ARCH, "skips": (4,)})
+        models.append((O.state_dict_to_torch(sd), O.Arch(**ARCH)))
+    cfg = O.RenderCfg(**RCFG)
+    best = float("inf")
+    with torch.no_grad():
+        for i in range(3):
+            t0 = time.perf_counter()
+            O.render_rays(cfg, batch, models[0], models[1])
+            dt = time.perf_counter() - t0
+            if i > 0:
+                best = min(best, dt)
+    return {"value": CHUNK / best, "unit": "rays/s", "cores": threads, "kind": "port",
+            "sample": "one %d-ray batch, 64+128 samples, torch-CPU oracle fp32, best of 2 after warm-up (%.2f s)" % (CHUNK, best)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from nerf_shared_amd import _lib, dist as nd, nerf, render_utils, synth, utils
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d (WORLD_SIZE=%d)"
+                         % (args.gpus, args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device; there is no CPU path")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    models = []
+    for seed in (0, 10):
+        m = nerf.NeRF(**ARCH)
+        m.load_state_dict(synth.torch_state_dict(seed, 1.0, **{**ARCH, "skips": (4,)}))
+        m.precision = args.precision
+        models.append(m.to(dev))
+    renderer = render_utils.Renderer(**RCFG)
+
+    Wimg = W_PER_GPU * world
+    K = synth.lego_intrinsics(H, W_PER_GPU)
+    K[0][2] = 0.5 * Wimg
+    n_total = H * Wimg
+    lo, hi = nd.shard_range(n_total, rank, world)
+    rays = utils.make_ray_batch(H, Wimg, K, synth.LEGO_C2W, 2.0, 6.0, True, False, device=dev, pix0=lo, n=hi - lo)
+    torch.cuda.synchronize()
+
+    def step():
+        ret = renderer.render_batch(models[0], models[1], rays, CHUNK, False)
+        if world > 1:
+            return nd.gather_rows(nd.pack_maps(ret), n_total, 0)
+        return ret
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        fence()
+        _lib.lib.nerf_amd_profile_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        _lib.lib.nerf_amd_profile_enable(0)
+
+    launches = (ctypes.c_int64 * 2)()
+    ms = (ctypes.c_double * 2)()
+    pts = (ctypes.c_double * 2)()
+    _lib.lib.nerf_amd_profile_collect(launches, ms, pts)
+    cls = 1 if args.precision == "bf16" else 0
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        rays_per_step = n_total
+        value = rays_per_step * args.steps / dt
+        kern_s = ms[cls] / 1e3
+        achieved = (pts[cls] * FLOP_PER_POINT / kern_s / 1e12) if kern_s > 0 else 0.0
+        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3
+        out = {
+            "metric": "rays_per_sec", "value": value, "unit": "rays/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": "lego_halfres_400x400_64c+128f_viewdirs_8x256_chunk4096",
+                       "rays_per_step": rays_per_step, "rays_per_gpu_per_step": H * W_PER_GPU, "chunk": CHUNK,
+                       "N_samples": N_SAMPLES, "N_importance": N_IMPORTANCE, "weights": "random-init seeds 0/10",
+                       "parallelism": "ray-range shards x%d, one gather of [rays,5] to rank 0 per step" % world
+                       if world > 1 else "single GPU"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": None,
+                         "kernel": "mlp_bf16_kernel" if cls == 1 else "mlp_f32_kernel",
+                         "launches": int(launches[cls]),
+                         "avg_launch_ms": (ms[cls] / launches[cls]) if launches[cls] else None,
+                         "flop_per_point": FLOP_PER_POINT, "points": pts[cls], "rank": 0},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(torch, synth)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

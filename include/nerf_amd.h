@@ -1,0 +1,202 @@
+/*
+ * nerf_amd.h -- C ABI of the MI355X (gfx950) NeRF volumetric-render hot path.
+ *
+ * Drop-in boundary for stanford-iprl-lab/nerf_shared's
+ *   Renderer.render -> render_batch -> render_rays -> {NeRF.forward/MLP,
+ *   raw2outputs, sample_pdf}
+ * The reference is pure Python/PyTorch and has no FFI layer of its own
+ * (SURVEY.md section 8b), so every entry point below names the Python
+ * function (reference file:line) whose arithmetic it replaces; the Python
+ * package nerf_shared_amd binds them with ctypes and keeps the reference's
+ * class/function signatures.  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no torch/C++ types.
+ *  - Every data pointer is a DEVICE pointer to contiguous fp32 (row-major,
+ *    innermost dimension last) unless a parameter says "host".  Buffers are
+ *    borrowed: the caller (torch) owns them; the library never frees them.
+ *  - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream()
+ *    .cuda_stream); all work is enqueued on it, nothing synchronises the host
+ *    except nerf_amd_model_create/_update (which read host weights).
+ *  - Return value: 0 on success, a negative NERF_AMD_E* code on failure;
+ *    nerf_amd_last_error() returns a thread-local message.  No exception
+ *    crosses the boundary.
+ *  - Re-entrant; the only shared state is inside model handles, which must not
+ *    be updated while a launch that uses them is being enqueued.
+ */
+#ifndef NERF_AMD_H
+#define NERF_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NERF_AMD_ABI_VERSION 1
+
+#define NERF_AMD_OK            0
+#define NERF_AMD_EINVAL       -1   /* bad argument / unsupported shape        */
+#define NERF_AMD_EHIP         -2   /* a HIP runtime call failed               */
+#define NERF_AMD_EUNSUPPORTED -3   /* architecture not supported by this path */
+#define NERF_AMD_ENOMEM       -4
+
+/* Arithmetic of the MLP (the only stage with a precision choice). */
+#define NERF_AMD_PREC_FP32 0       /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32): parity mode       */
+#define NERF_AMD_PREC_BF16 1       /* bf16 operands, fp32 accumulate (v_mfma_f32_32x32x16_bf16)   */
+
+#define NERF_AMD_MAX_SKIPS 8
+
+int         nerf_amd_abi_version(void);
+const char *nerf_amd_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * Model handle: packed weights of one reference NeRF.
+ * Replaces: NeRF.__init__ parameter layout, /root/reference/nerf_shared/nerf.py:62-94.
+ * ------------------------------------------------------------------------ */
+typedef struct nerf_amd_arch {
+    int32_t D;                 /* number of pts_linears                   (nerf.py:62)  */
+    int32_t W;                 /* hidden width                                          */
+    int32_t output_ch;         /* width of output_linear when !use_viewdirs             */
+    int32_t use_viewdirs;
+    int32_t multires;          /* L of the xyz encoding (input_ch = 3 + 6 L)            */
+    int32_t multires_views;    /* L of the view-direction encoding                      */
+    int32_t i_embed;           /* 0 = positional encoding, -1 = identity  (nerf.py:44)  */
+    int32_t n_skips;
+    int32_t skips[NERF_AMD_MAX_SKIPS];
+} nerf_amd_arch;
+
+typedef struct nerf_amd_model nerf_amd_model;   /* opaque, library-owned */
+
+/*
+ * Parameters are given in state_dict order as DEVICE pointers to the live fp32
+ * nn.Linear tensors ([out,in] row-major weights, [out] biases):
+ *   index 0..D-1 : pts_linears.i
+ *   viewdirs     : D = feature_linear, D+1 = alpha_linear, D+2 = views_linears.0, D+3 = rgb_linear
+ *   no viewdirs  : D = output_linear
+ * The library re-packs them on the device (bf16 MFMA A-fragment stream and an
+ * fp32 fragment stream) on `stream`; call nerf_amd_model_update again after the
+ * parameters change (the Python shim keys this on tensor._version/data_ptr).
+ */
+int  nerf_amd_model_create(const nerf_amd_arch *arch, int device, nerf_amd_model **out);
+int  nerf_amd_model_update(nerf_amd_model *m, const float *const *weights, const float *const *biases,
+                           int n_tensors, void *stream);
+void nerf_amd_model_destroy(nerf_amd_model *m);
+/* 1 when the fused bf16 kernel supports this architecture (D=8, W=256, skips=[4]). */
+int  nerf_amd_model_supports_bf16(const nerf_amd_model *m);
+int  nerf_amd_model_out_ch(const nerf_amd_model *m);       /* 4 with viewdirs, else output_ch */
+
+/* Host-side packing of one model into the bf16 fragment stream (test hook: lets
+ * CPU tests check the fragment layout without a GPU).  Weights/biases are HOST
+ * pointers here.  `stream_out` receives n_frags*512 uint16 (bf16 bits) and
+ * `bias_out` the fp32 bias table; pass NULL to query sizes only. */
+int  nerf_amd_pack_bf16_host(const nerf_amd_arch *arch, const float *const *weights,
+                             const float *const *biases, int n_tensors,
+                             uint16_t *stream_out, int64_t *n_frags, float *bias_out, int64_t *n_bias);
+
+/* ------------------------------------------------------------------------
+ * a1  Embedder.embed / get_embedder          nerf.py:16-58
+ * x [n,3] -> out [n, 3+6*multires]   (frequency-major, sin then cos, xyz innermost)
+ * ------------------------------------------------------------------------ */
+int nerf_amd_embed(const float *x, int64_t n, int multires, float *out, void *stream);
+
+/* ------------------------------------------------------------------------
+ * a3/a4  NeRF.forward + NeRF.MLP              nerf.py:96-134
+ * pts [n_rays*n_samples,3]; viewdirs [n_rays,3] (NULL when the model has no
+ * view branch; every sample of ray r uses viewdirs[r], nerf.py:101)
+ * -> out [n_rays*n_samples, out_ch].  No netchunk: the kernel tiles internally.
+ * ------------------------------------------------------------------------ */
+int nerf_amd_nerf_forward(const nerf_amd_model *m, const float *pts, const float *viewdirs,
+                          int64_t n_rays, int32_t n_samples, float *out, int precision, void *stream);
+
+/* ------------------------------------------------------------------------
+ * a10  Renderer.raw2outputs                   render_utils.py:241-290
+ * raw [R,S,raw_ch] (channels 0..2 rgb, 3 sigma), z_vals [R,S], rays_d with row
+ * stride `rays_d_stride` floats, noise [R,S] or NULL (already scaled by
+ * raw_noise_std).  Any output pointer may be NULL.
+ * ------------------------------------------------------------------------ */
+int nerf_amd_raw2outputs(const float *raw, int32_t raw_ch, const float *z_vals,
+                         const float *rays_d, int32_t rays_d_stride, const float *noise,
+                         int64_t R, int32_t S, int white_bkgd,
+                         float *rgb_map, float *disp_map, float *acc_map, float *weights,
+                         float *depth_map, void *stream);
+
+/* ------------------------------------------------------------------------
+ * a11  utils.sample_pdf                       utils.py:74-117
+ * bins [R,n_bins], weights [R,n_bins-1], u [R,n_samples] or NULL (then
+ * u = t_lin[n_samples], the caller's torch.linspace(0,1,n_samples), det=True).
+ * -> samples [R,n_samples]
+ * ------------------------------------------------------------------------ */
+int nerf_amd_sample_pdf(const float *bins, const float *weights, const float *u, const float *t_lin,
+                        int64_t R, int32_t n_bins, int32_t n_samples, float *samples, void *stream);
+
+/* ------------------------------------------------------------------------
+ * a9  Renderer.render_rays                    render_utils.py:67-174
+ * One call enqueues the whole two-pass pipeline for R rays:
+ *   z_vals (lin / lindisp, optional stratified jitter) -> coarse field ->
+ *   composite -> sample_pdf -> sort(cat) -> fine field -> composite.
+ * ------------------------------------------------------------------------ */
+typedef struct nerf_amd_render_cfg {
+    int32_t N_samples;
+    int32_t N_importance;
+    int32_t perturb;           /* perturb > 0                               (:115) */
+    int32_t lindisp;
+    int32_t white_bkgd;
+    int32_t use_noise;         /* raw_noise_std > 0: noise0/noise1 are read (:262) */
+    int32_t precision;         /* NERF_AMD_PREC_*                                  */
+    int32_t reserved;
+} nerf_amd_render_cfg;
+
+typedef struct nerf_amd_render_io {
+    /* inputs */
+    const float *rays;         /* [R, ray_ch]: o(3) d(3) near far [viewdirs(3)]  (:98-103) */
+    int32_t      ray_ch;       /* 8 or 11                                                  */
+    int32_t      pad0;
+    const float *t_vals;       /* [N_samples]  torch.linspace(0,1,N_samples)      (:105)   */
+    const float *t_rand;       /* [R,N_samples] jitter draws, NULL unless perturb (:121)   */
+    const float *noise0;       /* [R,N_samples] scaled sigma noise, coarse pass   (:264)   */
+    const float *noise1;       /* [R,N_samples+N_importance], fine pass                    */
+    const float *u;            /* [R,N_importance] sample_pdf draws; NULL => det  (utils.py:83-86) */
+    const float *t_lin_imp;    /* [N_importance] torch.linspace(0,1,N_importance), used when u == NULL */
+    /* outputs (NULL = not wanted) */
+    float *rgb_map, *disp_map, *acc_map;      /* [R,3] [R] [R]  from the last pass         */
+    float *rgb0, *disp0, *acc0;               /* coarse-pass maps (N_importance > 0)       */
+    float *z_std;                             /* [R]  std(z_samples, unbiased=False) (:168) */
+    float *raw;                               /* [R,S_last,out_ch] raw of the last pass    */
+    float *weights;                           /* [R,S_last]                                */
+    float *z_vals;                            /* [R,S_last]                                */
+    /* workspace: nerf_amd_render_rays_workspace(cfg, R, out_ch) bytes, 256-B aligned */
+    void   *workspace;
+    int64_t workspace_bytes;
+} nerf_amd_render_io;
+
+int64_t nerf_amd_render_rays_workspace(const nerf_amd_render_cfg *cfg, int64_t R, int32_t out_ch);
+int     nerf_amd_render_rays(const nerf_amd_render_cfg *cfg, const nerf_amd_model *coarse,
+                             const nerf_amd_model *fine /* NULL: reuse coarse (:150) */,
+                             const nerf_amd_render_io *io, int64_t R, void *stream);
+
+/* ------------------------------------------------------------------------
+ * a12/a13 + ray-batch assembly of Renderer.render   utils.py:33-71, render_utils.py:200-226
+ * Generates rays for flat pixel range [pix0, pix0+n) of an H x W image straight
+ * into the [n, 8|11] batch layout (o, d, near, far, viewdirs), NDC-warped when
+ * asked.  K = {fx, fy, cx, cy}; c2w is 12 floats (3x4 row-major), both HOST.
+ * c2w_static (HOST, may be NULL) reproduces c2w_staticcam (:208-210).
+ * ------------------------------------------------------------------------ */
+int nerf_amd_make_rays(int32_t H, int32_t W, const double *K4, const float *c2w, const float *c2w_static,
+                       int64_t pix0, int64_t n, float near, float far, int use_viewdirs, int ndc,
+                       float *rays_out, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Measurement hook (bench.py): while enabled, every field-MLP launch is
+ * bracketed by hipEvents on its own stream.  nerf_amd_profile_collect waits for
+ * the recorded events and returns, per class (0 = fp32 kernel, 1 = fused bf16
+ * kernel), the number of launches, the summed device time in milliseconds and
+ * the summed number of points, then forgets them.
+ * ------------------------------------------------------------------------ */
+int nerf_amd_profile_enable(int on);
+int nerf_amd_profile_collect(int64_t launches[2], double total_ms[2], double total_points[2]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERF_AMD_H */

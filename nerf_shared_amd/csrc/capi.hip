@@ -1,0 +1,362 @@
+// capi.hip -- the extern "C" boundary declared in include/nerf_amd.h.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <utility>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "program.h"
+
+using namespace na;
+
+namespace {
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+int hip_fail(hipError_t e, const char *what) {
+    return fail(NERF_AMD_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(expr)                                        \
+    do {                                                     \
+        hipError_t e_ = (expr);                              \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr);    \
+    } while (0)
+
+// ---- measurement hook: hipEvent pairs around field launches
+struct ProfRec { hipEvent_t a, b; int cls; double points; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_recs;
+std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_free;
+
+template <class T>
+int upload(T **dst, const std::vector<T> &src) {
+    *dst = nullptr;
+    if (src.empty()) return NERF_AMD_OK;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(dst), src.size() * sizeof(T)));
+    HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return NERF_AMD_OK;
+}
+size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+}  // namespace
+
+struct nerf_amd_model {
+    Program prog;
+    int device = 0;
+    FragDesc *d_frags = nullptr;
+    TileDesc *d_tiles = nullptr;
+    LayerF32 *d_layers = nullptr;
+    TensorDesc *d_tensors = nullptr;
+    const float **d_wptrs = nullptr, **d_bptrs = nullptr;
+    std::vector<const float *> h_wptrs, h_bptrs;
+    uint16_t *stream_bf16 = nullptr;
+    float *bias_bf16 = nullptr, *stream_f32 = nullptr, *bias_f32 = nullptr;
+    bool packed = false;
+};
+
+extern "C" {
+
+int nerf_amd_abi_version(void) { return NERF_AMD_ABI_VERSION; }
+const char *nerf_amd_last_error(void) { return g_err.c_str(); }
+
+int nerf_amd_model_create(const nerf_amd_arch *arch, int device, nerf_amd_model **out) {
+    if (!arch || !out) return fail(NERF_AMD_EINVAL, "null argument");
+    *out = nullptr;
+    nerf_amd_model *m = new (std::nothrow) nerf_amd_model;
+    if (!m) return fail(NERF_AMD_ENOMEM, "out of host memory");
+    const char *err = "";
+    if (build_program(*arch, m->prog, &err) != 0) {
+        delete m;
+        return fail(NERF_AMD_EINVAL, err);
+    }
+    m->device = device;
+    HIP_TRY(hipSetDevice(device));
+    const Program &p = m->prog;
+    int rc;
+    if ((rc = upload(&m->d_frags, p.frags)) || (rc = upload(&m->d_tiles, p.tiles)) ||
+        (rc = upload(&m->d_layers, p.layers)) || (rc = upload(&m->d_tensors, p.tensors))) {
+        nerf_amd_model_destroy(m);
+        return rc;
+    }
+    const size_t nt = p.tensors.size();
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&m->d_wptrs), nt * sizeof(float *));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->d_bptrs), nt * sizeof(float *));
+    if (e == hipSuccess && p.bf16_ok) {
+        e = hipMalloc(reinterpret_cast<void **>(&m->stream_bf16), p.frags.size() * 1024);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->bias_bf16), p.tiles.size() * 32 * sizeof(float));
+    }
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->stream_f32), (size_t)p.f32_stream_floats * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->bias_f32), (size_t)p.f32_bias_floats * sizeof(float));
+    if (e != hipSuccess) {
+        nerf_amd_model_destroy(m);
+        return hip_fail(e, "hipMalloc(model buffers)");
+    }
+    *out = m;
+    return NERF_AMD_OK;
+}
+
+int nerf_amd_model_update(nerf_amd_model *m, const float *const *weights, const float *const *biases,
+                          int n_tensors, void *stream) {
+    if (!m || !weights || !biases) return fail(NERF_AMD_EINVAL, "null argument");
+    const Program &p = m->prog;
+    if (n_tensors != (int)p.tensors.size())
+        return fail(NERF_AMD_EINVAL, "expected " + std::to_string(p.tensors.size()) + " parameter tensors, got " + std::to_string(n_tensors));
+    for (int i = 0; i < n_tensors; ++i)
+        if (!weights[i] || !biases[i]) return fail(NERF_AMD_EINVAL, "null parameter pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    m->h_wptrs.assign(weights, weights + n_tensors);
+    m->h_bptrs.assign(biases, biases + n_tensors);
+    HIP_TRY(hipMemcpyAsync(m->d_wptrs, m->h_wptrs.data(), n_tensors * sizeof(float *), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(m->d_bptrs, m->h_bptrs.data(), n_tensors * sizeof(float *), hipMemcpyHostToDevice, s));
+    int rc = launch_pack(p, m->d_frags, m->d_tiles, m->d_layers, m->d_tensors, m->d_wptrs, m->d_bptrs,
+                         m->stream_bf16, m->bias_bf16, m->stream_f32, m->bias_f32, s);
+    if (rc) return fail(rc, "pack launch failed");
+    m->packed = true;
+    return NERF_AMD_OK;
+}
+
+void nerf_amd_model_destroy(nerf_amd_model *m) {
+    if (!m) return;
+    (void)hipFree(m->d_frags); (void)hipFree(m->d_tiles); (void)hipFree(m->d_layers); (void)hipFree(m->d_tensors);
+    (void)hipFree(m->d_wptrs); (void)hipFree(m->d_bptrs);
+    (void)hipFree(m->stream_bf16); (void)hipFree(m->bias_bf16); (void)hipFree(m->stream_f32); (void)hipFree(m->bias_f32);
+    delete m;
+}
+
+int nerf_amd_model_supports_bf16(const nerf_amd_model *m) {
+    if (!m) return 0;
+    const nerf_amd_arch &a = m->prog.arch;
+    return m->prog.bf16_ok && a.i_embed == 0 && mlp_bf16_supported(a.multires, a.multires_views, a.use_viewdirs);
+}
+int nerf_amd_model_out_ch(const nerf_amd_model *m) { return m ? m->prog.out_ch : 0; }
+
+int nerf_amd_pack_bf16_host(const nerf_amd_arch *arch, const float *const *weights, const float *const *biases,
+                            int n_tensors, uint16_t *stream_out, int64_t *n_frags, float *bias_out, int64_t *n_bias) {
+    if (!arch) return fail(NERF_AMD_EINVAL, "null argument");
+    Program p;
+    const char *err = "";
+    if (build_program(*arch, p, &err) != 0) return fail(NERF_AMD_EINVAL, err);
+    if (!p.bf16_ok) return fail(NERF_AMD_EUNSUPPORTED, "architecture has no fused bf16 program (needs D=8, W=256, skips=[4])");
+    if (n_frags) *n_frags = (int64_t)p.frags.size();
+    if (n_bias) *n_bias = (int64_t)p.tiles.size() * 32;
+    if (stream_out || bias_out) {
+        if (!weights || !biases || n_tensors != (int)p.tensors.size()) return fail(NERF_AMD_EINVAL, "bad parameter list");
+        pack_bf16_host(p, weights, biases, stream_out, bias_out);
+    }
+    return NERF_AMD_OK;
+}
+
+int nerf_amd_embed(const float *x, int64_t n, int multires, float *out, void *stream) {
+    if (n < 0 || multires < 0 || multires > 20 || (n > 0 && (!x || !out))) return fail(NERF_AMD_EINVAL, "bad embed arguments");
+    int rc = launch_embed(x, n, multires, out, static_cast<hipStream_t>(stream));
+    return rc ? fail(rc, "embed launch failed") : NERF_AMD_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+int run_field(const nerf_amd_model *m, MlpArgs a, int precision, hipStream_t s) {
+    const Program &p = m->prog;
+    if (!m->packed) return fail(NERF_AMD_EINVAL, "model has no parameters yet (call nerf_amd_model_update)");
+    a.stream_bf16 = m->stream_bf16; a.bias_bf16 = m->bias_bf16;
+    a.stream_f32 = m->stream_f32; a.bias_f32 = m->bias_f32;
+    a.layers = m->d_layers; a.n_layers = (int)p.layers.size();
+    a.input_ch = p.input_ch; a.input_ch_views = p.input_ch_views; a.W = p.arch.W; a.lds_rows = p.lds_rows;
+    a.multires = p.arch.multires; a.multires_views = p.arch.multires_views; a.i_embed = p.arch.i_embed;
+    a.out_ch = p.out_ch;
+    if (p.arch.use_viewdirs && !a.viewdirs) return fail(NERF_AMD_EINVAL, "model has a view branch but no viewdirs were given");
+    if (!p.arch.use_viewdirs) a.viewdirs = nullptr;
+    int rc;
+    ProfRec rec{nullptr, nullptr, precision == NERF_AMD_PREC_BF16 ? 1 : 0, (double)a.P};
+    bool prof = false;
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (g_prof_on) {
+            prof = true;
+            if (!g_prof_free.empty()) {
+                rec.a = g_prof_free.back().first; rec.b = g_prof_free.back().second;
+                g_prof_free.pop_back();
+            } else if (hipEventCreate(&rec.a) != hipSuccess || hipEventCreate(&rec.b) != hipSuccess) {
+                prof = false;
+            }
+        }
+    }
+    if (prof) (void)hipEventRecord(rec.a, s);
+    struct Closer {
+        bool on; ProfRec r; hipStream_t s;
+        ~Closer() {
+            if (!on) return;
+            (void)hipEventRecord(r.b, s);
+            std::lock_guard<std::mutex> lk(g_prof_mu);
+            g_prof_recs.push_back(r);
+        }
+    } closer{prof, rec, s};
+    if (precision == NERF_AMD_PREC_BF16) {
+        if (!nerf_amd_model_supports_bf16(m))
+            return fail(NERF_AMD_EUNSUPPORTED, "fused bf16 kernel needs D=8, W=256, skips=[4], multires/views in {(10,4),(15,6)}; use NERF_AMD_PREC_FP32");
+        rc = launch_mlp_bf16(a, p.arch.multires, p.arch.multires_views, p.arch.use_viewdirs, p.n_frags_used, (int)p.tiles.size(), s);
+    } else if (precision == NERF_AMD_PREC_FP32) {
+        rc = launch_mlp_f32(a, s);
+    } else {
+        return fail(NERF_AMD_EINVAL, "unknown precision");
+    }
+    return rc ? fail(rc, "field kernel launch failed") : NERF_AMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nerf_amd_nerf_forward(const nerf_amd_model *m, const float *pts, const float *viewdirs,
+                          int64_t n_rays, int32_t n_samples, float *out, int precision, void *stream) {
+    if (!m || n_rays < 0 || n_samples < 1) return fail(NERF_AMD_EINVAL, "bad forward arguments");
+    if (n_rays == 0) return NERF_AMD_OK;
+    if (!pts || !out) return fail(NERF_AMD_EINVAL, "null pts/out");
+    MlpArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.pts = pts; a.viewdirs = viewdirs; a.vd_stride = 3;
+    a.P = n_rays * n_samples; a.S = n_samples; a.out = out;
+    return run_field(m, a, precision, static_cast<hipStream_t>(stream));
+}
+
+int nerf_amd_raw2outputs(const float *raw, int32_t raw_ch, const float *z_vals, const float *rays_d,
+                         int32_t rays_d_stride, const float *noise, int64_t R, int32_t S, int white_bkgd,
+                         float *rgb_map, float *disp_map, float *acc_map, float *weights, float *depth_map,
+                         void *stream) {
+    if (R < 0 || S < 1 || raw_ch < 4 || (R > 0 && (!raw || !z_vals || !rays_d))) return fail(NERF_AMD_EINVAL, "bad raw2outputs arguments");
+    int rc = launch_composite(raw, raw_ch, z_vals, rays_d, rays_d_stride, noise, R, S, white_bkgd, rgb_map, disp_map,
+                              acc_map, weights, depth_map, static_cast<hipStream_t>(stream));
+    return rc ? fail(rc, "composite launch failed") : NERF_AMD_OK;
+}
+
+int nerf_amd_sample_pdf(const float *bins, const float *weights, const float *u, const float *t_lin,
+                        int64_t R, int32_t n_bins, int32_t n_samples, float *samples, void *stream) {
+    if (R < 0 || n_bins < 2 || n_samples < 0 || (R > 0 && (!bins || !weights || !samples || (!u && !t_lin))))
+        return fail(NERF_AMD_EINVAL, "bad sample_pdf arguments");
+    int rc = launch_sample_pdf(bins, weights, u, t_lin, R, n_bins, n_samples, samples, static_cast<hipStream_t>(stream));
+    return rc ? fail(rc, "sample_pdf launch failed (n_bins must be <= 4096)") : NERF_AMD_OK;
+}
+
+int64_t nerf_amd_render_rays_workspace(const nerf_amd_render_cfg *cfg, int64_t R, int32_t out_ch) {
+    if (!cfg || R < 0) return -1;
+    const size_t Nc = cfg->N_samples, Nf = cfg->N_samples + cfg->N_importance;
+    size_t b = 0;
+    b += align_up(R * Nc * sizeof(float));                 // z coarse
+    b += align_up(R * Nc * out_ch * sizeof(float));        // raw coarse
+    b += align_up(R * Nc * sizeof(float));                 // weights coarse
+    if (cfg->N_importance > 0) {
+        b += align_up(R * Nf * sizeof(float));             // z fine
+        b += align_up(R * Nf * out_ch * sizeof(float));    // raw fine
+    }
+    return (int64_t)b;
+}
+
+int nerf_amd_render_rays(const nerf_amd_render_cfg *cfg, const nerf_amd_model *coarse, const nerf_amd_model *fine,
+                         const nerf_amd_render_io *io, int64_t R, void *stream) {
+    if (!cfg || !coarse || !io || R < 0) return fail(NERF_AMD_EINVAL, "null argument");
+    if (R == 0) return NERF_AMD_OK;
+    const int Nc = cfg->N_samples, Ni = cfg->N_importance, Nf = Nc + Ni;
+    if (Nc < 1 || Ni < 0) return fail(NERF_AMD_EINVAL, "bad sample counts");
+    if (Ni > 0 && Nc < 3) return fail(NERF_AMD_EINVAL, "hierarchical sampling needs N_samples >= 3");
+    if (!io->rays || (io->ray_ch != 8 && io->ray_ch != 11)) return fail(NERF_AMD_EINVAL, "rays must be [R,8] or [R,11]");
+    if (!io->t_vals) return fail(NERF_AMD_EINVAL, "t_vals missing");
+    if (cfg->perturb && !io->t_rand) return fail(NERF_AMD_EINVAL, "perturb set but t_rand missing");
+    if (cfg->use_noise && (!io->noise0 || (Ni > 0 && !io->noise1))) return fail(NERF_AMD_EINVAL, "use_noise set but noise missing");
+    if (Ni > 0 && !io->u && !io->t_lin_imp) return fail(NERF_AMD_EINVAL, "need u or t_lin_imp for sample_pdf");
+    const nerf_amd_model *fm = fine ? fine : coarse;
+    const int och = coarse->prog.out_ch;
+    if (Ni > 0 && fm->prog.out_ch != och) return fail(NERF_AMD_EINVAL, "coarse and fine models disagree on output channels");
+    if (och < 4) return fail(NERF_AMD_EINVAL, "field must output at least 4 channels");
+    const bool has_vd = io->ray_ch > 8;
+    if ((coarse->prog.arch.use_viewdirs != 0) != has_vd || (fm->prog.arch.use_viewdirs != 0) != has_vd)
+        return fail(NERF_AMD_EINVAL, "ray batch width does not match the models' use_viewdirs");
+    if (io->workspace_bytes < nerf_amd_render_rays_workspace(cfg, R, och) || !io->workspace)
+        return fail(NERF_AMD_EINVAL, "workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+
+    char *w = static_cast<char *>(io->workspace);
+    auto take = [&](size_t bytes) { float *p = reinterpret_cast<float *>(w); w += align_up(bytes); return p; };
+    float *z_c = take(R * Nc * sizeof(float));
+    float *raw_c = take(R * Nc * och * sizeof(float));
+    float *w_c = take(R * Nc * sizeof(float));
+    float *z_f = nullptr, *raw_f = nullptr;
+    if (Ni > 0) {
+        z_f = take(R * (size_t)Nf * sizeof(float));
+        raw_f = take(R * (size_t)Nf * och * sizeof(float));
+        if (io->z_vals) z_f = io->z_vals;
+        if (io->raw) raw_f = io->raw;
+    } else {
+        if (io->z_vals) z_c = io->z_vals;
+        if (io->raw) raw_c = io->raw;
+        if (io->weights) w_c = io->weights;
+    }
+
+    int rc = launch_coarse_z(io->rays, io->ray_ch, io->t_vals, cfg->perturb ? io->t_rand : nullptr, R, Nc,
+                             cfg->lindisp, cfg->perturb, z_c, s);
+    if (rc) return fail(rc, "coarse_z launch failed");
+
+    MlpArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.rays = io->rays; a.ray_stride = io->ray_ch; a.z_vals = z_c;
+    a.viewdirs = has_vd ? io->rays + 8 : nullptr; a.vd_stride = io->ray_ch;
+    a.P = R * Nc; a.S = Nc; a.out = raw_c;
+    if ((rc = run_field(coarse, a, cfg->precision, s))) return rc;
+
+    const float *rays_d = io->rays + 3;
+    if (Ni == 0) {
+        rc = launch_composite(raw_c, och, z_c, rays_d, io->ray_ch, cfg->use_noise ? io->noise0 : nullptr, R, Nc,
+                              cfg->white_bkgd, io->rgb_map, io->disp_map, io->acc_map, w_c, nullptr, s);
+        return rc ? fail(rc, "composite launch failed") : NERF_AMD_OK;
+    }
+    rc = launch_composite(raw_c, och, z_c, rays_d, io->ray_ch, cfg->use_noise ? io->noise0 : nullptr, R, Nc,
+                          cfg->white_bkgd, io->rgb0, io->disp0, io->acc0, w_c, nullptr, s);
+    if (rc) return fail(rc, "composite launch failed");
+    rc = launch_resample(z_c, w_c, io->u, io->t_lin_imp, R, Nc, Ni, z_f, io->z_std, s);
+    if (rc) return fail(rc, "resample launch failed (N_samples + N_importance must be <= 4096)");
+    a.z_vals = z_f; a.P = R * (int64_t)Nf; a.S = Nf; a.out = raw_f;
+    if ((rc = run_field(fm, a, cfg->precision, s))) return rc;
+    rc = launch_composite(raw_f, och, z_f, rays_d, io->ray_ch, cfg->use_noise ? io->noise1 : nullptr, R, Nf,
+                          cfg->white_bkgd, io->rgb_map, io->disp_map, io->acc_map, io->weights, nullptr, s);
+    return rc ? fail(rc, "composite launch failed") : NERF_AMD_OK;
+}
+
+int nerf_amd_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return NERF_AMD_OK;
+}
+
+int nerf_amd_profile_collect(int64_t launches[2], double total_ms[2], double total_points[2]) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (int c = 0; c < 2; ++c) { launches[c] = 0; total_ms[c] = 0.0; total_points[c] = 0.0; }
+    for (const ProfRec &r : g_prof_recs) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            launches[r.cls] += 1; total_ms[r.cls] += ms; total_points[r.cls] += r.points;
+        }
+        g_prof_free.emplace_back(r.a, r.b);
+    }
+    g_prof_recs.clear();
+    return NERF_AMD_OK;
+}
+
+int nerf_amd_make_rays(int32_t H, int32_t W, const double *K4, const float *c2w, const float *c2w_static,
+                       int64_t pix0, int64_t n, float near, float far, int use_viewdirs, int ndc,
+                       float *rays_out, void *stream) {
+    if (H < 1 || W < 1 || !K4 || !c2w || pix0 < 0 || n < 0 || pix0 + n > (int64_t)H * W || (n > 0 && !rays_out))
+        return fail(NERF_AMD_EINVAL, "bad make_rays arguments");
+    int rc = launch_make_rays(H, W, K4, c2w, c2w_static, pix0, n, near, far, use_viewdirs, ndc, rays_out,
+                              static_cast<hipStream_t>(stream));
+    return rc ? fail(rc, "make_rays launch failed") : NERF_AMD_OK;
+}
+
+}  // extern "C"

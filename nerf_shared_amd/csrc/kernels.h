@@ -1,0 +1,62 @@
+// kernels.h -- internal launch interfaces between the C ABI (capi.hip) and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "program.h"
+
+namespace na {
+
+// Arguments of both MLP kernels (fused bf16 and generic fp32).
+struct MlpArgs {
+    // packed parameters (device)
+    const uint16_t *stream_bf16;   // bf16 A-fragment stream
+    const float *bias_bf16;        // [n_tiles][2][16]
+    const float *stream_f32;       // fp32 fragment stream
+    const float *bias_f32;
+    const LayerF32 *layers;        // device copy of the fp32 program
+    int32_t n_layers;
+    int32_t input_ch, input_ch_views, W, lds_rows;
+    int32_t multires, multires_views, i_embed;
+    // points: either explicit pts [P,3], or rays + z_vals (pts = o + d*z)
+    const float *pts;
+    const float *rays;             // [R, ray_stride]: o(3) d(3) ...
+    const float *z_vals;           // [R, S]
+    const float *viewdirs;         // row stride vd_stride, NULL without view branch
+    int32_t ray_stride, vd_stride;
+    int64_t P;                     // number of points = R * S
+    int32_t S;                     // samples per ray (ray index = p / S)
+    int32_t out_ch;
+    float *out;                    // [P, out_ch]
+};
+
+bool mlp_bf16_supported(int multires, int multires_views, int use_viewdirs);
+int launch_mlp_bf16(const MlpArgs &a, int multires, int multires_views, int use_viewdirs,
+                    int n_frags_used, int n_tiles, hipStream_t s);
+int launch_mlp_f32(const MlpArgs &a, hipStream_t s);
+int launch_embed(const float *x, int64_t n, int multires, float *out, hipStream_t s);
+
+// pack.hip
+int launch_pack(const Program &p, const FragDesc *d_frags, const TileDesc *d_tiles, const LayerF32 *d_layers,
+                const TensorDesc *d_tensors, const float *const *d_weight_ptrs, const float *const *d_bias_ptrs,
+                uint16_t *stream_bf16, float *bias_bf16, float *stream_f32, float *bias_f32, hipStream_t s);
+void pack_bf16_host(const Program &p, const float *const *w, const float *const *b, uint16_t *stream, float *bias);
+
+// render.hip
+struct RenderCfgK {
+    int32_t Nc, Ni, perturb, lindisp, white_bkgd;
+};
+int launch_coarse_z(const float *rays, int ray_stride, const float *t_vals, const float *t_rand,
+                    int64_t R, int Nc, int lindisp, int perturb, float *z, hipStream_t s);
+int launch_composite(const float *raw, int raw_ch, const float *z, const float *rays_d, int rays_d_stride,
+                     const float *noise, int64_t R, int S, int white_bkgd, float *rgb, float *disp, float *acc,
+                     float *weights, float *depth, hipStream_t s);
+int launch_sample_pdf(const float *bins, const float *weights, const float *u, const float *t_lin,
+                      int64_t R, int n_bins, int n_samples, float *samples, hipStream_t s);
+int launch_resample(const float *z_coarse, const float *weights, const float *u, const float *t_lin,
+                    int64_t R, int Nc, int Ni, float *z_fine, float *z_std, hipStream_t s);
+int launch_make_rays(int H, int W, const double *K4, const float *c2w, const float *c2w_static,
+                     int64_t pix0, int64_t n, float near, float far, int use_viewdirs, int ndc,
+                     float *rays_out, hipStream_t s);
+
+}  // namespace na

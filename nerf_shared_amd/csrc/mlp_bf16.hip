@@ -1,0 +1,322 @@
+// mlp_bf16.hip -- fused positional-encoding + 8x256 NeRF MLP for gfx950 (MI355X).
+//
+// Replaces NeRF.forward + NeRF.MLP (/root/reference/nerf_shared/nerf.py:96-134)
+// together with the point construction pts = o + d*z of render_rays
+// (/root/reference/nerf_shared/render_utils.py:131,148) for the canonical
+// architecture D=8, W=256, skips=[4].
+//
+// Design:
+//  * The network is evaluated transposed, H_out^T = W . H_in^T, with
+//    v_mfma_f32_32x32x16_bf16.  One wave owns 32 points (MFMA columns) and keeps
+//    the whole 256-wide activation of those points in registers: the fp32
+//    accumulator tile of layer l, converted in place to bf16, *is* the B operand
+//    of layer l+1 (no LDS round trip, no lane movement) because the weight
+//    stream is pre-permuted to the accumulator's row order (program.h).
+//  * Weights are the A operand.  A workgroup of 8 waves (256 points) streams the
+//    packed 1-KiB fragments once from L2 into a 3 x 16 KiB LDS ring with
+//    global_load_lds_dwordx4 (LDS-DMA, no VGPR staging); every wave then reads
+//    each fragment with one conflict-free ds_read_b128 per MFMA.
+//  * Positional encodings are generated in registers straight into B-operand
+//    layout (sin features on lanes 0-31, cos features on lanes 32-63).
+//  * bias add = accumulator initialisation from an LDS table; ReLU + bf16
+//    conversion happen on the accumulator registers.
+#include <hip/hip_runtime.h>
+#include <utility>
+
+#include "kernels.h"
+#include "program.h"
+
+namespace na {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int WG_THREADS = 512;
+constexpr int WG_WAVES = 8;
+constexpr int WG_POINTS = WG_WAVES * 32;
+constexpr int BLOCK_BYTES = BLOCK_FRAGS * 1024;
+constexpr int RING_BYTES = RING_SLOTS * BLOCK_BYTES;
+constexpr int PREFETCH = RING_SLOTS - 1;   // blocks in flight ahead of the consumer
+constexpr int PIECES_PER_WAVE = BLOCK_FRAGS / WG_WAVES;
+
+template <int N, class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl<N>(f, std::make_integer_sequence<int, N>{});
+}
+
+struct Ctx {
+    const char *gstream;     // this lane's view of the fragment stream (base + lane*16)
+    const char *ring_lane;   // LDS ring + lane*16
+    uint32_t ring_u32;       // LDS byte address of the ring
+    const float *bias_half;  // LDS bias table + (lane>>5)*16
+    int wave;
+};
+
+// LDS-DMA of this wave's share (2 x 1 KiB) of stream block BB into its ring slot.
+template <int BB>
+__device__ __forceinline__ void issue_block(const Ctx &c) {
+    constexpr int slot = BB % RING_SLOTS;
+#pragma unroll
+    for (int i = 0; i < PIECES_PER_WAVE; ++i) {
+        const int piece = c.wave * PIECES_PER_WAVE + i;
+        const char *g = c.gstream + (size_t)BB * BLOCK_BYTES + piece * 1024;
+        const uint32_t l = c.ring_u32 + slot * BLOCK_BYTES + piece * 1024;   // wave-uniform
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, off\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(g), "s"(l)
+            : "memory");
+    }
+}
+
+// Block boundary: my pieces of block B have landed (vmcnt), my reads of the
+// slot that is about to be refilled are done (lgkmcnt), everyone agrees
+// (s_barrier); then refill the slot block B-1 lived in with block B+PREFETCH.
+template <int B, int NB>
+__device__ __forceinline__ void block_sync(const Ctx &c) {
+    constexpr int ahead = (NB - 1 - B) < (PREFETCH - 1) ? (NB - 1 - B) : (PREFETCH - 1);
+    if constexpr (ahead * PIECES_PER_WAVE == 2)
+        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if constexpr (ahead * PIECES_PER_WAVE == 0)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else
+        static_assert(ahead * PIECES_PER_WAVE == 0 || ahead * PIECES_PER_WAVE == 2, "extend the vmcnt table");
+    if constexpr (B + PREFETCH < NB) issue_block<B + PREFETCH>(c);
+}
+
+template <int n>
+__device__ __forceinline__ bf16x8 ring_frag(const Ctx &c) {
+    return *reinterpret_cast<const bf16x8 *>(c.ring_lane + ((n % (RING_SLOTS * BLOCK_FRAGS)) << 10));
+}
+
+// One 32-row output tile: acc = bias + sum over K1 k-steps of x1 and K2 of x2.
+template <int F0, int T, int K1, int K2, int NB>
+__device__ __forceinline__ f32x16 tile(const Ctx &c, const bf16x8 *x1, const bf16x8 *x2) {
+    f32x16 acc;
+    {
+        const f32x4 *b = reinterpret_cast<const f32x4 *>(c.bias_half + T * 32);
+        f32x4 b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc[i] = b0[i]; acc[4 + i] = b1[i]; acc[8 + i] = b2[i]; acc[12 + i] = b3[i]; }
+    }
+    static_for<K1>([&](auto k_) {
+        constexpr int k = k_, n = F0 + k;
+        if constexpr (n % BLOCK_FRAGS == 0) block_sync<n / BLOCK_FRAGS, NB>(c);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring_frag<n>(c), x1[k], acc, 0, 0, 0);
+    });
+    static_for<K2>([&](auto k_) {
+        constexpr int k = k_, n = F0 + K1 + k;
+        if constexpr (n % BLOCK_FRAGS == 0) block_sync<n / BLOCK_FRAGS, NB>(c);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring_frag<n>(c), x2[k], acc, 0, 0, 0);
+    });
+    return acc;
+}
+
+// ReLU as one integer max on the fp32 bits (negative floats are negative ints);
+// fmaxf would cost a second v_max to canonicalise a possible sNaN.
+__device__ __forceinline__ float relu_bits(float v) {
+    int i = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, i > 0 ? i : 0);
+}
+
+template <bool RELU>
+__device__ __forceinline__ void pack_tile(const f32x16 &acc, bf16x8 &lo, bf16x8 &hi) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        float a = acc[r], b = acc[8 + r];
+        if (RELU) { a = relu_bits(a); b = relu_bits(b); }
+        lo[r] = (__bf16)a;
+        hi[r] = (__bf16)b;
+    }
+}
+
+// A full hidden layer: NT output tiles -> y[2*NT] (next layer's B fragments).
+template <int F0, int T0, int NT, int K1, int K2, bool RELU, int NB>
+__device__ __forceinline__ void layer(const Ctx &c, const bf16x8 *x1, const bf16x8 *x2, bf16x8 *y) {
+    static_for<NT>([&](auto t_) {
+        constexpr int t = t_;
+        f32x16 acc = tile<F0 + t * (K1 + K2), T0 + t, K1, K2, NB>(c, x1, x2);
+        pack_tile<RELU>(acc, y[2 * t], y[2 * t + 1]);
+    });
+}
+
+// Positional encoding of (x0,x1,x2) into B-operand layout (program.h, FRAG_GEN):
+// lane half 0 evaluates sin(2^f x), half 1 cos(2^f x) = sin(2^f x + pi/2).
+// The argument is reduced exactly: t = x/(2 pi) is kept as an unevaluated fp32
+// sum th + tl, doubling th and taking v_fract is exact, and v_sin_f32 takes
+// revolutions.  Absolute error is ~1e-6, far below the bf16 quantum (4e-3).
+template <int L, int K>
+__device__ __forceinline__ void encode(float x0, float x1, float x2, int h, bf16x8 *out) {
+    constexpr float INV2PI_HI = 0.15915494f;                       // fl32(1/(2 pi))
+    constexpr float INV2PI_LO = (float)(0.15915494309189535 - (double)INV2PI_HI);
+    float x[3] = {x0, x1, x2};
+    const float phase = h ? 0.25f : 0.0f;
+    float ra[3], tl[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float th = x[c] * INV2PI_HI;
+        tl[c] = __builtin_fmaf(x[c], INV2PI_HI, -th) + x[c] * INV2PI_LO;
+        ra[c] = __builtin_amdgcn_fractf(th);
+    }
+    float vals[8 * K];
+#pragma unroll
+    for (int e = 0; e < 8 * K; ++e) vals[e] = 0.0f;
+#pragma unroll
+    for (int f = 0; f < L; ++f) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            vals[3 * f + c] = __builtin_amdgcn_sinf(ra[c] + (tl[c] + phase));
+            ra[c] = __builtin_amdgcn_fractf(ra[c] * 2.0f);   // exact
+            tl[c] *= 2.0f;                                   // exact
+        }
+    }
+    vals[3 * L] = h ? x2 : x0;
+    vals[3 * L + 1] = h ? 0.0f : x1;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[k][j] = (__bf16)vals[8 * k + j];
+}
+
+template <int LX, int LD, bool VD>
+struct Layout {
+    static constexpr int KE = gen_ksteps(LX);
+    static constexpr int KD = VD ? gen_ksteps(LD) : 0;
+    static constexpr int F_L0 = 0;
+    static constexpr int F_L1 = F_L0 + 8 * KE;
+    static constexpr int F_L5 = F_L1 + 4 * 128;
+    static constexpr int F_L6 = F_L5 + 8 * (KE + 16);
+    static constexpr int F_HEAD = F_L6 + 2 * 128;
+    // viewdirs head
+    static constexpr int F_FEAT = F_HEAD;
+    static constexpr int F_ALPHA = F_FEAT + 128;
+    static constexpr int F_VIEWS = F_ALPHA + 16;
+    static constexpr int F_RGB = F_VIEWS + 4 * (16 + KD);
+    static constexpr int F_END = VD ? F_RGB + 8 : F_HEAD + 16;
+    static constexpr int NB = (F_END + BLOCK_FRAGS - 1) / BLOCK_FRAGS;
+    static constexpr int T_HEAD = 64;
+    static constexpr int N_TILES = VD ? 64 + 8 + 1 + 4 + 1 : 64 + 1;
+};
+
+template <int LX, int LD, bool VD>
+__global__ __launch_bounds__(WG_THREADS, 2) void mlp_bf16_kernel(MlpArgs a) {
+    using Lay = Layout<LX, LD, VD>;
+    constexpr int KE = Lay::KE, KD = Lay::KD, NB = Lay::NB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *bias_lds = reinterpret_cast<float *>(smem + RING_BYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int h = lane >> 5;
+    Ctx c;
+    c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    c.gstream = reinterpret_cast<const char *>(a.stream_bf16) + lane * 16;
+    c.ring_lane = smem + lane * 16;
+    c.ring_u32 = (uint32_t)(uintptr_t)smem;
+    c.bias_half = bias_lds + h * 16;
+
+    static_for<PREFETCH>([&](auto b_) { constexpr int b = b_; if constexpr (b < NB) issue_block<b>(c); });
+
+    for (int i = tid; i < Lay::N_TILES * 32; i += WG_THREADS) bias_lds[i] = a.bias_bf16[i];
+
+    // ---- this lane's point (both lane halves hold the same point)
+    const int64_t p = (int64_t)blockIdx.x * WG_POINTS + c.wave * 32 + (lane & 31);
+    const bool valid = p < a.P;
+    const int64_t pc = valid ? p : a.P - 1;
+    const int64_t ray = (int64_t)((uint32_t)pc / (uint32_t)a.S);   // P < 2^31 (checked at launch)
+    float x0, x1, x2;
+    if (a.pts) {
+        x0 = a.pts[3 * pc + 0]; x1 = a.pts[3 * pc + 1]; x2 = a.pts[3 * pc + 2];
+    } else {
+        const float *r = a.rays + ray * a.ray_stride;
+        const float z = a.z_vals[pc];
+        x0 = __fadd_rn(r[0], __fmul_rn(r[3], z));
+        x1 = __fadd_rn(r[1], __fmul_rn(r[4], z));
+        x2 = __fadd_rn(r[2], __fmul_rn(r[5], z));
+    }
+    bf16x8 E[KE];
+    encode<LX, KE>(x0, x1, x2, h, E);
+    bf16x8 Dv[VD ? KD : 1];
+    if constexpr (VD) {
+        const float *d = a.viewdirs + ray * a.vd_stride;
+        encode<LD, KD>(d[0], d[1], d[2], h, Dv);
+    }
+
+    bf16x8 A[16], B[16];
+    layer<Lay::F_L0, 0, 8, KE, 0, true, NB>(c, E, E, A);
+    layer<Lay::F_L1 + 0 * 128, 8, 8, 16, 0, true, NB>(c, A, A, B);
+    layer<Lay::F_L1 + 1 * 128, 16, 8, 16, 0, true, NB>(c, B, B, A);
+    layer<Lay::F_L1 + 2 * 128, 24, 8, 16, 0, true, NB>(c, A, A, B);
+    layer<Lay::F_L1 + 3 * 128, 32, 8, 16, 0, true, NB>(c, B, B, A);
+    layer<Lay::F_L5, 40, 8, KE, 16, true, NB>(c, E, A, B);          // skip: [input_pts | h]
+    layer<Lay::F_L6, 48, 8, 16, 0, true, NB>(c, B, B, A);
+    layer<Lay::F_L6 + 128, 56, 8, 16, 0, true, NB>(c, A, A, B);     // h7 in B
+
+    if constexpr (VD) {
+        layer<Lay::F_FEAT, 64, 8, 16, 0, false, NB>(c, B, B, A);                       // feature (no activation)
+        f32x16 alpha = tile<Lay::F_ALPHA, 72, 16, 0, NB>(c, B, B);                     // row 0 = sigma
+        layer<Lay::F_VIEWS, 73, 4, 16, KD, true, NB>(c, A, Dv, B);                     // views_linears.0
+        f32x16 rgb = tile<Lay::F_RGB, 77, 8, 0, NB>(c, B, B);                          // rows 0..2
+        if (valid && h == 0) {
+            f32x4 o = {rgb[0], rgb[1], rgb[2], alpha[0]};
+            *reinterpret_cast<f32x4 *>(a.out + 4 * p) = o;
+        }
+    } else {
+        f32x16 o = tile<Lay::F_HEAD, 64, 16, 0, NB>(c, B, B);
+        if (valid) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = acc_row(r, h);
+                if (row < a.out_ch) a.out[(int64_t)a.out_ch * p + row] = o[r];
+            }
+        }
+    }
+}
+
+template <int LX, int LD, bool VD>
+static int launch_one(const MlpArgs &a, int n_frags_used, int n_tiles, hipStream_t s) {
+    using Lay = Layout<LX, LD, VD>;
+    if (n_frags_used != Lay::F_END || n_tiles != Lay::N_TILES) return NERF_AMD_EINVAL;
+    const size_t lds = RING_BYTES + (size_t)Lay::N_TILES * 32 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_bf16_kernel<LX, LD, VD>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return NERF_AMD_EHIP;
+        attr_set = true;
+    }
+    const int64_t groups = (a.P + WG_POINTS - 1) / WG_POINTS;
+    if (groups <= 0) return NERF_AMD_OK;
+    if (a.P >= (int64_t)1 << 31) return NERF_AMD_EINVAL;
+    hipLaunchKernelGGL((mlp_bf16_kernel<LX, LD, VD>), dim3((unsigned)groups), dim3(WG_THREADS), lds, s, a);
+    return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
+}
+
+bool mlp_bf16_supported(int multires, int multires_views, int use_viewdirs) {
+    if (use_viewdirs) return (multires == 10 && multires_views == 4) || (multires == 15 && multires_views == 6);
+    return multires == 10 || multires == 15;
+}
+
+int launch_mlp_bf16(const MlpArgs &a, int multires, int multires_views, int use_viewdirs,
+                    int n_frags_used, int n_tiles, hipStream_t s) {
+    if (use_viewdirs) {
+        if (multires == 10 && multires_views == 4) return launch_one<10, 4, true>(a, n_frags_used, n_tiles, s);
+        if (multires == 15 && multires_views == 6) return launch_one<15, 6, true>(a, n_frags_used, n_tiles, s);
+    } else {
+        if (multires == 10) return launch_one<10, 0, false>(a, n_frags_used, n_tiles, s);
+        if (multires == 15) return launch_one<15, 0, false>(a, n_frags_used, n_tiles, s);
+    }
+    return NERF_AMD_EUNSUPPORTED;
+}
+
+}  // namespace na

@@ -1,0 +1,155 @@
+// mlp_fp32.hip -- exact-fp32 NeRF field for any reference architecture, and the
+// standalone positional encoding.
+//
+// Replaces Embedder.embed (/root/reference/nerf_shared/nerf.py:16-41) and
+// NeRF.forward + NeRF.MLP (nerf.py:96-134) for every D / W (multiple of 32) /
+// skips / multires / viewdirs combination the reference constructor accepts.
+// This is the parity path (v_mfma_f32_32x32x2_f32 is a bit-exact fp32 fma
+// chain) and the fallback for architectures the fused bf16 kernel does not
+// cover; it is still MFMA code, just at the fp32 rate (1/16 of bf16).
+//
+// One workgroup (4 waves) evaluates 32 points.  Activations live in LDS as
+// [feature row][32 points] fp32 in two ping-pong buffers whose rows are
+//   [0, input_ch)                    encoded xyz      (kept for the skip concat)
+//   [input_ch, input_ch+W)           hidden
+//   [input_ch+W, +input_ch_views)    encoded view dir (kept for the view concat)
+// so both torch.cat calls of the reference (nerf.py:117-118, :123) are just a
+// different first row.  The network is evaluated transposed (weights = A
+// operand, points = B operand); wave w computes output tiles w, w+4, ...
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "program.h"
+
+namespace na {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// Feature `col` of the reference embedding of x (nerf.py:32-41): accurate sinf/cosf.
+__device__ __forceinline__ float embed_feature(const float x[3], int col, int i_embed) {
+    if (col < 3 || i_embed == -1) return x[col];
+    const int g = col - 3, f = g / 6, rem = g % 6;
+    const float arg = x[rem % 3] * __builtin_ldexpf(1.0f, f);   // 2^f exact, as 2.**linspace in fp32
+    return rem < 3 ? sinf(arg) : cosf(arg);
+}
+
+__global__ __launch_bounds__(256) void embed_kernel(const float *x, int64_t n, int multires, float *out) {
+    const int dim = 3 + 6 * multires;
+    const int64_t total = n * dim;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i / dim;
+        const int col = (int)(i - p * dim);
+        const float v[3] = {x[3 * p], x[3 * p + 1], x[3 * p + 2]};
+        out[i] = embed_feature(v, col, 0);
+    }
+}
+
+int launch_embed(const float *x, int64_t n, int multires, float *out, hipStream_t s) {
+    if (n <= 0) return NERF_AMD_OK;
+    const int64_t total = n * (3 + 6 * multires);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n, multires, out);
+    return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
+}
+
+__global__ __launch_bounds__(256) void mlp_f32_kernel(MlpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int rows = a.lds_rows;
+    float *buf[2] = {lds, lds + rows * 32};
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pt = lane & 31, h = lane >> 5;
+
+    for (int i = tid; i < 2 * rows * 32; i += 256) lds[i] = 0.0f;
+    __syncthreads();
+
+    // ---- encode this tile's 32 points into both buffers
+    const int64_t p0 = (int64_t)blockIdx.x * 32;
+    for (int i = tid; i < (a.input_ch + a.input_ch_views) * 32; i += 256) {
+        const int row = i >> 5, q = i & 31;
+        int64_t p = p0 + q;
+        if (p >= a.P) p = a.P - 1;
+        const int64_t ray = (int64_t)((uint32_t)p / (uint32_t)a.S);
+        float v[3];
+        float val;
+        if (row < a.input_ch) {
+            if (a.pts) {
+                v[0] = a.pts[3 * p]; v[1] = a.pts[3 * p + 1]; v[2] = a.pts[3 * p + 2];
+            } else {
+                const float *r = a.rays + ray * a.ray_stride;
+                const float z = a.z_vals[p];
+                v[0] = __fadd_rn(r[0], __fmul_rn(r[3], z));
+                v[1] = __fadd_rn(r[1], __fmul_rn(r[4], z));
+                v[2] = __fadd_rn(r[2], __fmul_rn(r[5], z));
+            }
+            val = embed_feature(v, row, a.i_embed);
+            buf[0][row * 32 + q] = val;
+            buf[1][row * 32 + q] = val;
+        } else {
+            const float *d = a.viewdirs + ray * a.vd_stride;
+            v[0] = d[0]; v[1] = d[1]; v[2] = d[2];
+            val = embed_feature(v, row - a.input_ch, a.i_embed);
+            const int dst = a.input_ch + a.W + (row - a.input_ch);
+            buf[0][dst * 32 + q] = val;
+            buf[1][dst * 32 + q] = val;
+        }
+    }
+    __syncthreads();
+
+    const int64_t p = p0 + pt;
+    const bool valid = p < a.P;
+
+    for (int li = 0; li < a.n_layers; ++li) {
+        const LayerF32 L = a.layers[li];
+        const float *in = buf[L.in_buf] + L.in_row * 32 + pt;
+        float *outb = buf[L.in_buf ^ 1];
+        const int tiles = (L.n_out + 31) >> 5, groups = (L.n_in + 7) >> 3;
+        for (int t = wave; t < tiles; t += 4) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = a.bias_f32[L.bias_off + 32 * t + acc_row(r, h)];
+            const f32x4 *wf = reinterpret_cast<const f32x4 *>(a.stream_f32 + L.frag_off + (int64_t)t * groups * 256) + lane;
+#pragma unroll 4
+            for (int g = 0; g < groups; ++g) {
+                const f32x4 w = wf[(int64_t)g * 64];
+                const float *bp = in + (8 * g + h) * 32;
+                const float b0 = bp[0], b1 = bp[64], b2 = bp[128], b3 = bp[192];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], b0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1], b1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2], b2, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[3], b3, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * t + acc_row(r, h);
+                float v = acc[r];
+                if (L.relu) v = fmaxf(v, 0.0f);
+                if (row < L.n_out) {
+                    if (L.out_row >= 0) outb[(L.out_row + row) * 32 + pt] = v;
+                    else if (valid) a.out[(int64_t)a.out_ch * p + L.out_col + row] = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int launch_mlp_f32(const MlpArgs &a, hipStream_t s) {
+    if (a.P <= 0) return NERF_AMD_OK;
+    if (a.P >= (int64_t)1 << 31) return NERF_AMD_EINVAL;
+    const size_t lds = (size_t)2 * a.lds_rows * 32 * sizeof(float);
+    if (lds > 160 * 1024) return NERF_AMD_EUNSUPPORTED;
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_f32_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return NERF_AMD_EHIP;
+        attr_lds = lds;
+    }
+    const int64_t blocks = (a.P + 31) / 32;
+    hipLaunchKernelGGL(mlp_f32_kernel, dim3((unsigned)blocks), dim3(256), lds, s, a);
+    return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
+}
+
+}  // namespace na

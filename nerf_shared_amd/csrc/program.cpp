@@ -1,0 +1,109 @@
+// program.cpp -- host-side construction of the fragment programs (see program.h).
+#include "program.h"
+
+namespace na {
+
+namespace {
+struct Seg { int kind, col_base, len, nk, L; };
+}
+
+int build_program(const nerf_amd_arch &a, Program &p, const char **err) {
+    p = Program();
+    p.arch = a;
+    if (a.D < 1 || a.D > 64 || a.W < 32 || a.W % 32 != 0 || a.W > 1024) { *err = "D/W out of range (W must be a multiple of 32)"; return -1; }
+    if (a.n_skips < 0 || a.n_skips > NERF_AMD_MAX_SKIPS) { *err = "too many skips"; return -1; }
+    if (a.i_embed != 0 && a.i_embed != -1) { *err = "i_embed must be 0 or -1"; return -1; }
+    if (a.multires < 0 || a.multires > 20 || a.multires_views < 0 || a.multires_views > 20) { *err = "multires out of range"; return -1; }
+    const int Lx = a.i_embed == -1 ? 0 : a.multires;
+    const int Ld = a.i_embed == -1 ? 0 : a.multires_views;
+    p.input_ch = embed_dim(a.multires, a.i_embed);
+    p.input_ch_views = a.use_viewdirs ? embed_dim(a.multires_views, a.i_embed) : 0;
+    p.out_ch = a.use_viewdirs ? 4 : a.output_ch;
+    if (p.out_ch < 1 || p.out_ch > 32) { *err = "output_ch must be in 1..32"; return -1; }
+    auto is_skip = [&](int i) { for (int s = 0; s < a.n_skips; ++s) if (a.skips[s] == i) return true; return false; };
+    if (is_skip(a.D - 1)) { *err = "a skip on the last pts_linear feeds W+input_ch columns into a W-column head (the reference fails too)"; return -1; }
+    const int W = a.W, D = a.D;
+
+    // ---- tensors in nerf_amd.h order
+    for (int i = 0; i < D; ++i) {
+        int n_in = i == 0 ? p.input_ch : (is_skip(i - 1) ? W + p.input_ch : W);
+        p.tensors.push_back({W, n_in});
+    }
+    if (a.use_viewdirs) {
+        p.tensors.push_back({W, W});                          // feature_linear
+        p.tensors.push_back({1, W});                          // alpha_linear
+        p.tensors.push_back({W / 2, W + p.input_ch_views});   // views_linears.0
+        p.tensors.push_back({3, W / 2});                      // rgb_linear
+    } else {
+        p.tensors.push_back({a.output_ch, W});                // output_linear
+    }
+
+    // ---- fp32 generic program
+    {
+        p.lds_rows = (p.input_ch + W + p.input_ch_views + 8 + 1) & ~1;   // +8: k-groups of 8 may read past the last valid row
+        int cur = 0;
+        int64_t foff = 0, boff = 0;
+        auto push = [&](int tensor, int in_row, int out_row, int out_col, int relu, bool flip) {
+            LayerF32 l;
+            l.tensor = tensor; l.n_out = p.tensors[tensor].n_out; l.n_in = p.tensors[tensor].n_in;
+            l.in_row = in_row; l.out_row = out_row; l.out_col = out_col; l.relu = relu; l.in_buf = cur;
+            l.frag_off = foff; l.bias_off = boff;
+            int tiles = (l.n_out + 31) / 32, groups = (l.n_in + 7) / 8;
+            foff += (int64_t)tiles * groups * 256;
+            boff += tiles * 32;
+            p.layers.push_back(l);
+            if (flip) cur ^= 1;
+        };
+        for (int i = 0; i < D; ++i) {
+            int in_row = (i == 0 || is_skip(i - 1)) ? 0 : p.input_ch;
+            push(i, in_row, p.input_ch, 0, 1, true);
+        }
+        if (a.use_viewdirs) {
+            push(D + 1, p.input_ch, -1, 3, 0, false);          // alpha -> out[:,3]
+            push(D + 0, p.input_ch, p.input_ch, 0, 0, true);   // feature
+            push(D + 2, p.input_ch, p.input_ch, 0, 1, true);   // views
+            push(D + 3, p.input_ch, -1, 0, 0, false);          // rgb -> out[:,0:3]
+        } else {
+            push(D, p.input_ch, -1, 0, 0, false);
+        }
+        p.f32_stream_floats = foff;
+        p.f32_bias_floats = boff;
+    }
+
+    // ---- bf16 fused program: canonical D=8, W=256, skips=[4]
+    p.bf16_ok = (D == 8 && W == 256 && a.n_skips == 1 && a.skips[0] == 4);
+    if (p.bf16_ok) {
+        p.KE = gen_ksteps(Lx);
+        p.KD = a.use_viewdirs ? gen_ksteps(Ld) : 0;
+        auto add_layer = [&](int tensor, std::initializer_list<Seg> segs) {
+            int n_out = p.tensors[tensor].n_out;
+            for (int t = 0; t < (n_out + 31) / 32; ++t) {
+                p.tiles.push_back({tensor, 32 * t});
+                for (const Seg &s : segs)
+                    for (int ks = 0; ks < s.nk; ++ks)
+                        p.frags.push_back({tensor, s.kind, 32 * t, s.col_base, ks, s.len, s.L, 0});
+            }
+        };
+        const Seg E{FRAG_GEN, 0, p.input_ch, p.KE, Lx};
+        const Seg H{FRAG_ACC, 0, W, 16, 0};
+        add_layer(0, {E});
+        for (int i = 1; i <= 4; ++i) add_layer(i, {H});
+        add_layer(5, {E, Seg{FRAG_ACC, p.input_ch, W, 16, 0}});
+        add_layer(6, {H});
+        add_layer(7, {H});
+        if (a.use_viewdirs) {
+            add_layer(8, {H});                                                         // feature
+            add_layer(9, {H});                                                         // alpha (1 row)
+            add_layer(10, {H, Seg{FRAG_GEN, W, p.input_ch_views, p.KD, Ld}});          // views
+            add_layer(11, {Seg{FRAG_ACC, 0, W / 2, 8, 0}});                            // rgb (3 rows)
+        } else {
+            add_layer(8, {H});                                                         // output_linear
+        }
+        p.n_frags_used = (int)p.frags.size();
+        const int turn = RING_SLOTS * BLOCK_FRAGS;
+        while (p.frags.size() % turn) p.frags.push_back({0, FRAG_ZERO, 0, 0, 0, 0, 0, 0});
+    }
+    return 0;
+}
+
+}  // namespace na

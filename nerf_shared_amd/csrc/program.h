@@ -1,0 +1,117 @@
+// program.h -- how one reference NeRF (nerf.py:62-134) is laid out as MFMA
+// fragment streams.  Shared by the host packer, the device pack kernel and
+// the kernels that consume the streams.
+//
+// bf16 stream (fused kernel, mlp_bf16.hip)
+//   The network is evaluated transposed: H_out^T[out, pts] = W[out, in] . H_in^T[in, pts],
+//   so weights are the MFMA *A* operand and 32 points sit on the lanes of a wave
+//   as the *B* operand.  The stream is the exact sequence of 1-KiB A fragments
+//   (v_mfma_f32_32x32x16_bf16: lane l holds A[row = l&31][k = 8*(l>>5) + j], j<8)
+//   in consumption order: layer -> 32-row output tile -> k-step.
+//   Two k orders exist inside a k-step:
+//    * FRAG_ACC: the B operand is the previous layer's accumulator tile converted
+//      to bf16 in place (no lane movement).  Accumulator register r of lane
+//      (col, h) holds feature row (r&3) + 8*(r>>2) + 4*h of its 32-row tile, so
+//      k slot (h, j) of k-step ks means input column
+//          32*(ks>>1) + 16*(ks&1) + 8*(j>>2) + 4*h + (j&3).
+//    * FRAG_GEN: the B operand is a positional encoding generated in registers.
+//      Lane half h = 0 evaluates the sin features, h = 1 the cos features, so
+//      with e = 8*ks + j:  e < 3L  -> column 3 + 6*(e/3) + 3*h + e%3
+//                          e = 3L  -> column 0 (h=0) / 2 (h=1)      (raw x / z)
+//                          e = 3L+1-> column 1 (h=0) / none (h=1)   (raw y)
+//      (column = index into the reference embedding, nerf.py:16-41).
+//
+// fp32 stream (generic kernel, mlp_fp32.hip)
+//   v_mfma_f32_32x32x2_f32: lane l holds A[row = l&31][k = l>>5].  Fragments are
+//   grouped four k-pairs at a time so a lane loads 16 bytes: group g of tile t
+//   holds W[32t + (l&31)][8g + 2i + (l>>5)], i < 4.
+#pragma once
+#include <stdint.h>
+#include <vector>
+
+#include "../../include/nerf_amd.h"
+
+#if defined(__HIPCC__)
+#define NA_HD __host__ __device__
+#else
+#define NA_HD
+#endif
+
+namespace na {
+
+enum { FRAG_ACC = 0, FRAG_GEN = 1, FRAG_ZERO = 2 };
+
+struct FragDesc {        // one bf16 A fragment: 32 out rows x 16 k
+    int32_t tensor;      // index into the parameter list (nerf_amd.h order)
+    int32_t kind;        // FRAG_*
+    int32_t row0;        // first output row of the tile
+    int32_t col_base;    // first weight column of this input segment
+    int32_t ks;          // k-step inside the segment
+    int32_t seg_len;     // valid columns in the segment
+    int32_t L;           // multires of the generated encoding (FRAG_GEN)
+    int32_t pad;
+};
+
+struct TileDesc {        // one 32-row output tile (bias table entry)
+    int32_t tensor;
+    int32_t row0;
+};
+
+struct TensorDesc {      // one nn.Linear
+    int32_t n_out, n_in;
+};
+
+// fp32 generic program: one entry per layer, executed in order by mlp_fp32.hip
+struct LayerF32 {
+    int32_t tensor;
+    int32_t n_out, n_in;     // true sizes
+    int32_t in_row;          // first LDS row of the input  (rows are features)
+    int32_t out_row;         // first LDS row of the output, or -1: write to global
+    int32_t out_col;         // channel offset in the global output row
+    int32_t relu;
+    int32_t in_buf;          // 0/1 ping-pong buffer the input is read from
+    int64_t frag_off;        // float offset of this layer's fragments in the fp32 stream
+    int64_t bias_off;        // float offset of the bias (padded to 32*tiles)
+};
+
+// Column of the reference embedding that slot (ks,h,j) of a FRAG_GEN segment holds, or -1.
+NA_HD constexpr inline int gen_col(int ks, int h, int j, int L) {
+    int e = 8 * ks + j;
+    if (e < 3 * L) return 3 + 6 * (e / 3) + 3 * h + (e % 3);
+    if (e == 3 * L) return h ? 2 : 0;
+    if (e == 3 * L + 1) return h ? -1 : 1;
+    return -1;
+}
+// Column (inside its segment) that slot (ks,h,j) of a FRAG_ACC segment holds.
+NA_HD constexpr inline int acc_col(int ks, int h, int j) {
+    return 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
+}
+// Feature row that accumulator register r of lane half h holds (32x32 C/D layout).
+NA_HD constexpr inline int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+NA_HD constexpr inline int gen_ksteps(int L) { return (3 * L + 2 + 7) / 8; }   // k-steps of a generated encoding
+
+inline int embed_dim(int L, int i_embed) { return i_embed == -1 ? 3 : 3 + 6 * L; }
+
+struct Program {
+    nerf_amd_arch arch;
+    int input_ch = 0, input_ch_views = 0, out_ch = 0;
+    std::vector<TensorDesc> tensors;
+    // bf16 fused program (empty when the architecture is not the canonical one)
+    bool bf16_ok = false;
+    int KE = 0, KD = 0;
+    std::vector<FragDesc> frags;     // padded to a whole number of ring turns
+    std::vector<TileDesc> tiles;
+    int n_frags_used = 0;
+    // fp32 generic program
+    std::vector<LayerF32> layers;
+    int64_t f32_stream_floats = 0, f32_bias_floats = 0;
+    int lds_rows = 0;                // rows of one ping-pong buffer
+};
+
+constexpr int RING_SLOTS = 3;        // 16-KiB blocks in the LDS weight ring
+constexpr int BLOCK_FRAGS = 16;      // fragments per block (one barrier per block)
+
+int build_program(const nerf_amd_arch &arch, Program &p, const char **err);
+
+}  // namespace na

@@ -1,0 +1,365 @@
+// render.hip -- the per-ray stages of Renderer.render_rays around the field MLP:
+// stratified depths, alpha compositing, hierarchical resampling, ray generation.
+//
+// All of these are HBM-/latency-bound per-ray scans and reductions; each ray is
+// owned by one 64-lane wavefront so the cumprod / cumsum / sort never leave the
+// wave (DPP shuffles + a few hundred bytes of LDS).
+//
+// Compiled with -ffp-contract=off: the reference's ATen ops round after every
+// multiply and add, so no fused multiply-add may be formed here.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "kernels.h"
+
+namespace na {
+
+constexpr int RAYS_PER_WG = 4;   // one wave per ray, 4 waves per workgroup
+
+__device__ __forceinline__ double wave_incl_prod(double v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        double o = __shfl_up(v, d);
+        if (lane >= d) v *= o;
+    }
+    return v;
+}
+__device__ __forceinline__ double wave_incl_sum(double v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        double o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+template <class T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// z_vals of the coarse pass: render_utils.py:105-129
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float z_of_t(float near, float far, float t, int lindisp) {
+    if (!lindisp) return near * (1.0f - t) + far * t;
+    return 1.0f / (1.0f / near * (1.0f - t) + 1.0f / far * t);
+}
+
+__global__ __launch_bounds__(256) void coarse_z_kernel(const float *rays, int ray_stride, const float *t_vals,
+                                                       const float *t_rand, int64_t R, int Nc, int lindisp,
+                                                       int perturb, float *z) {
+    const int64_t total = R * Nc;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / Nc;
+        const int s = (int)(i - r * Nc);
+        const float near = rays[r * ray_stride + 6], far = rays[r * ray_stride + 7];
+        float zc = z_of_t(near, far, t_vals[s], lindisp);
+        if (perturb) {
+            float upper = zc, lower = zc;
+            if (s + 1 < Nc) upper = 0.5f * (z_of_t(near, far, t_vals[s + 1], lindisp) + zc);
+            if (s > 0) lower = 0.5f * (zc + z_of_t(near, far, t_vals[s - 1], lindisp));
+            zc = lower + (upper - lower) * t_rand[i];
+        }
+        z[i] = zc;
+    }
+}
+
+int launch_coarse_z(const float *rays, int ray_stride, const float *t_vals, const float *t_rand,
+                    int64_t R, int Nc, int lindisp, int perturb, float *z, hipStream_t s) {
+    if (R <= 0) return NERF_AMD_OK;
+    int64_t blocks = (R * Nc + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(coarse_z_kernel, dim3((unsigned)blocks), dim3(256), 0, s, rays, ray_stride, t_vals, t_rand,
+                       R, Nc, lindisp, perturb, z);
+    return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
+}
+
+// ---------------------------------------------------------------------------
+// raw2outputs: render_utils.py:241-290.  One wave per ray, 64 samples per step.
+// The transmittance product is carried in fp64 like ATen's CPU cumprod
+// (acc_type<float> = double) and rounded to fp32 per sample.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * RAYS_PER_WG) void composite_kernel(
+    const float *raw, int raw_ch, const float *z, const float *rays_d, int rays_d_stride, const float *noise,
+    int64_t R, int S, int white_bkgd, float *rgb_map, float *disp_map, float *acc_map, float *weights,
+    float *depth_map) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * RAYS_PER_WG + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float *d = rays_d + r * rays_d_stride;
+    const float dnorm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    const float *zr = z + r * S;
+    double carry = 1.0;                      // product of (1 - alpha + 1e-10) over all previous samples
+    float sr = 0.f, sg = 0.f, sb = 0.f, sdepth = 0.f, sacc = 0.f;
+    for (int s0 = 0; s0 < S; s0 += 64) {
+        const int s = s0 + lane;
+        const bool in = s < S;
+        float w = 0.f, zc = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+        double term = 1.0;
+        float alpha = 0.f;
+        if (in) {
+            zc = zr[s];
+            float dist = (s + 1 < S) ? zr[s + 1] - zc : 1e10f;
+            dist = dist * dnorm;
+            const float *q = raw + (r * S + s) * raw_ch;
+            cr = 1.0f / (1.0f + expf(-q[0]));
+            cg = 1.0f / (1.0f + expf(-q[1]));
+            cb = 1.0f / (1.0f + expf(-q[2]));
+            float sigma = q[3];
+            if (noise) sigma = sigma + noise[r * S + s];
+            sigma = fmaxf(sigma, 0.0f);
+            alpha = 1.0f - expf(-sigma * dist);
+            term = (double)(1.0f - alpha + 1e-10f);
+        }
+        const double incl = wave_incl_prod(term, lane);
+        double excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = 1.0;
+        // ATen rounds every running product to fp32 on output; the running value itself stays fp64.
+        const float T = (float)(carry * excl);
+        carry = carry * __shfl(incl, 63);
+        if (in) {
+            w = alpha * T;
+            if (weights) weights[r * S + s] = w;
+        }
+        sr += w * cr; sg += w * cg; sb += w * cb;
+        sdepth += w * zc; sacc += w;
+    }
+    sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb);
+    sdepth = wave_sum(sdepth); sacc = wave_sum(sacc);
+    if (lane == 0) {
+        if (white_bkgd) { const float bg = 1.0f - sacc; sr = sr + bg; sg = sg + bg; sb = sb + bg; }
+        if (rgb_map) { rgb_map[3 * r] = sr; rgb_map[3 * r + 1] = sg; rgb_map[3 * r + 2] = sb; }
+        if (depth_map) depth_map[r] = sdepth;
+        if (acc_map) acc_map[r] = sacc;
+        if (disp_map) {
+            const float q = sdepth / sacc;               // 0/0 -> NaN, which torch.max propagates (:284)
+            const float m = (q != q) ? q : (q > 1e-10f ? q : 1e-10f);
+            disp_map[r] = 1.0f / m;
+        }
+    }
+}
+
+int launch_composite(const float *raw, int raw_ch, const float *z, const float *rays_d, int rays_d_stride,
+                     const float *noise, int64_t R, int S, int white_bkgd, float *rgb, float *disp, float *acc,
+                     float *weights, float *depth, hipStream_t s) {
+    if (R <= 0) return NERF_AMD_OK;
+    if (S < 1 || raw_ch < 4) return NERF_AMD_EINVAL;
+    const int64_t blocks = (R + RAYS_PER_WG - 1) / RAYS_PER_WG;
+    hipLaunchKernelGGL(composite_kernel, dim3((unsigned)blocks), dim3(64 * RAYS_PER_WG), 0, s, raw, raw_ch, z,
+                       rays_d, rays_d_stride, noise, R, S, white_bkgd, rgb, disp, acc, weights, depth);
+    return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
+}
+
+// ---------------------------------------------------------------------------
+// sample_pdf: utils.py:74-117.  cdf (fp64 running sum rounded to fp32 per bin,
+// like ATen's CPU cumsum) and bins of one ray live in this wave's LDS slice.
+// ---------------------------------------------------------------------------
+// Builds cdf[0..nb) in LDS from w[0..nb-1) (weights already offset so w[i] is bin i).
+template <class LoadW>
+__device__ __forceinline__ void build_cdf(LoadW load_w, int nb, float *cdf, int lane) {
+    double total = 0.0;
+    for (int i0 = 0; i0 < nb - 1; i0 += 64) {
+        const int i = i0 + lane;
+        total += (i < nb - 1) ? (double)(load_w(i) + 1e-5f) : 0.0;
+    }
+    const float wsum = (float)wave_sum(total);
+    double carry = 0.0;
+    if (lane == 0) cdf[0] = 0.0f;
+    for (int i0 = 0; i0 < nb - 1; i0 += 64) {
+        const int i = i0 + lane;
+        const float pdf = (i < nb - 1) ? (load_w(i) + 1e-5f) / wsum : 0.0f;
+        const double incl = wave_incl_sum((double)pdf, lane);
+        if (i < nb - 1) cdf[i + 1] = (float)(carry + incl);
+        carry += __shfl(incl, 63);
+    }
+}
+
+__device__ __forceinline__ float invert_cdf(const float *cdf, const float *bins, int nb, float u) {
+    int lo = 0, hi = nb;                      // first index with cdf[idx] > u   (searchsorted right=True)
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cdf[mid] > u) hi = mid; else lo = mid + 1;
+    }
+    const int below = lo - 1 > 0 ? lo - 1 : 0;
+    const int above = lo < nb - 1 ? lo : nb - 1;
+    const float c0 = cdf[below], c1 = cdf[above];
+    float denom = c1 - c0;
+    if (denom < 1e-5f) denom = 1.0f;
+    const float t = (u - c0) / denom;
+    const float b0 = bins[below], b1 = bins[above];
+    return b0 + t * (b1 - b0);
+}
+
+__global__ __launch_bounds__(64 * RAYS_PER_WG) void sample_pdf_kernel(const float *bins, const float *weights,
+                                                                      const float *u, const float *t_lin, int64_t R,
+                                                                      int nb, int N, float *samples) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int64_t r = (int64_t)blockIdx.x * RAYS_PER_WG + wv;
+    const bool live = r < R;
+    if (!live) r = R - 1;
+    float *cdf = lds + wv * 2 * nb, *bl = cdf + nb;
+    const float *wr = weights + r * (nb - 1);
+    build_cdf([&](int i) { return wr[i]; }, nb, cdf, lane);
+    for (int i = lane; i < nb; i += 64) bl[i] = bins[r * nb + i];
+    __syncthreads();
+    if (!live) return;
+    for (int i = lane; i < N; i += 64) {
+        const float uu = u ? u[r * N + i] : t_lin[i];
+        samples[r * N + i] = invert_cdf(cdf, bl, nb, uu);
+    }
+}
+
+int launch_sample_pdf(const float *bins, const float *weights, const float *u, const float *t_lin,
+                      int64_t R, int n_bins, int n_samples, float *samples, hipStream_t s) {
+    if (R <= 0 || n_samples <= 0) return NERF_AMD_OK;
+    if (n_bins < 2 || n_bins > 4096) return NERF_AMD_EINVAL;
+    const int64_t blocks = (R + RAYS_PER_WG - 1) / RAYS_PER_WG;
+    const size_t lds = (size_t)RAYS_PER_WG * 2 * n_bins * sizeof(float);
+    hipLaunchKernelGGL(sample_pdf_kernel, dim3((unsigned)blocks), dim3(64 * RAYS_PER_WG), lds, s, bins, weights, u,
+                       t_lin, R, n_bins, n_samples, samples);
+    return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
+}
+
+// ---------------------------------------------------------------------------
+// The resampling step of render_rays (render_utils.py:140-148, :168) fused:
+//   z_mid -> sample_pdf(z_mid, weights[1:-1]) -> z_std -> sort(cat[z, z_samples])
+// Per-ray LDS: cdf[Nc-1] + bins[Nc-1] + sort buffer[pow2 >= Nc+Ni].
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * RAYS_PER_WG) void resample_kernel(const float *z_coarse, const float *weights,
+                                                                    const float *u, const float *t_lin, int64_t R,
+                                                                    int Nc, int Ni, int npad, float *z_fine,
+                                                                    float *z_std) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int64_t r = (int64_t)blockIdx.x * RAYS_PER_WG + wv;
+    const bool live = r < R;
+    if (!live) r = R - 1;
+    const int nb = Nc - 1;
+    float *cdf = lds + wv * (2 * nb + npad), *bl = cdf + nb, *sb = bl + nb;
+    const float *zr = z_coarse + r * Nc;
+    const float *wr = weights + r * Nc + 1;                       // weights[..., 1:-1]
+    build_cdf([&](int i) { return wr[i]; }, nb, cdf, lane);
+    for (int i = lane; i < nb; i += 64) bl[i] = 0.5f * (zr[i + 1] + zr[i]);
+    for (int i = lane; i < Nc; i += 64) sb[i] = zr[i];
+    for (int i = Nc + Ni + lane; i < npad; i += 64) sb[i] = INFINITY;
+    __syncthreads();
+    double sum = 0.0;
+    for (int i = lane; i < Ni; i += 64) {
+        const float uu = u ? u[r * Ni + i] : t_lin[i];
+        const float v = invert_cdf(cdf, bl, nb, uu);
+        sb[Nc + i] = v;
+        sum += (double)v;
+    }
+    // std(z_samples, unbiased=False): two-pass in fp64
+    const double mean = wave_sum(sum) / (double)Ni;
+    double ss = 0.0;
+    for (int i = lane; i < Ni; i += 64) {
+        const double dv = (double)sb[Nc + i] - mean;
+        ss += dv * dv;
+    }
+    ss = wave_sum(ss);
+    if (live && lane == 0 && z_std) z_std[r] = (float)sqrt(ss / (double)Ni);
+    __syncthreads();
+    // bitonic sort of sb[0..npad), ascending; every wave runs the same step count
+    for (int k = 2; k <= npad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = lane; i < npad; i += 64) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const float a = sb[i], b = sb[p];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { sb[i] = b; sb[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (!live) return;
+    for (int i = lane; i < Nc + Ni; i += 64) z_fine[r * (Nc + Ni) + i] = sb[i];
+}
+
+int launch_resample(const float *z_coarse, const float *weights, const float *u, const float *t_lin,
+                    int64_t R, int Nc, int Ni, float *z_fine, float *z_std, hipStream_t s) {
+    if (R <= 0) return NERF_AMD_OK;
+    if (Nc < 3 || Ni < 1 || Nc + Ni > 4096) return NERF_AMD_EINVAL;
+    int npad = 2;
+    while (npad < Nc + Ni) npad <<= 1;
+    const int64_t blocks = (R + RAYS_PER_WG - 1) / RAYS_PER_WG;
+    const size_t lds = (size_t)RAYS_PER_WG * (2 * (Nc - 1) + npad) * sizeof(float);
+    hipLaunchKernelGGL(resample_kernel, dim3((unsigned)blocks), dim3(64 * RAYS_PER_WG), lds, s, z_coarse, weights, u,
+                       t_lin, R, Nc, Ni, npad, z_fine, z_std);
+    return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
+}
+
+// ---------------------------------------------------------------------------
+// get_rays + viewdirs + ndc_rays + batch assembly: utils.py:33-71,
+// render_utils.py:200-226.  One thread per pixel.
+// ---------------------------------------------------------------------------
+struct RayGen {
+    float fx, fy, cx, cy;
+    float c2w[12], c2ws[12];
+    int has_static, use_viewdirs, ndc, H, W;
+    float near, far;
+    float sx, sy;          // -1/(W/(2 focal)), -1/(H/(2 focal)) evaluated in fp64 like the Python scalars
+};
+
+__device__ __forceinline__ void cam_ray(const float *c, float dx, float dy, float dz, float *o, float *d) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        d[k] = dx * c[4 * k] + dy * c[4 * k + 1] + dz * c[4 * k + 2];
+        o[k] = c[4 * k + 3];
+    }
+}
+
+__global__ __launch_bounds__(256) void make_rays_kernel(RayGen g, int64_t pix0, int64_t n, float *out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int64_t pix = pix0 + idx;
+    const float i = (float)(pix % g.W), j = (float)(pix / g.W);
+    const float dx = (i - g.cx) / g.fx, dy = -(j - g.cy) / g.fy, dz = -1.0f;
+    float o[3], d[3], vd[3];
+    cam_ray(g.c2w, dx, dy, dz, o, d);
+    vd[0] = d[0]; vd[1] = d[1]; vd[2] = d[2];
+    if (g.has_static) cam_ray(g.c2ws, dx, dy, dz, o, d);
+    const int ch = g.use_viewdirs ? 11 : 8;
+    float *row = out + idx * ch;
+    if (g.use_viewdirs) {
+        const float nrm = sqrtf(vd[0] * vd[0] + vd[1] * vd[1] + vd[2] * vd[2]);
+        row[8] = vd[0] / nrm; row[9] = vd[1] / nrm; row[10] = vd[2] / nrm;
+    }
+    if (g.ndc) {
+        // ndc_rays(H, W, focal = K[0][0], near = 1.)
+        const float nearp = 1.0f;
+        const float t = -(nearp + o[2]) / d[2];
+        o[0] = o[0] + t * d[0]; o[1] = o[1] + t * d[1]; o[2] = o[2] + t * d[2];
+        const float sx = g.sx, sy = g.sy;
+        const float o0 = sx * o[0] / o[2], o1 = sy * o[1] / o[2], o2 = 1.0f + 2.0f * nearp / o[2];
+        const float d0 = sx * (d[0] / d[2] - o[0] / o[2]);
+        const float d1 = sy * (d[1] / d[2] - o[1] / o[2]);
+        const float d2 = -2.0f * nearp / o[2];
+        o[0] = o0; o[1] = o1; o[2] = o2; d[0] = d0; d[1] = d1; d[2] = d2;
+    }
+    row[0] = o[0]; row[1] = o[1]; row[2] = o[2];
+    row[3] = d[0]; row[4] = d[1]; row[5] = d[2];
+    row[6] = g.near; row[7] = g.far;
+}
+
+int launch_make_rays(int H, int W, const double *K4, const float *c2w, const float *c2w_static,
+                     int64_t pix0, int64_t n, float near, float far, int use_viewdirs, int ndc,
+                     float *rays_out, hipStream_t s) {
+    if (n <= 0) return NERF_AMD_OK;
+    RayGen g;
+    g.fx = (float)K4[0]; g.fy = (float)K4[1]; g.cx = (float)K4[2]; g.cy = (float)K4[3];
+    for (int i = 0; i < 12; ++i) { g.c2w[i] = c2w[i]; g.c2ws[i] = c2w_static ? c2w_static[i] : 0.0f; }
+    g.has_static = c2w_static != nullptr;
+    g.use_viewdirs = use_viewdirs; g.ndc = ndc; g.H = H; g.W = W; g.near = near; g.far = far;
+    g.sx = (float)(-1.0 / ((double)W / (2.0 * K4[0])));
+    g.sy = (float)(-1.0 / ((double)H / (2.0 * K4[0])));
+    hipLaunchKernelGGL(make_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, pix0, n, rays_out);
+    return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
+}
+
+}  // namespace na

@@ -1,0 +1,222 @@
+"""Drop-in for nerf_shared/nerf.py: Embedder, get_embedder and the NeRF field,
+evaluated by the HIP kernels in csrc/ (fused bf16 MFMA, or exact fp32 MFMA).
+
+Signatures, attribute names and state_dict keys follow the reference
+(/root/reference/nerf_shared/nerf.py:11-143) so a reference checkpoint
+(`coarse_model_state_dict` / `fine_model_state_dict`, utils.py:450-455) loads
+with ``load_state_dict`` unchanged.
+
+Forward only: outputs never carry autograd history (SURVEY.md section 8f ranks the
+backward pass as the next row).
+"""
+import ctypes
+import weakref
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import lib
+
+_PRECISIONS = {"fp32": _lib.PREC_FP32, "bf16": _lib.PREC_BF16}
+_default_precision = "bf16"
+
+
+def set_default_precision(name):
+    """'bf16' (fused kernel, bf16 operands / fp32 accumulate; falls back to fp32 for
+    architectures it does not cover) or 'fp32' (exact-fp32 MFMA parity mode)."""
+    global _default_precision
+    if name not in _PRECISIONS:
+        raise ValueError("precision must be one of %s" % sorted(_PRECISIONS))
+    _default_precision = name
+
+
+def get_default_precision():
+    return _default_precision
+
+
+# ------------------------------------------------------------------ embedding
+class Embedder:
+    """Positional encoding (nerf.py:11-41).  Same kwargs as the reference; the
+    HIP kernel covers the configuration get_embedder builds (3 inputs,
+    include_input, log sampling, [sin, cos])."""
+
+    def __init__(self, **kwargs):
+        self.kwargs = kwargs
+        self.create_embedding_fn()
+
+    def create_embedding_fn(self):
+        kw = self.kwargs
+        d = kw['input_dims']
+        if d != 3 or not kw['include_input'] or not kw['log_sampling'] \
+                or kw['max_freq_log2'] != kw['num_freqs'] - 1 \
+                or list(kw['periodic_fns']) != [torch.sin, torch.cos]:
+            raise NotImplementedError("the HIP embedder implements get_embedder's configuration "
+                                      "(3-d input, include_input, log sampling, [sin, cos])")
+        self.num_freqs = int(kw['num_freqs'])
+        self.out_dim = d + 2 * d * self.num_freqs
+
+    def embed(self, inputs):
+        _lib.require_device(inputs, "inputs")
+        x = inputs.detach().reshape(-1, 3).contiguous().float()
+        out = torch.empty(x.shape[0], self.out_dim, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.nerf_amd_embed(x.data_ptr(), x.shape[0], self.num_freqs, out.data_ptr(),
+                                          _lib.stream_of(x.device)), "nerf_amd_embed")
+        return out.reshape(list(inputs.shape[:-1]) + [self.out_dim])
+
+
+def get_embedder(multires, i=0):
+    """(embed_fn, out_dim), nerf.py:43-58."""
+    if i == -1:
+        return nn.Identity(), 3
+    embed_kwargs = {
+        'include_input': True,
+        'input_dims': 3,
+        'max_freq_log2': multires - 1,
+        'num_freqs': multires,
+        'log_sampling': True,
+        'periodic_fns': [torch.sin, torch.cos],
+    }
+    embedder_obj = Embedder(**embed_kwargs)
+    embed = lambda x, eo=embedder_obj: eo.embed(x)   # noqa: E731  (same closure shape as the reference)
+    return embed, embedder_obj.out_dim
+
+
+# ------------------------------------------------------------------ the field
+def _destroy_handle(handle):
+    if handle:
+        lib.nerf_amd_model_destroy(handle)
+
+
+class NeRF(nn.Module):
+    """The reference's field model (nerf.py:61-143), same constructor, same
+    parameters; ``forward`` runs on the MI355X kernels."""
+
+    def __init__(self, D=8, W=256, output_ch=4, skips=[4], use_viewdirs=False, multires=10,
+                 multires_views=4, i_embed=0):
+        super(NeRF, self).__init__()
+        self.D = D
+        self.W = W
+        self.skips = skips
+        self.use_viewdirs = use_viewdirs
+        self.output_ch = output_ch
+        self.multires, self.multires_views, self.i_embed = multires, multires_views, i_embed
+
+        self.embed_fn, self.input_ch = get_embedder(multires, i_embed)
+        self.input_ch_views = 0
+        self.embeddirs_fn = None
+        if use_viewdirs:
+            self.embeddirs_fn, self.input_ch_views = get_embedder(multires_views, i_embed)
+
+        self.pts_linears = nn.ModuleList(
+            [nn.Linear(self.input_ch, W)] +
+            [nn.Linear(W + self.input_ch, W) if i in self.skips else nn.Linear(W, W) for i in range(D - 1)])
+        self.views_linears = nn.ModuleList([nn.Linear(self.input_ch_views + W, W // 2)])
+        if use_viewdirs:
+            self.feature_linear = nn.Linear(W, W)
+            self.alpha_linear = nn.Linear(W, 1)
+            self.rgb_linear = nn.Linear(W // 2, 3)
+        else:
+            self.output_linear = nn.Linear(W, output_ch)
+
+        self.precision = None          # None: follow set_default_precision()
+        self._handle = None
+        self._handle_device = None
+        self._packed_key = None
+        self._finalizer = None
+
+    # -- device-side packed copy of the parameters --------------------------------
+    def _linears(self):
+        """nn.Linear modules in the C ABI's tensor order (include/nerf_amd.h)."""
+        mods = list(self.pts_linears)
+        if self.use_viewdirs:
+            mods += [self.feature_linear, self.alpha_linear, self.views_linears[0], self.rgb_linear]
+        else:
+            mods += [self.output_linear]
+        return mods
+
+    def _model_handle(self, device):
+        """Create the library handle on first use and re-pack when any parameter changed."""
+        mods = self._linears()
+        for m in mods:
+            for t in (m.weight, m.bias):
+                if t.device != device or t.dtype != torch.float32:
+                    raise _lib.NerfAmdError("NeRF parameters must be fp32 on %s (found %s on %s); call model.to(device)"
+                                            % (device, t.dtype, t.device))
+        if self._handle is None or self._handle_device != device:
+            if self._finalizer is not None:
+                self._finalizer()
+            arch = _lib.make_arch(self.D, self.W, self.output_ch, self.skips, self.use_viewdirs,
+                                  self.multires, self.multires_views, self.i_embed)
+            h = ctypes.c_void_p()
+            with torch.cuda.device(device):
+                _lib.check(lib.nerf_amd_model_create(ctypes.byref(arch), device.index or 0, ctypes.byref(h)),
+                           "nerf_amd_model_create")
+            self._handle, self._handle_device, self._packed_key = h, device, None
+            self._finalizer = weakref.finalize(self, _destroy_handle, h)
+        ws = [m.weight.detach().contiguous() for m in mods]
+        bs = [m.bias.detach().contiguous() for m in mods]
+        key = tuple((t.data_ptr(), t._version) for t in ws + bs)
+        if key != self._packed_key:
+            n = len(mods)
+            wp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in ws])
+            bp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in bs])
+            with torch.cuda.device(device):
+                _lib.check(lib.nerf_amd_model_update(self._handle, wp, bp, n, _lib.stream_of(device)),
+                           "nerf_amd_model_update")
+            self._packed_key = key
+        return self._handle
+
+    def _precision_code(self):
+        name = self.precision or _default_precision
+        if name not in _PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(_PRECISIONS))
+        code = _PRECISIONS[name]
+        if code == _lib.PREC_BF16 and self._handle is not None and not lib.nerf_amd_model_supports_bf16(self._handle):
+            code = _lib.PREC_FP32      # still a HIP MFMA kernel, at the fp32 rate
+        return code
+
+    def supports_bf16(self, device=None):
+        dev = device or next(self.parameters()).device
+        return bool(lib.nerf_amd_model_supports_bf16(self._model_handle(torch.device(dev))))
+
+    # -- reference API ------------------------------------------------------------
+    def forward(self, inputs, viewdirs, netchunk=1024 * 64):
+        """inputs [..., S, 3], viewdirs [R, 3] or None -> [..., S, 4 | output_ch]
+        (nerf.py:96-108).  ``netchunk`` is accepted for compatibility; the kernel
+        tiles points itself, so chunking cannot change the result."""
+        _lib.require_device(inputs, "inputs")
+        dev = inputs.device
+        pts = inputs.detach().reshape(-1, 3).contiguous().float()
+        n_samples = inputs.shape[-2] if inputs.dim() >= 2 else 1
+        vd = None
+        if viewdirs is not None:
+            if not self.use_viewdirs:
+                raise _lib.NerfAmdError("viewdirs given to a NeRF built with use_viewdirs=False")
+            if inputs.dim() != 3 or viewdirs.shape[0] != inputs.shape[0]:
+                raise _lib.NerfAmdError("with viewdirs, inputs must be [R, S, 3] and viewdirs [R, 3]")
+            vd = viewdirs.detach().reshape(-1, 3).contiguous().float()
+        elif self.use_viewdirs:
+            raise _lib.NerfAmdError("this NeRF was built with use_viewdirs=True: viewdirs is required")
+        handle = self._model_handle(dev)
+        out_ch = 4 if self.use_viewdirs else self.output_ch
+        out = torch.empty(pts.shape[0], out_ch, device=dev, dtype=torch.float32)
+        n_rays = pts.shape[0] // n_samples
+        with torch.cuda.device(dev):
+            _lib.check(lib.nerf_amd_nerf_forward(handle, pts.data_ptr(), _lib.ptr(vd), n_rays, n_samples,
+                                                 out.data_ptr(), self._precision_code(), _lib.stream_of(dev)),
+                       "nerf_amd_nerf_forward")
+        return out.reshape(list(inputs.shape[:-1]) + [out_ch])
+
+    def MLP(self, x):
+        """Embedded rows [P, input_ch + input_ch_views] -> [P, 4|output_ch] (nerf.py:110-134).
+        Kept for API parity; the kernels fuse the encoding, so this entry point
+        is the one place that cannot: it is not provided."""
+        raise NotImplementedError("NeRF.MLP on pre-embedded rows is not exposed; call forward(inputs, viewdirs)")
+
+    def get_density(self, points, chunk=1024 * 64):
+        """Raw sigma with an all-ones view direction (nerf.py:136-143)."""
+        view_dir = torch.ones_like(points[..., 0, :]) if self.use_viewdirs else None
+        output = self.forward(points, view_dir, chunk)
+        return output[..., -1]

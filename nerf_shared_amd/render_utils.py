@@ -1,0 +1,314 @@
+"""Drop-in for nerf_shared/render_utils.py: the volumetric Renderer, running on
+the MI355X kernels behind include/nerf_amd.h.
+
+Same constructor, methods, argument names, return structures and key order as
+/root/reference/nerf_shared/render_utils.py:13-319.  Differences, all at the
+edges of the hot path:
+  * temporaries are allocated on ``ray_batch.device`` (the reference uses the
+    process-wide default device, main.py:150-152);
+  * random draws use torch's generator for that device in the reference's order
+    and shapes (t_rand, coarse noise, u, fine noise), so a seeded run matches a
+    seeded reference run on the same device; ``pytest=True`` reproduces the
+    reference's seeded numpy draws bit for bit;
+  * the NaN/Inf scan of every output (render_utils.py:170-172) only runs when
+    DEBUG is set -- it never changes outputs and costs a device sync per key;
+  * forward only (no autograd history on the outputs).
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import _lib, utils
+from ._lib import lib
+from .nerf import NeRF, get_default_precision
+
+DEBUG = False
+
+_KEYS_MAIN = ('rgb_map', 'disp_map', 'acc_map')
+
+
+class _Workspace:
+    """Grow-only scratch buffer per device (raw/z/weights of the two passes)."""
+    _bufs = {}
+
+    @classmethod
+    def get(cls, device, nbytes):
+        buf = cls._bufs.get(device)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+            cls._bufs[device] = buf
+        return buf
+
+
+_linspace_cache = {}
+
+
+def _linspace01(n, device):
+    key = (n, device)
+    t = _linspace_cache.get(key)
+    if t is None:
+        t = torch.linspace(0., 1., steps=n, device=device)
+        _linspace_cache[key] = t
+    return t
+
+
+def _pytest_uniform(shape, device):
+    """np.random.seed(0); np.random.rand(*shape) -> fp32 (render_utils.py:124-127)."""
+    np.random.seed(0)
+    return torch.Tensor(np.random.rand(*list(shape))).to(device)
+
+
+class Renderer(torch.nn.Module):
+    def __init__(self, perturb=True, N_importance=128, N_samples=64, use_viewdirs=True,
+                 white_bkgd=True, raw_noise_std=0.0, ndc=False, lindisp=False,
+                 near=0.0, far=1.0):
+        """
+        Stores values as class data.
+        """
+        super(Renderer, self).__init__()
+        self.perturb = perturb
+        self.N_importance = N_importance
+        self.N_samples = N_samples
+        self.use_viewdirs = use_viewdirs
+        self.white_bkgd = white_bkgd
+        self.raw_noise_std = raw_noise_std
+        self.ndc = ndc
+        self.lindisp = lindisp
+        self.near = near
+        self.far = far
+        if os.environ.get("NERF_AMD_QUIET") != "1":
+            print(self.__dict__)     # the reference prints its configuration (render_utils.py:32)
+
+    # ------------------------------------------------------------------ wrappers
+    def render_from_pose(self, H, W, K, chunk, c2w, coarse_model, fine_model, retraw=True):
+        rgb, disp, acc, extras = self.render(
+            H, W, K, coarse_model, fine_model, chunk=chunk, c2w=c2w, retraw=retraw)
+        return rgb, disp, acc, extras
+
+    def render_from_rays(self, H, W, K, chunk, rays, coarse_model, fine_model, retraw=True):
+        rgb, disp, acc, extras = self.render(H, W, K, coarse_model, fine_model,
+                                             chunk=chunk, rays=rays, retraw=retraw)
+        return rgb, disp, acc, extras
+
+    def render_path(self):
+        pass
+
+    # ------------------------------------------------------------------ core
+    def _cfg(self, precision):
+        cfg = _lib.RenderCfg()
+        cfg.N_samples, cfg.N_importance = int(self.N_samples), int(self.N_importance)
+        cfg.perturb = int(self.perturb > 0.)
+        cfg.lindisp, cfg.white_bkgd = int(bool(self.lindisp)), int(bool(self.white_bkgd))
+        cfg.use_noise = int(self.raw_noise_std > 0.)
+        cfg.precision = precision
+        return cfg
+
+    @staticmethod
+    def _check_model(m, name):
+        if not isinstance(m, NeRF):
+            raise TypeError("%s must be a nerf_shared_amd.nerf.NeRF (got %s); load a reference model's "
+                            "state_dict into one" % (name, type(m).__name__))
+
+    def _launch(self, rays, coarse_model, fine_model, outs, retraw, retweights, pytest):
+        """Enqueue render_rays for contiguous fp32 rays [R, 8|11]; writes into the
+        tensors of ``outs`` (rows [0, R))."""
+        R, dev = rays.shape[0], rays.device
+        Nc, Ni = int(self.N_samples), int(self.N_importance)
+        Nf = Nc + Ni
+        self._check_model(coarse_model, "coarse_model")
+        if fine_model is not None:
+            self._check_model(fine_model, "fine_model")
+        hc = coarse_model._model_handle(dev)
+        hf = fine_model._model_handle(dev) if (fine_model is not None and Ni > 0) else None
+        prec = coarse_model._precision_code()
+        if hf is not None and fine_model._precision_code() != prec:
+            prec = _lib.PREC_FP32
+        cfg = self._cfg(prec)
+        out_ch = lib.nerf_amd_model_out_ch(hc)
+
+        # --- random draws, in the reference's order and shapes
+        t_rand = noise0 = noise1 = u = None
+        if self.perturb > 0.:
+            t_rand = _pytest_uniform([R, Nc], dev) if pytest else torch.rand([R, Nc], device=dev)
+        if self.raw_noise_std > 0.:
+            noise0 = (_pytest_uniform([R, Nc], dev) if pytest else torch.randn([R, Nc], device=dev)) * self.raw_noise_std
+        t_lin = None
+        if Ni > 0:
+            det = (self.perturb == 0.)
+            if pytest:
+                np.random.seed(0)
+                if det:
+                    u = np.broadcast_to(np.linspace(0., 1., Ni), [R, Ni])
+                else:
+                    u = np.random.rand(R, Ni)
+                u = torch.Tensor(np.ascontiguousarray(u)).to(dev)
+            elif det:
+                t_lin = _linspace01(Ni, dev)
+            else:
+                u = torch.rand([R, Ni], device=dev)
+            if self.raw_noise_std > 0.:
+                noise1 = (_pytest_uniform([R, Nf], dev) if pytest else torch.randn([R, Nf], device=dev)) * self.raw_noise_std
+
+        io = _lib.RenderIO()
+        io.rays, io.ray_ch = rays.data_ptr(), rays.shape[1]
+        io.t_vals = _linspace01(Nc, dev).data_ptr()
+        io.t_rand, io.noise0, io.noise1 = _lib.ptr(t_rand), _lib.ptr(noise0), _lib.ptr(noise1)
+        io.u, io.t_lin_imp = _lib.ptr(u), _lib.ptr(t_lin)
+        for k in ('rgb_map', 'disp_map', 'acc_map', 'rgb0', 'disp0', 'acc0', 'z_std', 'raw', 'weights', 'z_vals'):
+            setattr(io, k, _lib.ptr(outs.get(k)))
+        nbytes = lib.nerf_amd_render_rays_workspace(cfg, R, out_ch)
+        ws = _Workspace.get(dev, nbytes)
+        io.workspace, io.workspace_bytes = ws.data_ptr(), ws.numel()
+        with torch.cuda.device(dev):
+            _lib.check(lib.nerf_amd_render_rays(cfg, hc, hf, io, R, _lib.stream_of(dev)), "nerf_amd_render_rays")
+        # keep the draws alive until the stream has consumed them (caching allocator is stream-ordered)
+        return t_rand, noise0, noise1, u
+
+    def _alloc_outputs(self, R, dev, out_ch, retraw, retweights):
+        Ni = int(self.N_importance)
+        S_last = int(self.N_samples) + Ni
+        f = dict(device=dev, dtype=torch.float32)
+        outs = {'rgb_map': torch.empty(R, 3, **f), 'disp_map': torch.empty(R, **f), 'acc_map': torch.empty(R, **f)}
+        if retraw:
+            outs['raw'] = torch.empty(R, S_last, out_ch, **f)
+        if retweights:
+            outs['weights'] = torch.empty(R, S_last, **f)
+            outs['z_vals'] = torch.empty(R, S_last, **f)
+        if Ni > 0:
+            outs['rgb0'] = torch.empty(R, 3, **f)
+            outs['disp0'] = torch.empty(R, **f)
+            outs['acc0'] = torch.empty(R, **f)
+            outs['z_std'] = torch.empty(R, **f)
+        return outs
+
+    def render_rays(self, ray_batch, coarse_model, fine_model, retraw=False, retweights=False,
+                    verbose=False, pytest=False):
+        """Volumetric rendering of one ray batch (render_utils.py:67-174).
+
+        ray_batch [N, 8|11] = origin, direction, near, far, (unit view dir).
+        Returns the reference's dict: rgb_map, disp_map, acc_map, [raw],
+        [weights, z_vals], and with N_importance > 0: rgb0, disp0, acc0, z_std.
+        """
+        _lib.require_device(ray_batch, "ray_batch")
+        rays = ray_batch.detach().contiguous().float()
+        if rays.dim() != 2 or rays.shape[1] not in (8, 11):
+            raise _lib.NerfAmdError("ray_batch must be [N, 8] or [N, 11], got %s" % (tuple(ray_batch.shape),))
+        self._check_model(coarse_model, "coarse_model")
+        out_ch = 4 if coarse_model.use_viewdirs else coarse_model.output_ch
+        outs = self._alloc_outputs(rays.shape[0], rays.device, out_ch, retraw, retweights)
+        self._launch(rays, coarse_model, fine_model, outs, retraw, retweights, pytest)
+        ret = outs
+        if DEBUG:
+            for k in ret:
+                if torch.isnan(ret[k]).any() or torch.isinf(ret[k]).any():
+                    print(f"! [Numerical Error] {k} contains nan or inf.")
+        return ret
+
+    def render_batch(self, coarse_model, fine_model, rays_flat, chunk=1024 * 32, retraw=False):
+        """Render rays in chunks (render_utils.py:51-65).  Outputs of every chunk
+        land directly in one preallocated tensor per key (the reference's
+        per-key torch.cat, without the copy)."""
+        _lib.require_device(rays_flat, "rays_flat")
+        rays = rays_flat.detach().contiguous().float()
+        self._check_model(coarse_model, "coarse_model")
+        N = rays.shape[0]
+        out_ch = 4 if coarse_model.use_viewdirs else coarse_model.output_ch
+        full = self._alloc_outputs(N, rays.device, out_ch, retraw, False)
+        keep = []
+        for i in range(0, N, chunk):
+            part = {k: v[i:i + chunk] for k, v in full.items()}
+            keep.append(self._launch(rays[i:i + chunk], coarse_model, fine_model, part, retraw, False, False))
+        return full
+
+    def render(self, H, W, K, coarse_model, fine_model, chunk=1024 * 32, rays=None, retraw=True,
+               c2w=None, c2w_staticcam=None):
+        """Render a full image from ``c2w`` or an explicit ray set (render_utils.py:176-238).
+        Returns [rgb_map, disp_map, acc_map, extras]."""
+        if c2w is not None:
+            dev = next(coarse_model.parameters()).device
+            if not dev.type == 'cuda':
+                raise _lib.NerfAmdError("models are on %s; nerf_shared_amd runs on ROCm devices only" % dev)
+            batch = utils.make_ray_batch(H, W, K, c2w, self.near, self.far, self.use_viewdirs, self.ndc,
+                                         c2w_staticcam=c2w_staticcam, device=dev)
+            sh = (H, W, 3)
+        else:
+            rays_o, rays_d = rays
+            _lib.require_device(rays_d, "rays")
+            viewdirs = None
+            if self.use_viewdirs:
+                viewdirs = rays_d
+                if c2w_staticcam is not None:
+                    rays_o, rays_d = utils.get_rays(H, W, K, c2w_staticcam)
+                viewdirs = viewdirs / torch.norm(viewdirs, dim=-1, keepdim=True)
+                viewdirs = torch.reshape(viewdirs, [-1, 3]).float()
+            sh = rays_d.shape
+            if self.ndc:
+                rays_o, rays_d = utils.ndc_rays(H, W, K[0][0], 1., rays_o, rays_d)
+            rays_o = torch.reshape(rays_o, [-1, 3]).float()
+            rays_d = torch.reshape(rays_d, [-1, 3]).float()
+            near, far = self.near * torch.ones_like(rays_d[..., :1]), self.far * torch.ones_like(rays_d[..., :1])
+            batch = torch.cat([rays_o, rays_d, near, far], -1)
+            if self.use_viewdirs:
+                batch = torch.cat([batch, viewdirs], -1)
+
+        all_ret = self.render_batch(coarse_model, fine_model, batch, chunk, retraw)
+        for k in all_ret:
+            k_sh = list(sh[:-1]) + list(all_ret[k].shape[1:])
+            all_ret[k] = torch.reshape(all_ret[k], k_sh)
+
+        ret_list = [all_ret[k] for k in _KEYS_MAIN]
+        ret_dict = {k: all_ret[k] for k in all_ret if k not in _KEYS_MAIN}
+        return ret_list + [ret_dict]
+
+    def raw2outputs(self, raw, z_vals, rays_d, pytest=False):
+        """raw [R,S,>=4], z_vals [R,S], rays_d [R,3] -> rgb_map, disp_map, acc_map,
+        weights, depth_map (render_utils.py:241-290)."""
+        _lib.require_device(raw, "raw")
+        dev = raw.device
+        raw_c = raw.detach().contiguous().float()
+        if raw_c.dim() != 3 or raw_c.shape[-1] < 4:
+            raise _lib.NerfAmdError("raw must be [num_rays, num_samples, >=4]")
+        R, S, ch = raw_c.shape
+        z = z_vals.detach().contiguous().float()
+        d = rays_d.detach().contiguous().float()
+        noise = None
+        if self.raw_noise_std > 0.:
+            noise = (_pytest_uniform([R, S], dev) if pytest else torch.randn([R, S], device=dev)) * self.raw_noise_std
+        f = dict(device=dev, dtype=torch.float32)
+        rgb_map, disp_map, acc_map = torch.empty(R, 3, **f), torch.empty(R, **f), torch.empty(R, **f)
+        weights, depth_map = torch.empty(R, S, **f), torch.empty(R, **f)
+        with torch.cuda.device(dev):
+            _lib.check(lib.nerf_amd_raw2outputs(raw_c.data_ptr(), ch, z.data_ptr(), d.data_ptr(), 3, _lib.ptr(noise),
+                                                R, S, int(bool(self.white_bkgd)), rgb_map.data_ptr(),
+                                                disp_map.data_ptr(), acc_map.data_ptr(), weights.data_ptr(),
+                                                depth_map.data_ptr(), _lib.stream_of(dev)), "nerf_amd_raw2outputs")
+        return rgb_map, disp_map, acc_map, weights, depth_map
+
+    def render_from_batch_poses(self, H, W, K, chunk, batch_c2w, coarse_model, fine_model,
+                                retraw, save_directory, b_combine_as_video=False, tb_writer=None):
+        """Render a set of poses and save them (render_utils.py:293-319).  PNG/video
+        writing needs imageio, which is outside the hot path; without it the
+        frames are saved as .npy."""
+        os.makedirs(save_directory, exist_ok=True)
+        try:
+            import imageio
+        except ImportError:
+            imageio = None
+        rgbs = []
+        with torch.no_grad():
+            for i, c2w in enumerate(batch_c2w):
+                rgb, _, _, _ = self.render_from_pose(H, W, K, chunk=chunk, c2w=c2w,
+                                                     coarse_model=coarse_model, fine_model=fine_model)
+                rgbs.append(rgb.cpu().detach().numpy())
+                rgb8 = utils.to8b(rgbs[-1])
+                if imageio is not None:
+                    imageio.imwrite(os.path.join(save_directory, '{:03d}.png'.format(i)), rgb8)
+                else:
+                    np.save(os.path.join(save_directory, '{:03d}.npy'.format(i)), rgb8)
+            if b_combine_as_video and imageio is not None:
+                imageio.mimwrite(os.path.join(save_directory, 'video.mp4'), utils.to8b(rgbs), fps=30, quality=8)
+            if tb_writer is not None:
+                rgb_tensor = torch.tensor(utils.to8b(rgbs))
+                tb_writer.add_images('Test/Images', rgb_tensor, dataformats="NHWC")
+        return rgbs

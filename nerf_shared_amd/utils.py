@@ -1,0 +1,161 @@
+"""Drop-in for the hot-path half of nerf_shared/utils.py: ray generation, the NDC
+warp, hierarchical sampling, metrics and the two factories that build models
+and renderers from an argparse namespace.
+
+Reference: /root/reference/nerf_shared/utils.py:24-161.  Dataset loaders,
+checkpoint I/O and the training-batch plumbing (utils.py:174-494) are outside
+the hot path and are not reproduced.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib
+
+# ---------------------------------------------------------------- metrics (utils.py:24-30)
+img2mse = lambda x, y: torch.mean((x - y) ** 2)                                      # noqa: E731
+mse2psnr = lambda x: -10. * torch.log(x) / torch.log(torch.Tensor([10.]).to(x.device))  # noqa: E731
+to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)                           # noqa: E731
+
+
+def _default_device():
+    if not torch.cuda.is_available():
+        raise _lib.NerfAmdError("no ROCm device visible; nerf_shared_amd has no CPU path")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _host_pose(c2w):
+    """First three rows of a camera-to-world matrix as 12 host floats (3x4 row-major)."""
+    if isinstance(c2w, torch.Tensor):
+        c2w = c2w.detach().cpu().numpy()
+    c2w = np.asarray(c2w, dtype=np.float32)
+    if c2w.ndim != 2 or c2w.shape[0] < 3 or c2w.shape[1] != 4:
+        raise ValueError("c2w must be [>=3, 4], got %s" % (c2w.shape,))
+    return np.ascontiguousarray(c2w[:3, :4])
+
+
+def make_ray_batch(H, W, K, c2w, near, far, use_viewdirs, ndc, c2w_staticcam=None, device=None,
+                   pix0=0, n=None):
+    """get_rays + viewdirs + (ndc_rays) + near/far assembled as the [n, 8|11] batch
+    that Renderer.render builds (render_utils.py:200-226), in one kernel, for the
+    flat pixel range [pix0, pix0+n) (default: the whole image)."""
+    device = device or _default_device()
+    n = H * W - pix0 if n is None else n
+    K4 = (ctypes.c_double * 4)(float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2]))
+    pose = _host_pose(c2w)
+    pose_s = _host_pose(c2w_staticcam) if c2w_staticcam is not None else None
+    ch = 11 if use_viewdirs else 8
+    out = torch.empty(n, ch, device=device, dtype=torch.float32)
+    fp = ctypes.POINTER(ctypes.c_float)
+    with torch.cuda.device(device):
+        _lib.check(lib.nerf_amd_make_rays(int(H), int(W), K4, pose.ctypes.data_as(fp),
+                                          pose_s.ctypes.data_as(fp) if pose_s is not None else None,
+                                          int(pix0), int(n), float(near), float(far), int(bool(use_viewdirs)),
+                                          int(bool(ndc)), out.data_ptr(), _lib.stream_of(device)),
+                   "nerf_amd_make_rays")
+    return out
+
+
+def get_rays(H, W, K, c2w):
+    """rays_o, rays_d [H, W, 3] (utils.py:33-42); pixel centres at integer
+    coordinates, camera looks down -z."""
+    dev = c2w.device if isinstance(c2w, torch.Tensor) and c2w.is_cuda else _default_device()
+    b = make_ray_batch(H, W, K, c2w, 0.0, 1.0, False, False, device=dev)
+    return b[:, 0:3].reshape(H, W, 3), b[:, 3:6].reshape(H, W, 3)
+
+
+def get_rays_np(H, W, K, c2w):
+    """numpy twin used by the reference's training-data batching (utils.py:45-52)."""
+    i, j = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32), indexing='xy')
+    dirs = np.stack([(i - K[0][2]) / K[0][0], -(j - K[1][2]) / K[1][1], -np.ones_like(i)], -1)
+    rays_d = np.sum(dirs[..., np.newaxis, :] * c2w[:3, :3], -1)
+    rays_o = np.broadcast_to(c2w[:3, -1], np.shape(rays_d))
+    return rays_o, rays_d
+
+
+def ndc_rays(H, W, focal, near, rays_o, rays_d):
+    """Forward-facing NDC warp (utils.py:54-71).  Twelve flops per ray: plain
+    device tensor arithmetic (the fused image path applies the same warp inside
+    nerf_amd_make_rays)."""
+    t = -(near + rays_o[..., 2]) / rays_d[..., 2]
+    rays_o = rays_o + t[..., None] * rays_d
+    sx = -1. / (W / (2. * focal))
+    sy = -1. / (H / (2. * focal))
+    o0 = sx * rays_o[..., 0] / rays_o[..., 2]
+    o1 = sy * rays_o[..., 1] / rays_o[..., 2]
+    o2 = 1. + 2. * near / rays_o[..., 2]
+    d0 = sx * (rays_d[..., 0] / rays_d[..., 2] - rays_o[..., 0] / rays_o[..., 2])
+    d1 = sy * (rays_d[..., 1] / rays_d[..., 2] - rays_o[..., 1] / rays_o[..., 2])
+    d2 = -2. * near / rays_o[..., 2]
+    return torch.stack([o0, o1, o2], -1), torch.stack([d0, d1, d2], -1)
+
+
+def sample_pdf(bins, weights, N_samples, det=False, pytest=False):
+    """Inverse-CDF sampling along each ray (utils.py:74-117).
+    bins [R, M], weights [R, M-1] -> samples [R, N_samples]."""
+    _lib.require_device(bins, "bins")
+    dev = bins.device
+    lead = list(bins.shape[:-1])
+    b = bins.detach().reshape(-1, bins.shape[-1]).contiguous().float()
+    w = weights.detach().reshape(-1, weights.shape[-1]).contiguous().float()
+    if w.shape[-1] != b.shape[-1] - 1 or w.shape[0] != b.shape[0]:
+        raise _lib.NerfAmdError("weights must be [..., len(bins)-1]")
+    R = b.shape[0]
+    u = t_lin = None
+    if pytest:
+        np.random.seed(0)
+        if det:
+            un = np.broadcast_to(np.linspace(0., 1., N_samples), [R, N_samples])
+        else:
+            un = np.random.rand(R, N_samples)
+        u = torch.Tensor(np.ascontiguousarray(un)).to(dev)
+    elif det:
+        t_lin = torch.linspace(0., 1., steps=N_samples, device=dev)
+    else:
+        u = torch.rand([R, N_samples], device=dev)
+    out = torch.empty(R, N_samples, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _lib.check(lib.nerf_amd_sample_pdf(b.data_ptr(), w.data_ptr(), _lib.ptr(u), _lib.ptr(t_lin), R,
+                                           b.shape[-1], int(N_samples), out.data_ptr(), _lib.stream_of(dev)),
+                   "nerf_amd_sample_pdf")
+    return out.reshape(lead + [N_samples])
+
+
+# ---------------------------------------------------------------- factories (utils.py:119-161)
+def create_nerf_models(args, device=None):
+    """coarse (+ fine when N_importance > 0) NeRF from an args namespace (utils.py:119-139)."""
+    from . import nerf
+    device = device or _default_device()
+    output_ch = 5 if args.N_importance > 0 else 4
+    skips = [4]
+    coarse_model = nerf.NeRF(D=args.netdepth, W=args.netwidth, output_ch=output_ch, skips=skips,
+                             use_viewdirs=args.use_viewdirs, multires=args.multires,
+                             multires_views=args.multires_views, i_embed=args.i_embed).to(device)
+    fine_model = None
+    if args.N_importance > 0:
+        fine_model = nerf.NeRF(D=args.netdepth_fine, W=args.netwidth_fine, output_ch=output_ch, skips=skips,
+                               use_viewdirs=args.use_viewdirs, multires=args.multires,
+                               multires_views=args.multires_views, i_embed=args.i_embed).to(device)
+    return coarse_model, fine_model
+
+
+def get_renderer(args, bds_dict):
+    """Renderer from an args namespace + {'near':..., 'far':...} (utils.py:141-161)."""
+    from . import render_utils
+    render_kwargs = {
+        'perturb': args.perturb,
+        'N_importance': args.N_importance,
+        'N_samples': args.N_samples,
+        'use_viewdirs': args.use_viewdirs,
+        'white_bkgd': args.white_bkgd,
+        'raw_noise_std': args.raw_noise_std,
+        'ndc': True,
+        'lindisp': args.lindisp,
+    }
+    if args.dataset_type != 'llff' or args.no_ndc:
+        print('Not ndc!')
+        render_kwargs['ndc'] = False
+    render_kwargs.update(bds_dict)
+    return render_utils.Renderer(**render_kwargs)

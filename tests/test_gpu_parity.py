@@ -1,0 +1,441 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI by the
+Python drop-in, against (a) the golden vectors the reference produced and
+(b) the CPU oracle on the same seeded inputs; plus size-independent
+properties at the benchmark's full batch size.
+
+Tolerances (fp32 inputs everywhere):
+  * per-ray stages (z_vals, raw2outputs, sample_pdf, sort): 1e-5 abs on
+    quantities of order 1 -- same arithmetic, libm-level differences only;
+  * field MLP, fp32 mode (exact-fp32 MFMA, different summation order than the
+    CPU GEMM): 1e-4 abs + 1e-4 rel on raw outputs of magnitude <= ~20;
+  * field MLP, bf16 mode (bf16 operands, fp32 accumulate): relative L2 error
+    <= 3e-2 on raw outputs, image PSNR >= 30 dB against the fp32 reference on
+    the sharpened weights (the SURVEY's CPU bf16-autocast of the reference
+    measured 39.8 dB there and 61 dB on default-scale weights).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+os.environ.setdefault("NERF_AMD_QUIET", "1")
+
+pytestmark = pytest.mark.gpu
+
+from nerf_shared_amd import synth  # noqa: E402
+from oracle import nerf_oracle as O  # noqa: E402
+
+VD = dict(D=8, W=256, output_ch=5, skips=[4], use_viewdirs=True, multires=10, multires_views=4)
+NOVD = dict(D=8, W=256, output_ch=5, skips=[4], use_viewdirs=False, multires=10, multires_views=4)
+BASE = dict(perturb=0.0, N_importance=128, N_samples=64, use_viewdirs=True, white_bkgd=True,
+            raw_noise_std=0.0, ndc=False, lindisp=False, near=2.0, far=6.0)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "-m gpu tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+def amd():
+    from nerf_shared_amd import nerf, render_utils, utils
+    return nerf, render_utils, utils
+
+
+def gpu_model(dev, seed, sharpen, precision, **arch):
+    nerf, _, _ = amd()
+    m = nerf.NeRF(**arch)
+    m.load_state_dict(synth.torch_state_dict(seed, sharpen, **{**arch, "skips": tuple(arch["skips"])}))
+    m.precision = precision
+    return m.to(dev)
+
+
+def cpu_model(seed, sharpen, **arch):
+    return O.state_dict_to_torch(synth.make_state_dict(seed, sharpen, **{**arch, "skips": tuple(arch["skips"])})), O.Arch(**arch)
+
+
+def close(a, b, atol, rtol=0.0):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
+    np.testing.assert_allclose(np.nan_to_num(a), np.nan_to_num(b), atol=atol, rtol=rtol)
+
+
+def rel_l2(a, b):
+    a = a.detach().cpu().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, np.float64)
+    b = b.detach().cpu().double().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def psnr(a, b):
+    a, b = torch.as_tensor(a).detach().cpu().double(), torch.as_tensor(b).detach().cpu().double()
+    return float(-10.0 * torch.log10(torch.mean((a - b) ** 2) + 1e-30))
+
+
+def test_native_library_loaded(dev):
+    from nerf_shared_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH)
+    with open("/proc/self/maps") as f:
+        assert "libnerf_amd.so" in f.read()
+
+
+# ------------------------------------------------------------------ G1
+def test_embedder_golden(dev, golden):
+    nerf, _, _ = amd()
+    g = golden("g1_embedder")
+    x = torch.from_numpy(g["x"]).to(dev)
+    for L in (10, 4, 15, 6):
+        fn, dim = nerf.get_embedder(L, 0)
+        assert dim == 3 + 6 * L
+        close(fn(x), g["L%d" % L], atol=2e-6)
+    fn, dim = nerf.get_embedder(10, -1)
+    assert dim == 3
+    close(fn(x), g["identity"], atol=0)
+    # leading dims are preserved
+    fn, _ = nerf.get_embedder(4, 0)
+    assert fn(x.reshape(8, 8, 3)).shape == (8, 8, 27)
+
+
+# ------------------------------------------------------------------ G2
+@pytest.mark.parametrize("tag,seed,sharpen", [("s0", 0, 1.0), ("s1", 1, 3.0)])
+def test_nerf_forward_fp32_golden(dev, golden, tag, seed, sharpen):
+    g = golden("g2_nerf")
+    pts, vd = torch.from_numpy(g["pts"]).to(dev), torch.from_numpy(g["viewdirs"]).to(dev)
+    m = gpu_model(dev, seed, sharpen, "fp32", **VD)
+    close(m(pts, vd), g["vd_" + tag], atol=1e-4, rtol=1e-4)
+    close(m.get_density(pts), g["density_" + tag], atol=1e-4, rtol=1e-4)
+    m2 = gpu_model(dev, seed, sharpen, "fp32", **NOVD)
+    out = m2(pts, None)
+    assert out.shape == (32, 8, 5)
+    close(out, g["novd_" + tag], atol=1e-4, rtol=1e-4)
+
+
+def test_nerf_forward_fp32_other_archs(dev, golden):
+    g = golden("g2_nerf")
+    pts, vd = torch.from_numpy(g["pts"]).to(dev), torch.from_numpy(g["viewdirs"]).to(dev)
+    small = dict(D=4, W=128, output_ch=4, skips=[1], use_viewdirs=True, multires=6, multires_views=2)
+    close(gpu_model(dev, 5, 3.0, "fp32", **small)(pts, vd), g["small_s1"], atol=1e-4, rtol=1e-4)
+    wide = dict(VD, multires=15, multires_views=6)
+    close(gpu_model(dev, 6, 3.0, "fp32", **wide)(pts, vd), g["wide_s1"], atol=2e-4, rtol=2e-4)
+    # bf16 requested on an architecture the fused kernel does not cover: still HIP, fp32 rate
+    close(gpu_model(dev, 5, 3.0, "bf16", **small)(pts, vd), g["small_s1"], atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("tag,seed,sharpen", [("s0", 0, 1.0), ("s1", 1, 3.0)])
+def test_nerf_forward_bf16_golden(dev, golden, tag, seed, sharpen):
+    g = golden("g2_nerf")
+    pts, vd = torch.from_numpy(g["pts"]).to(dev), torch.from_numpy(g["viewdirs"]).to(dev)
+    m = gpu_model(dev, seed, sharpen, "bf16", **VD)
+    assert m.supports_bf16()
+    assert rel_l2(m(pts, vd), g["vd_" + tag]) < 3e-2
+    m2 = gpu_model(dev, seed, sharpen, "bf16", **NOVD)
+    assert rel_l2(m2(pts, None), g["novd_" + tag]) < 3e-2
+    wide = dict(VD, multires=15, multires_views=6)
+    if tag == "s1":
+        assert rel_l2(gpu_model(dev, 6, 3.0, "bf16", **wide)(pts, vd), g["wide_s1"]) < 3e-2
+
+
+def test_nerf_forward_ragged_and_large(dev, golden):
+    """Point counts that are not multiples of the 256-point workgroup tile, and the
+    reference's > netchunk case (70400 points, strided subset pinned by the golden)."""
+    g = golden("g2_nerf")
+    rng2 = np.random.default_rng(203)
+    big = torch.from_numpy(rng2.uniform(-3, 3, size=(1100, 64, 3)).astype(np.float32)).to(dev)
+    bvd = rng2.normal(size=(1100, 3)).astype(np.float32)
+    bvd /= np.linalg.norm(bvd, axis=-1, keepdims=True)
+    bvd = torch.from_numpy(bvd).to(dev)
+    stride = int(g["big_stride"])
+    m32 = gpu_model(dev, 1, 3.0, "fp32", **VD)
+    full32 = m32(big, bvd)
+    close(full32.reshape(-1, 4)[::stride], g["big_subset"], atol=1e-4, rtol=1e-4)
+    mbf = gpu_model(dev, 1, 3.0, "bf16", **VD)
+    fullbf = mbf(big, bvd)
+    assert rel_l2(fullbf.reshape(-1, 4)[::stride], g["big_subset"]) < 3e-2
+    # ragged: 37 rays x 5 samples = 185 points; results must equal the same rays inside the big batch
+    sub, subvd = big[:37, :5].contiguous(), bvd[:37].contiguous()
+    close(m32(sub, subvd), full32[:37, :5], atol=0)
+    close(mbf(sub, subvd), fullbf[:37, :5], atol=0)
+    # a single point
+    one = mbf(big[:1, :1].contiguous(), bvd[:1].contiguous())
+    close(one, fullbf[:1, :1], atol=0)
+
+
+def test_weight_update_repacks(dev, golden):
+    g = golden("g2_nerf")
+    pts, vd = torch.from_numpy(g["pts"]).to(dev), torch.from_numpy(g["viewdirs"]).to(dev)
+    m = gpu_model(dev, 0, 1.0, "fp32", **VD)
+    close(m(pts, vd), g["vd_s0"], atol=1e-4, rtol=1e-4)
+    m.load_state_dict({k: v.to(dev) for k, v in synth.torch_state_dict(1, 3.0, **{**VD, "skips": (4,)}).items()})
+    close(m(pts, vd), g["vd_s1"], atol=1e-4, rtol=1e-4)
+
+
+# ------------------------------------------------------------------ G3
+def test_raw2outputs_golden(dev, golden):
+    _, render_utils, _ = amd()
+    g = golden("g3_raw2outputs")
+    raw, z, rd = (torch.from_numpy(g[k]).to(dev) for k in ("raw", "z_vals", "rays_d"))
+    names = ("rgb", "disp", "acc", "weights", "depth")
+    for white in (True, False):
+        r = render_utils.Renderer(perturb=0.0, white_bkgd=white, raw_noise_std=0.0)
+        for n, v in zip(names, r.raw2outputs(raw, z, rd)):
+            close(v, g["%s_white%d" % (n, white)], atol=2e-6, rtol=2e-5)
+    r = render_utils.Renderer(perturb=0.0, white_bkgd=True, raw_noise_std=1.0)
+    for n, v in zip(names, r.raw2outputs(raw, z, rd, pytest=True)):
+        close(v, g["%s_noise" % n], atol=2e-6, rtol=2e-5)
+    r = render_utils.Renderer(perturb=0.0, white_bkgd=True, raw_noise_std=0.0)
+    res = r.raw2outputs(*(torch.from_numpy(g[k]).to(dev) for k in ("raw_192", "z_vals_192", "rays_d_192")))
+    for n, v in zip(names, res):
+        close(v, g["%s_192" % n], atol=2e-6, rtol=2e-5)
+    # 5-channel raw (no-viewdirs models emit output_ch=5; the 5th channel is ignored)
+    raw5 = torch.cat([raw, torch.randn_like(raw[..., :1])], -1)
+    for n, v in zip(names, r.raw2outputs(raw5, z, rd)):
+        close(v, g["%s_white1" % n], atol=2e-6, rtol=2e-5)
+
+
+# ------------------------------------------------------------------ G4
+def test_sample_pdf_golden(dev, golden):
+    _, _, utils = amd()
+    g = golden("g4_sample_pdf")
+    bins, w = torch.from_numpy(g["bins"]).to(dev), torch.from_numpy(g["weights"]).to(dev)
+    for N in (64, 128):
+        close(utils.sample_pdf(bins, w, N, det=True), g["det_N%d" % N], atol=1e-5)
+        close(utils.sample_pdf(bins, w, N, det=True, pytest=True), g["detpytest_N%d" % N], atol=1e-5)
+        close(utils.sample_pdf(bins, w, N, det=False, pytest=True), g["rand_N%d" % N], atol=1e-5)
+    known = utils.sample_pdf(torch.from_numpy(g["known_bins"]).to(dev), torch.from_numpy(g["known_weights"]).to(dev), 8, det=True)
+    close(known, g["known_det8"], atol=1e-6)
+    # random draws: range and monotone dependence on u are the testable properties
+    s = utils.sample_pdf(bins, w, 128, det=False)
+    assert s.shape == (128, 128)
+    assert bool((s >= bins[:, :1] - 1e-6).all()) and bool((s <= bins[:, -1:] + 1e-6).all())
+
+
+# ------------------------------------------------------------------ G5
+G5_CASES = {
+    "det_s0": (dict(), VD, (0, 10, 1.0), False),
+    "det_s1": (dict(), VD, (1, 11, 3.0), False),
+    "perturb_s1": (dict(perturb=1.0), VD, (1, 11, 3.0), True),
+    "lindisp_s1": (dict(lindisp=True), VD, (1, 11, 3.0), False),
+    "coarseonly_s1": (dict(N_importance=0), VD, (1, None, 3.0), False),
+    "nofine_s1": (dict(), VD, (1, None, 3.0), False),
+    "black_noise_s1": (dict(white_bkgd=False, raw_noise_std=1.0, perturb=1.0), VD, (1, 11, 3.0), True),
+    "novd_s1": (dict(use_viewdirs=False), NOVD, (2, 12, 3.0), False),
+    "fern_s1": (dict(N_importance=64, ndc=True, near=0.0, far=1.0, white_bkgd=False,
+                     raw_noise_std=1.0, perturb=1.0), VD, (1, 11, 3.0), True),
+}
+G5_KEYS = ("rgb_map", "disp_map", "acc_map", "raw", "weights", "z_vals", "rgb0", "disp0", "acc0", "z_std")
+G5_TOL = {"rgb_map": 2e-4, "acc_map": 2e-4, "rgb0": 2e-4, "acc0": 2e-4, "weights": 2e-4,
+          "raw": 2e-4, "z_vals": 2e-5, "z_std": 2e-5, "disp_map": 2e-4, "disp0": 2e-4}
+
+
+@pytest.mark.parametrize("tag", sorted(G5_CASES))
+def test_render_rays_fp32_golden(dev, golden, tag):
+    _, render_utils, _ = amd()
+    g = golden("g5_render_rays")
+    over, arch, (sc, sf, sharpen), pytest_flag = G5_CASES[tag]
+    r = render_utils.Renderer(**dict(BASE, **over))
+    coarse = gpu_model(dev, sc, sharpen, "fp32", **arch)
+    fine = gpu_model(dev, sf, sharpen, "fp32", **arch) if sf is not None else None
+    ret = r.render_rays(torch.from_numpy(g[tag + "__batch"]).to(dev), coarse, fine,
+                        retraw=True, retweights=True, pytest=pytest_flag)
+    expected = [k for k in G5_KEYS if tag + "__" + k in g]
+    assert list(ret.keys()) == [k for k in ("rgb_map", "disp_map", "acc_map", "raw", "weights", "z_vals",
+                                            "rgb0", "disp0", "acc0", "z_std") if k in expected]
+    for k in expected:
+        close(ret[k], g[tag + "__" + k], atol=G5_TOL[k], rtol=2e-4)
+    # without retraw / retweights those keys are absent
+    ret2 = r.render_rays(torch.from_numpy(g[tag + "__batch"]).to(dev), coarse, fine, pytest=pytest_flag)
+    assert "raw" not in ret2 and "weights" not in ret2 and "z_vals" not in ret2
+    close(ret2["rgb_map"], ret["rgb_map"], atol=0)
+
+
+@pytest.mark.parametrize("tag", ["det_s0", "det_s1", "novd_s1", "fern_s1"])
+def test_render_rays_bf16_golden(dev, golden, tag):
+    """bf16 mode: depth samples are a discontinuous function of the coarse weights
+    only through searchsorted, so compare maps, not per-sample raw."""
+    _, render_utils, _ = amd()
+    g = golden("g5_render_rays")
+    over, arch, (sc, sf, sharpen), pytest_flag = G5_CASES[tag]
+    r = render_utils.Renderer(**dict(BASE, **over))
+    coarse = gpu_model(dev, sc, sharpen, "bf16", **arch)
+    fine = gpu_model(dev, sf, sharpen, "bf16", **arch)
+    ret = r.render_rays(torch.from_numpy(g[tag + "__batch"]).to(dev), coarse, fine, pytest=pytest_flag)
+    for k in ("rgb_map", "rgb0"):
+        a, b = ret[k].cpu().numpy(), g[tag + "__" + k]
+        # the last sample's alpha is a step function of the sign of sigma (dists[-1] = 1e10,
+        # render_utils.py:257): with sigma ~ 0 a bf16 rounding flips whole rays, so bound the
+        # median and the fraction of rays that moved instead of the max
+        err = np.abs(a - b).max(-1)
+        assert np.median(err) < 2e-2, (k, np.median(err))
+        assert (err > 0.1).mean() < 0.2, (k, (err > 0.1).mean())
+
+
+# ------------------------------------------------------------------ G6
+def test_rays_golden(dev, golden):
+    _, _, utils = amd()
+    g = golden("g6_rays")
+    c2w = torch.from_numpy(synth.LEGO_C2W)
+    ro, rd = utils.get_rays(4, 6, g["small_K"], c2w)
+    assert ro.shape == (4, 6, 3) and ro.is_cuda
+    close(ro, g["small_rays_o"], atol=0)
+    close(rd, g["small_rays_d"], atol=2e-7, rtol=2e-7)
+    c2w4 = torch.eye(4)
+    c2w4[:3, :4] = c2w
+    ro, rd = utils.get_rays(4, 6, g["small_K"], c2w4.to(dev))
+    close(rd, g["small4_rays_d"], atol=2e-7, rtol=2e-7)
+    K = synth.lego_intrinsics(400, 400)
+    ro, rd = utils.get_rays(400, 400, K, c2w)
+    close(rd.reshape(-1, 3)[torch.from_numpy(g["lego_corners"]).to(dev)], g["lego_rays_d"], atol=2e-7, rtol=2e-7)
+    H, W, focal = g["ndc_HWf"]
+    o2, d2 = utils.ndc_rays(int(H), int(W), float(focal), 1.0, torch.from_numpy(g["ndc_in_o"]).to(dev),
+                            torch.from_numpy(g["ndc_in_d"]).to(dev))
+    close(o2, g["ndc_out_o"], atol=1e-6, rtol=1e-6)
+    close(d2, g["ndc_out_d"], atol=1e-6, rtol=1e-6)
+    rn_o, rn_d = utils.get_rays_np(4, 6, g["small_K"], synth.LEGO_C2W)
+    close(rn_d, g["small_rays_d_np"], atol=1e-12)
+
+
+# ------------------------------------------------------------------ G7
+def test_render_golden(dev, golden):
+    _, render_utils, _ = amd()
+    g = golden("g7_render")
+    r = render_utils.Renderer(**BASE)
+    coarse, fine = gpu_model(dev, 1, 3.0, "fp32", **VD), gpu_model(dev, 11, 3.0, "fp32", **VD)
+    rgb, disp, acc, extras = r.render(16, 16, g["K"], coarse, fine, chunk=100, c2w=torch.from_numpy(g["c2w"]), retraw=True)
+    assert rgb.shape == (16, 16, 3) and disp.shape == (16, 16)
+    close(rgb, g["pose_rgb"], atol=2e-4)
+    close(disp, g["pose_disp"], atol=2e-4, rtol=2e-4)
+    close(acc, g["pose_acc"], atol=2e-4)
+    assert sorted(extras) == sorted(k[len("pose_extra_"):] for k in g if k.startswith("pose_extra_"))
+    assert extras["raw"].shape == (16, 16, 192, 4)
+    for k, v in extras.items():
+        close(v, g["pose_extra_" + k], atol=2e-4, rtol=2e-4)
+    rays = torch.from_numpy(g["rays_in"]).to(dev)
+    rgb, disp, acc, extras = r.render(16, 16, g["K"], coarse, fine, chunk=32768, rays=rays, retraw=False)
+    close(rgb, g["rays_rgb"], atol=2e-4)
+    assert "raw" not in extras
+    for k, v in extras.items():
+        close(v, g["rays_extra_" + k], atol=2e-4, rtol=2e-4)
+    rn = render_utils.Renderer(**dict(BASE, ndc=True, near=0.0, far=1.0, N_importance=64, white_bkgd=False))
+    rgb, disp, acc, extras = rn.render(12, 16, g["ndc_K"], coarse, fine, chunk=77, c2w=torch.from_numpy(g["ndc_c2w"]), retraw=False)
+    close(rgb, g["ndc_rgb"], atol=2e-4)
+    close(acc, g["ndc_acc"], atol=2e-4)
+    close(disp, g["ndc_disp"], atol=2e-4, rtol=2e-4)
+    # wrappers
+    out = r.render_from_pose(16, 16, g["K"], 100, torch.from_numpy(g["c2w"]), coarse, fine, retraw=False)
+    close(out[0], g["pose_rgb"], atol=2e-4)
+    out = r.render_from_rays(16, 16, g["K"], 32768, rays, coarse, fine, retraw=False)
+    close(out[0], g["rays_rgb"], atol=2e-4)
+
+
+# ------------------------------------------------------------------ G8 + PSNR
+def test_psnr_crop(dev, golden):
+    _, render_utils, _ = amd()
+    g = golden("g8_psnr_crop")
+    H = W = 800
+    K = synth.lego_intrinsics(H, W)
+    ro, rd = synth.rays_np(H, W, K, synth.LEGO_C2W, g["pixel_index"])
+    rays = torch.from_numpy(np.stack([ro, rd], 0)).to(dev)
+    r = render_utils.Renderer(**BASE)
+    report = {}
+    for tag, (sc, sf, sh) in (("s0", (0, 10, 1.0)), ("s1", (1, 11, 3.0))):
+        for prec in ("fp32", "bf16"):
+            c, f = gpu_model(dev, sc, sh, prec, **VD), gpu_model(dev, sf, sh, prec, **VD)
+            rgb, disp, acc, extras = r.render(H, W, K, c, f, chunk=4096, rays=rays, retraw=False)
+            report[(tag, prec)] = psnr(rgb, g["rgb_" + tag])
+    print("PSNR vs reference fp32 render:", report)
+    assert report[("s0", "fp32")] > 80 and report[("s1", "fp32")] > 70
+    assert report[("s0", "bf16")] > 45 and report[("s1", "bf16")] > 30
+
+
+# ------------------------------------------------------------------ oracle on fresh seeded inputs
+def test_render_rays_vs_oracle_seeded(dev):
+    _, render_utils, _ = amd()
+    rng = np.random.default_rng(99)
+    K = synth.lego_intrinsics(400, 400)
+    idx = np.sort(rng.choice(160000, size=333, replace=False))      # ragged: not a multiple of anything
+    ro, rd = synth.rays_np(400, 400, K, synth.pose_spherical(37.0), idx)
+    batch = torch.from_numpy(synth.ray_batch_np(ro, rd, 2.0, 6.0, True))
+    cfg = dict(BASE, N_samples=48, N_importance=80)                  # non-default, non-power-of-two sample counts
+    ref = O.render_rays(O.RenderCfg(**cfg), batch, cpu_model(21, 3.0, **VD), cpu_model(22, 3.0, **VD),
+                        retraw=True, retweights=True)
+    r = render_utils.Renderer(**cfg)
+    out = r.render_rays(batch.to(dev), gpu_model(dev, 21, 3.0, "fp32", **VD), gpu_model(dev, 22, 3.0, "fp32", **VD),
+                        retraw=True, retweights=True)
+    for k in ref:
+        close(out[k], ref[k], atol=G5_TOL[k], rtol=2e-4)
+
+
+def test_empty_and_errors(dev):
+    nerf, render_utils, utils = amd()
+    from nerf_shared_amd._lib import NerfAmdError
+    m = gpu_model(dev, 0, 1.0, "bf16", **VD)
+    r = render_utils.Renderer(**BASE)
+    out = r.render_rays(torch.empty(0, 11, device=dev), m, m)
+    assert out["rgb_map"].shape == (0, 3) and out["z_std"].shape == (0,)
+    with pytest.raises(NerfAmdError):
+        r.render_rays(torch.zeros(4, 11), m, m)                      # CPU tensor: no CPU path
+    with pytest.raises(NerfAmdError):
+        r.render_rays(torch.zeros(4, 7, device=dev), m, m)           # bad width
+    with pytest.raises(NerfAmdError):
+        r.render_rays(torch.zeros(4, 8, device=dev), m, m)           # viewdirs model, no viewdirs in batch
+    with pytest.raises(TypeError):
+        r.render_rays(torch.zeros(4, 11, device=dev), torch.nn.Linear(3, 4), None)
+    with pytest.raises(NerfAmdError):
+        m(torch.zeros(2, 3, 3, device=dev), None)                    # use_viewdirs model needs viewdirs
+
+
+# ------------------------------------------------------------------ properties at the benchmark batch size
+def test_full_batch_properties(dev):
+    """C2 size: 4096 rays x (64 + 128) samples, bf16.  Properties that hold for any input."""
+    _, render_utils, utils = amd()
+    K = synth.lego_intrinsics(400, 400)
+    batch = utils.make_ray_batch(400, 400, K, synth.LEGO_C2W, 2.0, 6.0, True, False, device=dev, pix0=80000, n=4096)
+    c, f = gpu_model(dev, 1, 3.0, "bf16", **VD), gpu_model(dev, 11, 3.0, "bf16", **VD)
+    r = render_utils.Renderer(**BASE)
+    out = r.render_rays(batch, c, f, retraw=True, retweights=True)
+    z, w = out["z_vals"], out["weights"]
+    assert z.shape == (4096, 192) and bool((z[:, 1:] >= z[:, :-1]).all())          # sorted
+    assert bool((z >= 2.0 - 1e-5).all()) and bool((z <= 6.0 + 1e-5).all())
+    assert bool((w >= 0).all()) and bool((w.sum(-1) <= 1 + 1e-4).all())
+    close(out["acc_map"], w.sum(-1), atol=1e-5)
+    assert bool(((out["rgb_map"] >= -1e-5) & (out["rgb_map"] <= 1 + 1e-4)).all())
+    # the coarse grid is a subset of the merged samples
+    t = torch.linspace(0., 1., 64, device=dev)
+    zc = 2.0 * (1 - t) + 6.0 * t
+    pos = torch.searchsorted(z.contiguous(), zc.expand(4096, 64).contiguous())
+    assert bool((torch.gather(z, 1, pos.clamp(max=191)) == zc).all())
+    # chunk invariance (deterministic config): different chunking, bit-identical maps
+    full = r.render_batch(c, f, batch, chunk=4096)
+    parts = r.render_batch(c, f, batch, chunk=1000)
+    for k in full:
+        close(full[k], parts[k], atol=0)
+    close(full["rgb_map"], out["rgb_map"], atol=0)
+    # ray-permutation equivariance, bit exact
+    perm = torch.randperm(4096, device=dev)
+    outp = r.render_rays(batch[perm].contiguous(), c, f)
+    close(outp["rgb_map"], out["rgb_map"][perm], atol=0)
+    close(outp["disp_map"], out["disp_map"][perm], atol=0)
+    # bf16 vs fp32 on the same rays: image-level agreement
+    for m in (c, f):
+        m.precision = "fp32"
+    out32 = r.render_rays(batch, c, f)
+    assert psnr(out["rgb_map"], out32["rgb_map"]) > 30
+
+
+def test_perturbed_run_is_seed_reproducible(dev):
+    _, render_utils, utils = amd()
+    K = synth.lego_intrinsics(400, 400)
+    batch = utils.make_ray_batch(400, 400, K, synth.LEGO_C2W, 2.0, 6.0, True, False, device=dev, pix0=1000, n=512)
+    c, f = gpu_model(dev, 1, 3.0, "bf16", **VD), gpu_model(dev, 11, 3.0, "bf16", **VD)
+    r = render_utils.Renderer(**dict(BASE, perturb=1.0, raw_noise_std=1.0))
+    torch.manual_seed(5)
+    a = r.render_rays(batch, c, f, retweights=True)
+    torch.manual_seed(5)
+    b = r.render_rays(batch, c, f, retweights=True)
+    close(a["rgb_map"], b["rgb_map"], atol=0)
+    close(a["z_vals"], b["z_vals"], atol=0)
+    assert bool((a["z_vals"][:, 1:] >= a["z_vals"][:, :-1]).all())
+    cdet = render_utils.Renderer(**BASE).render_rays(batch, c, f, retweights=True)
+    assert not torch.equal(cdet["z_vals"], a["z_vals"])

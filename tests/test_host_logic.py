@@ -1,0 +1,187 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol
+declared in include/nerf_amd.h, the Python drop-in keeps the reference's
+surface (signatures, state_dict keys), refuses CPU tensors loudly, and the
+multi-GPU sharding/gather logic is correct (gloo, world_size 2).  No compute
+call reaches a GPU here.
+"""
+import ctypes
+import inspect
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+os.environ.setdefault("NERF_AMD_QUIET", "1")
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from nerf_shared_amd import _lib, dist as nd, nerf, render_utils, synth, utils  # noqa: E402
+
+
+def test_library_exports_every_declared_symbol():
+    with open(os.path.join(REPO, "include", "nerf_amd.h")) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    declared = set(re.findall(r"\b(nerf_amd_[a-z0-9_]+)\s*\(", text))
+    assert len(declared) >= 15
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), "library does not export %s" % name
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert lib.nerf_amd_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    assert ctypes.sizeof(_lib.Arch) == 4 * (8 + 8)
+    assert ctypes.sizeof(_lib.RenderCfg) == 32
+    assert ctypes.sizeof(_lib.RenderIO) == 8 + 8 + 8 * 17 + 8
+
+
+def test_program_validation_errors():
+    lib = _lib.lib
+    h = ctypes.c_void_p()
+    bad = _lib.make_arch(8, 250, 4, [4], True, 10, 4, 0)        # W not a multiple of 32
+    nf = ctypes.c_int64()
+    assert lib.nerf_amd_pack_bf16_host(ctypes.byref(bad), None, None, 0, None, ctypes.byref(nf), None, None) == -1
+    assert b"multiple of 32" in lib.nerf_amd_last_error()
+    bad = _lib.make_arch(8, 256, 4, [7], True, 10, 4, 0)        # skip on the last layer: the reference fails too
+    assert lib.nerf_amd_pack_bf16_host(ctypes.byref(bad), None, None, 0, None, ctypes.byref(nf), None, None) == -1
+    with pytest.raises(ValueError):
+        _lib.make_arch(8, 256, 4, list(range(9)), True, 10, 4, 0)
+    del h
+
+
+def test_nerf_surface_matches_reference():
+    sig = inspect.signature(nerf.NeRF.__init__)
+    assert list(sig.parameters)[1:] == ["D", "W", "output_ch", "skips", "use_viewdirs", "multires", "multires_views", "i_embed"]
+    assert [p.default for p in list(sig.parameters.values())[1:]] == [8, 256, 4, [4], False, 10, 4, 0]
+    assert list(inspect.signature(nerf.NeRF.forward).parameters) == ["self", "inputs", "viewdirs", "netchunk"]
+    assert list(inspect.signature(nerf.NeRF.get_density).parameters) == ["self", "points", "chunk"]
+    m = nerf.NeRF(use_viewdirs=True, output_ch=5)
+    assert (m.D, m.W, m.skips, m.use_viewdirs, m.input_ch, m.input_ch_views) == (8, 256, [4], True, 63, 27)
+    keys = set(m.state_dict().keys())
+    expect = {"pts_linears.%d.%s" % (i, s) for i in range(8) for s in ("weight", "bias")}
+    expect |= {"%s.%s" % (n, s) for n in ("views_linears.0", "feature_linear", "alpha_linear", "rgb_linear")
+               for s in ("weight", "bias")}
+    assert keys == expect
+    assert sum(p.numel() for p in m.parameters()) == 595844
+    assert tuple(m.pts_linears[5].weight.shape) == (256, 319)
+    assert tuple(m.views_linears[0].weight.shape) == (128, 283)
+    m2 = nerf.NeRF(use_viewdirs=False, output_ch=5)
+    assert "output_linear.weight" in m2.state_dict() and "views_linears.0.weight" in m2.state_dict()
+    assert tuple(m2.output_linear.weight.shape) == (5, 256)
+    # synthetic state dicts have exactly these keys and shapes
+    sd = synth.torch_state_dict(0, 1.0, D=8, W=256, output_ch=5, skips=(4,), use_viewdirs=True)
+    m.load_state_dict(sd)
+    fn, dim = nerf.get_embedder(10, 0)
+    assert dim == 63 and callable(fn)
+    fn, dim = nerf.get_embedder(10, -1)
+    assert dim == 3 and isinstance(fn, torch.nn.Identity)
+
+
+def test_renderer_surface_matches_reference():
+    sig = inspect.signature(render_utils.Renderer.__init__)
+    assert list(sig.parameters)[1:] == ["perturb", "N_importance", "N_samples", "use_viewdirs", "white_bkgd",
+                                        "raw_noise_std", "ndc", "lindisp", "near", "far"]
+    assert [p.default for p in list(sig.parameters.values())[1:]] == [True, 128, 64, True, True, 0.0, False, False, 0.0, 1.0]
+    R = render_utils.Renderer
+    assert list(inspect.signature(R.render).parameters) == ["self", "H", "W", "K", "coarse_model", "fine_model", "chunk",
+                                                            "rays", "retraw", "c2w", "c2w_staticcam"]
+    assert inspect.signature(R.render).parameters["chunk"].default == 1024 * 32
+    assert inspect.signature(R.render).parameters["retraw"].default is True
+    assert list(inspect.signature(R.render_rays).parameters) == ["self", "ray_batch", "coarse_model", "fine_model",
+                                                                 "retraw", "retweights", "verbose", "pytest"]
+    assert list(inspect.signature(R.render_batch).parameters) == ["self", "coarse_model", "fine_model", "rays_flat", "chunk", "retraw"]
+    assert list(inspect.signature(R.raw2outputs).parameters) == ["self", "raw", "z_vals", "rays_d", "pytest"]
+    assert list(inspect.signature(R.render_from_pose).parameters) == ["self", "H", "W", "K", "chunk", "c2w", "coarse_model", "fine_model", "retraw"]
+    assert list(inspect.signature(R.render_from_rays).parameters) == ["self", "H", "W", "K", "chunk", "rays", "coarse_model", "fine_model", "retraw"]
+    assert list(inspect.signature(utils.sample_pdf).parameters) == ["bins", "weights", "N_samples", "det", "pytest"]
+    assert list(inspect.signature(utils.get_rays).parameters) == ["H", "W", "K", "c2w"]
+    assert list(inspect.signature(utils.ndc_rays).parameters) == ["H", "W", "focal", "near", "rays_o", "rays_d"]
+    r = R(perturb=0.0, near=2.0, far=6.0)
+    assert isinstance(r, torch.nn.Module) and len(list(r.parameters())) == 0
+
+
+def test_cpu_tensors_are_refused_loudly():
+    """The product has no CPU path: it must raise, never fall back."""
+    m = nerf.NeRF(use_viewdirs=True)
+    r = render_utils.Renderer(perturb=0.0, near=2.0, far=6.0)
+    with pytest.raises(_lib.NerfAmdError, match="no CPU path"):
+        m(torch.zeros(2, 4, 3), torch.zeros(2, 3))
+    with pytest.raises(_lib.NerfAmdError, match="no CPU path"):
+        r.render_rays(torch.zeros(4, 11), m, m)
+    with pytest.raises(_lib.NerfAmdError, match="no CPU path"):
+        r.raw2outputs(torch.zeros(2, 4, 4), torch.zeros(2, 4), torch.zeros(2, 3))
+    with pytest.raises(_lib.NerfAmdError, match="no CPU path"):
+        utils.sample_pdf(torch.zeros(2, 5), torch.zeros(2, 4), 8, det=True)
+    fn, _ = nerf.get_embedder(4, 0)
+    with pytest.raises(_lib.NerfAmdError, match="no CPU path"):
+        fn(torch.zeros(2, 3))
+
+
+def test_product_does_not_import_the_oracle():
+    """Only tests, smoke() and bench.py's cpu_baseline may touch oracle/."""
+    pkg = os.path.join(REPO, "nerf_shared_amd")
+    for root, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                with open(os.path.join(root, fn)) as f:
+                    src = f.read()
+                assert "nerf_oracle" not in src and "from oracle" not in src and "import oracle" not in src, fn
+
+
+def test_metrics_and_numpy_twin():
+    x = torch.tensor([[0.0, 0.5], [1.0, 0.25]])
+    y = torch.zeros(2, 2)
+    assert float(utils.img2mse(x, y)) == pytest.approx((0.25 + 1 + 0.0625) / 4)
+    assert float(utils.mse2psnr(torch.tensor(0.01))) == pytest.approx(20.0, abs=1e-4)
+    np.testing.assert_array_equal(utils.to8b(np.array([-1.0, 0.0, 0.5, 0.999, 1.0, 2.0])), [0, 0, 127, 254, 255, 255])
+    K = synth.lego_intrinsics(4, 6)
+    ro, rd = utils.get_rays_np(4, 6, K, synth.LEGO_C2W)
+    ro2, rd2 = synth.rays_np(4, 6, K, synth.LEGO_C2W)
+    np.testing.assert_allclose(rd.reshape(-1, 3), rd2, atol=1e-6)
+
+
+def test_shard_ranges_cover_exactly():
+    for n in (0, 1, 7, 160000, 640000, 160001):
+        for world in (1, 2, 3, 4, 8):
+            spans = [nd.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for (a, b), (c, d) in zip(spans, spans[1:]):
+                assert b == c and b >= a
+            sizes = nd.shard_sizes(n, world)
+            assert sum(sizes) == n and max(sizes) - min(sizes) <= 1
+
+
+_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %(repo)r)
+os.environ["NERF_AMD_QUIET"] = "1"
+from nerf_shared_amd import dist as nd
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[3]
+dist.init_process_group("gloo", rank=rank, world_size=world)
+ok = True
+for n in (10, 11, 4096):
+    full = torch.arange(n * 5, dtype=torch.float32).reshape(n, 5)
+    lo, hi = nd.shard_range(n, rank, world)
+    got = nd.gather_rows(full[lo:hi].clone(), n, 0)
+    if rank == 0:
+        ok = ok and got is not None and torch.equal(got, full)
+    else:
+        ok = ok and got is None
+dist.barrier()
+dist.destroy_process_group()
+sys.exit(0 if ok else 1)
+"""
+
+
+def test_gather_rows_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER % {"repo": REPO})
+    port = str(29500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", port]) for r in range(2)]
+    codes = [p.wait(timeout=180) for p in procs]
+    assert codes == [0, 0]

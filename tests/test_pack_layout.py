@@ -1,0 +1,233 @@
+"""CPU check of the bf16 fragment stream (program.h / pack.hip) without a GPU.
+
+A numpy emulator replays mlp_bf16.hip's data flow lane by lane -- MFMA operand
+maps of v_mfma_f32_32x32x16_bf16, accumulator-as-next-operand, generated
+encodings on lane halves, bias table, layer order -- on the stream produced by
+the library's host packer (nerf_amd_pack_bf16_host, the twin of the device
+pack kernel).  If the emulated network agrees with a plain bf16-rounded
+evaluation of the same weights, the permutations baked into the stream are
+consistent with the kernel's register layout.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from nerf_shared_amd import _lib, synth
+from oracle import nerf_oracle as O
+
+lib = _lib.lib
+
+
+def bf16_round(x):
+    """Round-to-nearest-even fp32 -> bf16 -> fp32 (numpy)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint32) << 16
+    return r.view(np.float32)
+
+
+def bf16_bits_to_f32(b):
+    return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+def acc_row(r, h):
+    return (r & 3) + 8 * (r >> 2) + 4 * h
+
+
+def gen_col(ks, h, j, L):
+    e = 8 * ks + j
+    if e < 3 * L:
+        return 3 + 6 * (e // 3) + 3 * h + (e % 3)
+    if e == 3 * L:
+        return 2 if h else 0
+    if e == 3 * L + 1:
+        return -1 if h else 1
+    return -1
+
+
+def gen_ksteps(L):
+    return (3 * L + 2 + 7) // 8
+
+
+def host_pack(arch_kwargs, sd):
+    names = ["pts_linears.%d" % i for i in range(arch_kwargs["D"])]
+    if arch_kwargs["use_viewdirs"]:
+        names += ["feature_linear", "alpha_linear", "views_linears.0", "rgb_linear"]
+    else:
+        names += ["output_linear"]
+    ws = [np.ascontiguousarray(sd[n + ".weight"], np.float32) for n in names]
+    bs = [np.ascontiguousarray(sd[n + ".bias"], np.float32) for n in names]
+    arch = _lib.make_arch(arch_kwargs["D"], arch_kwargs["W"], arch_kwargs["output_ch"], arch_kwargs["skips"],
+                          arch_kwargs["use_viewdirs"], arch_kwargs["multires"], arch_kwargs["multires_views"], 0)
+    n = len(names)
+    wp = (ctypes.c_void_p * n)(*[w.ctypes.data for w in ws])
+    bp = (ctypes.c_void_p * n)(*[b.ctypes.data for b in bs])
+    nf, nb = ctypes.c_int64(), ctypes.c_int64()
+    _lib.check(lib.nerf_amd_pack_bf16_host(ctypes.byref(arch), wp, bp, n, None, ctypes.byref(nf), None, ctypes.byref(nb)), "size query")
+    stream = np.zeros(nf.value * 512, np.uint16)
+    bias = np.zeros(nb.value, np.float32)
+    _lib.check(lib.nerf_amd_pack_bf16_host(ctypes.byref(arch), wp, bp, n,
+                                           stream.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)), ctypes.byref(nf),
+                                           bias.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), ctypes.byref(nb)), "pack")
+    return bf16_bits_to_f32(stream).reshape(nf.value, 64, 8), bias.reshape(-1, 2, 16)
+
+
+class WaveEmu:
+    """One wave = 32 points, emulated exactly as mlp_bf16.hip walks the stream."""
+
+    def __init__(self, stream, bias):
+        self.stream, self.bias = stream, bias
+        self.lane = np.arange(64)
+        self.col, self.h = self.lane & 31, self.lane >> 5
+
+    def mfma(self, a_frag, b_frag, acc):
+        # A[row = l&31][k = 8*(l>>5)+j], B[k = 8*(l>>5)+j][col = l&31]
+        A = np.zeros((32, 16), np.float32)
+        B = np.zeros((16, 32), np.float32)
+        for l in range(64):
+            A[l & 31, 8 * (l >> 5):8 * (l >> 5) + 8] = a_frag[l]
+            B[8 * (l >> 5):8 * (l >> 5) + 8, l & 31] = b_frag[l]
+        D = A.astype(np.float64) @ B.astype(np.float64)
+        out = acc.copy()
+        for l in range(64):
+            for r in range(16):
+                out[l, r] += D[acc_row(r, l >> 5), l & 31]
+        return out
+
+    def tile(self, f0, t, x1, k1, x2=None, k2=0):
+        acc = np.zeros((64, 16), np.float64)
+        for l in range(64):
+            acc[l] = self.bias[t, l >> 5]
+        for k in range(k1):
+            acc = self.mfma(self.stream[f0 + k], x1[k], acc)
+        for k in range(k2):
+            acc = self.mfma(self.stream[f0 + k1 + k], x2[k], acc)
+        return acc.astype(np.float32)
+
+    def layer(self, f0, t0, nt, x1, k1, x2=None, k2=0, relu=True):
+        y = []
+        for t in range(nt):
+            acc = self.tile(f0 + t * (k1 + k2), t0 + t, x1, k1, x2, k2)
+            if relu:
+                acc = np.maximum(acc, 0)
+            y.append(bf16_round(acc[:, 0:8]))
+            y.append(bf16_round(acc[:, 8:16]))
+        return y
+
+    def encode(self, emb, L, K):
+        """emb [32, 3+6L] fp32 reference embedding -> K fragments [64, 8] (FRAG_GEN order)."""
+        out = []
+        for ks in range(K):
+            f = np.zeros((64, 8), np.float32)
+            for l in range(64):
+                for j in range(8):
+                    c = gen_col(ks, l >> 5, j, L)
+                    f[l, j] = emb[l & 31, c] if c >= 0 else 0.0
+            out.append(bf16_round(f))
+        return out
+
+
+def emulate(arch, sd, pts, dirs):
+    LX, LD, VD = arch["multires"], arch["multires_views"], arch["use_viewdirs"]
+    KE, KD = gen_ksteps(LX), (gen_ksteps(LD) if VD else 0)
+    stream, bias = host_pack(arch, sd)
+    F_L1 = 8 * KE
+    F_L5 = F_L1 + 4 * 128
+    F_L6 = F_L5 + 8 * (KE + 16)
+    F_HEAD = F_L6 + 256
+    w = WaveEmu(stream, bias)
+    E = w.encode(O.embed(torch.from_numpy(pts), LX).numpy(), LX, KE)
+    A = w.layer(0, 0, 8, E, KE)
+    B = w.layer(F_L1, 8, 8, A, 16)
+    A = w.layer(F_L1 + 128, 16, 8, B, 16)
+    B = w.layer(F_L1 + 256, 24, 8, A, 16)
+    A = w.layer(F_L1 + 384, 32, 8, B, 16)
+    B = w.layer(F_L5, 40, 8, E, KE, A, 16)
+    A = w.layer(F_L6, 48, 8, B, 16)
+    B = w.layer(F_L6 + 128, 56, 8, A, 16)
+    if VD:
+        Dv = w.encode(O.embed(torch.from_numpy(dirs), LD).numpy(), LD, KD)
+        F_FEAT, F_ALPHA = F_HEAD, F_HEAD + 128
+        F_VIEWS = F_ALPHA + 16
+        F_RGB = F_VIEWS + 4 * (16 + KD)
+        assert F_RGB + 8 <= stream.shape[0]
+        A = w.layer(F_FEAT, 64, 8, B, 16, relu=False)
+        alpha = w.tile(F_ALPHA, 72, B, 16)
+        B2 = w.layer(F_VIEWS, 73, 4, A, 16, Dv, KD)
+        rgb = w.tile(F_RGB, 77, B2, 8)
+        return np.stack([rgb[:32, 0], rgb[:32, 1], rgb[:32, 2], alpha[:32, 0]], -1)
+    o = w.tile(F_HEAD, 64, B, 16)
+    out = np.zeros((32, arch["output_ch"]), np.float32)
+    for r in range(16):
+        for h in range(2):
+            row = acc_row(r, h)
+            if row < arch["output_ch"]:
+                out[:, row] = o[32 * h:32 * h + 32, r]
+    return out
+
+
+def plain_bf16(arch, sd, pts, dirs):
+    """Same network, natural layout: weights and every activation rounded to bf16, fp64 accumulate."""
+    W = {k: bf16_round(v).astype(np.float64) if k.endswith("weight") else v.astype(np.float64) for k, v in sd.items()}
+    x = bf16_round(O.embed(torch.from_numpy(pts), arch["multires"]).numpy()).astype(np.float64)
+    lin = lambda n, v: v @ W[n + ".weight"].T + W[n + ".bias"]       # noqa: E731
+    rb = lambda v: bf16_round(v.astype(np.float32)).astype(np.float64)  # noqa: E731
+    h = x
+    for i in range(8):
+        h = rb(np.maximum(lin("pts_linears.%d" % i, h), 0))
+        if i == 4:
+            h = np.concatenate([x, h], -1)
+    if not arch["use_viewdirs"]:
+        return lin("output_linear", h)
+    d = bf16_round(O.embed(torch.from_numpy(dirs), arch["multires_views"]).numpy()).astype(np.float64)
+    sigma = lin("alpha_linear", h)
+    feat = rb(lin("feature_linear", h))
+    hv = rb(np.maximum(lin("views_linears.0", np.concatenate([feat, d], -1)), 0))
+    return np.concatenate([lin("rgb_linear", hv), sigma], -1)
+
+
+CASES = [
+    dict(D=8, W=256, output_ch=5, skips=[4], use_viewdirs=True, multires=10, multires_views=4),
+    dict(D=8, W=256, output_ch=5, skips=[4], use_viewdirs=True, multires=15, multires_views=6),
+    dict(D=8, W=256, output_ch=5, skips=[4], use_viewdirs=False, multires=10, multires_views=4),
+]
+
+
+@pytest.mark.parametrize("arch", CASES, ids=["vd_10_4", "vd_15_6", "novd_10"])
+def test_stream_matches_kernel_dataflow(arch):
+    rng = np.random.default_rng(7)
+    pts = rng.uniform(-3, 3, size=(32, 3)).astype(np.float32)
+    dirs = rng.normal(size=(32, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    sd = synth.make_state_dict(3, 3.0, **{**arch, "skips": tuple(arch["skips"])})
+    emu = emulate(arch, sd, pts, dirs)
+    ref = plain_bf16(arch, sd, pts, dirs)
+    # identical roundings, different summation order only
+    np.testing.assert_allclose(emu, ref, atol=2e-3, rtol=2e-3)
+    # and the bf16 network is a faithful approximation of the fp32 oracle
+    sdt = O.state_dict_to_torch(sd)
+    a = O.Arch(**arch)
+    full = O.nerf_forward(sdt, a, torch.from_numpy(pts)[:, None, :],
+                          torch.from_numpy(dirs) if arch["use_viewdirs"] else None).reshape(32, -1).numpy()
+    assert np.abs(emu - full).max() < 0.35 * max(1.0, np.abs(full).max())
+
+
+def test_stream_sizes_and_padding():
+    arch = CASES[0]
+    sd = synth.make_state_dict(3, 1.0, **{**arch, "skips": tuple(arch["skips"])})
+    stream, bias = host_pack(arch, sd)
+    assert stream.shape[0] % 48 == 0 and stream.shape[0] >= 1184     # whole ring turns
+    assert bias.shape[0] == 78
+    assert np.all(stream[1184:] == 0)                                 # padding fragments are zero
+    # alpha tile: only output row 0 carries weights
+    alpha0 = 8 * 4 + 4 * 128 + 8 * 20 + 2 * 128 + 128
+    assert np.all(stream[alpha0:alpha0 + 16, 1:32] == 0) and np.all(stream[alpha0:alpha0 + 16, 33:64] == 0)
+    assert np.any(stream[alpha0, 0] != 0)
+
+
+def test_unsupported_arch_reports_error():
+    arch = _lib.make_arch(4, 128, 4, [1], True, 6, 2, 0)
+    nf = ctypes.c_int64()
+    rc = lib.nerf_amd_pack_bf16_host(ctypes.byref(arch), None, None, 0, None, ctypes.byref(nf), None, None)
+    assert rc == -3 and b"D=8" in lib.nerf_amd_last_error()
