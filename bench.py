@@ -47,7 +47,9 @@ def cpu_baseline(torch, synth):
     """Oracle on host cores: one 4096-ray 64+128 batch, 1 warm-up + best of 2."""
     from oracle import nerf_oracle as O
     import numpy as np
-    threads = torch.get_num_threads()
+    # the GPU box reports every host core but grants a 16-core share per GPU
+    threads = min(len(os.sched_getaffinity(0)), 16)
+    torch.set_num_threads(threads)
     K = synth.lego_intrinsics(H, W_PER_GPU)
     ro, rd = synth.rays_np(H, W_PER_GPU, K, synth.LEGO_C2W, np.arange(80000, 80000 + CHUNK))
     batch = torch.from_numpy(synth.ray_batch_np(ro, rd, 2.0, 6.0, True))
