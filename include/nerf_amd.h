@@ -194,6 +194,9 @@ int nerf_amd_make_rays(int32_t H, int32_t W, const double *K4, const float *c2w,
  * the summed number of points, then forgets them.
  * ------------------------------------------------------------------------ */
 int nerf_amd_profile_enable(int on);
+/* Tuning knobs for A/B measurements (results are identical for every setting).
+ * key 0: weight-pipeline shape of the fused bf16 kernel (0 = default; see mlp_bf16.hip launch_one). */
+int nerf_amd_set_tuning(int key, int value);
 int nerf_amd_profile_collect(int64_t launches[2], double total_ms[2], double total_points[2]);
 
 #ifdef __cplusplus

@@ -22,7 +22,7 @@ EXPORTS = (
     "nerf_amd_model_supports_bf16", "nerf_amd_model_out_ch", "nerf_amd_pack_bf16_host",
     "nerf_amd_embed", "nerf_amd_nerf_forward", "nerf_amd_raw2outputs", "nerf_amd_sample_pdf",
     "nerf_amd_render_rays_workspace", "nerf_amd_render_rays", "nerf_amd_make_rays",
-    "nerf_amd_profile_enable", "nerf_amd_profile_collect",
+    "nerf_amd_profile_enable", "nerf_amd_profile_collect", "nerf_amd_set_tuning",
 )
 
 
@@ -75,6 +75,7 @@ def _load():
         "nerf_amd_render_rays": (c_int, [POINTER(RenderCfg), c_void_p, c_void_p, POINTER(RenderIO), c_int64, c_void_p]),
         "nerf_amd_make_rays": (c_int, [c_int32, c_int32, POINTER(c_double), POINTER(c_float), POINTER(c_float),
                                        c_int64, c_int64, c_float, c_float, c_int, c_int, c_void_p, c_void_p]),
+        "nerf_amd_set_tuning": (c_int, [c_int, c_int]),
         "nerf_amd_profile_enable": (c_int, [c_int]),
         "nerf_amd_profile_collect": (c_int, [POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),
     }

@@ -329,6 +329,11 @@ int nerf_amd_render_rays(const nerf_amd_render_cfg *cfg, const nerf_amd_model *c
     return rc ? fail(rc, "composite launch failed") : NERF_AMD_OK;
 }
 
+int nerf_amd_set_tuning(int key, int value) {
+    if (key == 0 && value >= 0 && value <= 15) { g_variant = value; return NERF_AMD_OK; }
+    return fail(NERF_AMD_EINVAL, "unknown tuning key/value");
+}
+
 int nerf_amd_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_on = on != 0;

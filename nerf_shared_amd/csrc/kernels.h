@@ -30,6 +30,7 @@ struct MlpArgs {
     float *out;                    // [P, out_ch]
 };
 
+extern int g_variant;
 bool mlp_bf16_supported(int multires, int multires_views, int use_viewdirs);
 int launch_mlp_bf16(const MlpArgs &a, int multires, int multires_views, int use_viewdirs,
                     int n_frags_used, int n_tiles, hipStream_t s);

@@ -32,14 +32,6 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-constexpr int WG_THREADS = 512;
-constexpr int WG_WAVES = 8;
-constexpr int WG_POINTS = WG_WAVES * 32;
-constexpr int BLOCK_BYTES = BLOCK_FRAGS * 1024;
-constexpr int RING_BYTES = RING_SLOTS * BLOCK_BYTES;
-constexpr int PREFETCH = RING_SLOTS - 1;   // blocks in flight ahead of the consumer
-constexpr int PIECES_PER_WAVE = BLOCK_FRAGS / WG_WAVES;
-
 template <int N, class F, int... Is>
 __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) {
     (f(std::integral_constant<int, Is>{}), ...);
@@ -49,7 +41,28 @@ __device__ __forceinline__ void static_for(F &&f) {
     static_for_impl<N>(f, std::make_integer_sequence<int, N>{});
 }
 
+// Compile-time shape of the weight pipeline.
+//   WAVES  waves per workgroup (each owns 32 points)
+//   BF     fragments per ring block (one workgroup barrier per block)
+//   NS     ring slots (blocks resident in LDS)
+//   PHASE  0: the sync for block b sits at its first fragment (drains this wave's LDS reads).
+//          p>0: the sync that publishes block b+1 sits p fragments into block b, so the
+//          reads of the next block's first fragments are not fenced behind a barrier.
+//   LA     with PHASE > 0: A fragments are read LA MFMAs ahead of their use through a register
+//          queue, so the reads for the MFMAs right after a barrier are already in flight
+//          when the barrier is reached (legal while LA <= PHASE <= BF - LA).
+//   ABL    timing-only ablations for A/B measurements (results are WRONG when non-zero):
+//          1 = no syncs/DMA, 2 = no LDS fragment reads, 4 = no positional encoding
+template <int WAVES_, int BF_, int NS_, int PHASE_, int LA_ = 0, int ABL_ = 0>
 struct Ctx {
+    static constexpr int WAVES = WAVES_, BF = BF_, NS = NS_, PHASE = PHASE_, LA = LA_, ABL = ABL_;
+    static_assert(LA_ == 0 || (PHASE_ > 0 && LA_ <= PHASE_ && PHASE_ + LA_ <= BF_), "read-ahead would cross an unpublished block");
+    bf16x8 q[LA_ > 0 ? LA_ : 1];
+    static constexpr int PIECES = BF / WAVES;            // 1-KiB DMA pieces per wave per block
+    static constexpr int BLOCK_BYTES = BF * 1024;
+    static constexpr int RING_BYTES = NS * BLOCK_BYTES;
+    static constexpr int LOOKAHEAD = PHASE > 0 ? 1 : 0;  // a sync at block b publishes block b + LOOKAHEAD
+    static_assert(BF % WAVES == 0 && NS >= 3 && PHASE < BF, "bad pipeline shape");
     const char *gstream;     // this lane's view of the fragment stream (base + lane*16)
     const char *ring_lane;   // LDS ring + lane*16
     uint32_t ring_u32;       // LDS byte address of the ring
@@ -57,15 +70,15 @@ struct Ctx {
     int wave;
 };
 
-// LDS-DMA of this wave's share (2 x 1 KiB) of stream block BB into its ring slot.
-template <int BB>
-__device__ __forceinline__ void issue_block(const Ctx &c) {
-    constexpr int slot = BB % RING_SLOTS;
+// LDS-DMA of this wave's share of stream block BB into its ring slot.
+template <int BB, class C>
+__device__ __forceinline__ void issue_block(const C &c) {
+    constexpr int slot = BB % C::NS;
 #pragma unroll
-    for (int i = 0; i < PIECES_PER_WAVE; ++i) {
-        const int piece = c.wave * PIECES_PER_WAVE + i;
-        const char *g = c.gstream + (size_t)BB * BLOCK_BYTES + piece * 1024;
-        const uint32_t l = c.ring_u32 + slot * BLOCK_BYTES + piece * 1024;   // wave-uniform
+    for (int i = 0; i < C::PIECES; ++i) {
+        const int piece = c.wave * C::PIECES + i;
+        const char *g = c.gstream + (size_t)BB * C::BLOCK_BYTES + piece * 1024;
+        const uint32_t l = c.ring_u32 + slot * C::BLOCK_BYTES + piece * 1024;   // wave-uniform
         unsigned keep;
         asm volatile(
             "s_mov_b32 %0, m0\n\t"
@@ -79,29 +92,65 @@ __device__ __forceinline__ void issue_block(const Ctx &c) {
     }
 }
 
-// Block boundary: my pieces of block B have landed (vmcnt), my reads of the
-// slot that is about to be refilled are done (lgkmcnt), everyone agrees
-// (s_barrier); then refill the slot block B-1 lived in with block B+PREFETCH.
-template <int B, int NB>
-__device__ __forceinline__ void block_sync(const Ctx &c) {
-    constexpr int ahead = (NB - 1 - B) < (PREFETCH - 1) ? (NB - 1 - B) : (PREFETCH - 1);
-    if constexpr (ahead * PIECES_PER_WAVE == 2)
-        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else if constexpr (ahead * PIECES_PER_WAVE == 0)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else
-        static_assert(ahead * PIECES_PER_WAVE == 0 || ahead * PIECES_PER_WAVE == 2, "extend the vmcnt table");
-    if constexpr (B + PREFETCH < NB) issue_block<B + PREFETCH>(c);
+// Sync S_b (b >= -LOOKAHEAD): this wave's pieces of block b+LOOKAHEAD have landed
+// (counted vmcnt: younger blocks stay in flight), everyone agrees (s_barrier), then
+// the slot of block b-1 -- which every wave has finished reading -- is refilled with
+// block b+NS-1.  With PHASE == 0 the slot being refilled was read up to the previous
+// instruction, so this wave's LDS reads are drained first (lgkmcnt(0)); with PHASE > 0
+// its last read is PHASE MFMAs old and already consumed, and only instruction motion
+// across the sync has to be prevented.
+template <int B, int NB, class C>
+__device__ __forceinline__ void block_sync(const C &c) {
+    if constexpr (C::ABL & 1) return;
+    constexpr int need = B + C::LOOKAHEAD;
+    constexpr int last_issued = (B + C::NS - 2) < (NB - 1) ? (B + C::NS - 2) : (NB - 1);
+    constexpr int cnt = (last_issued > need ? last_issued - need : 0) * C::PIECES;
+    if constexpr (C::PHASE == 0) {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(cnt) : "memory");
+    } else {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(cnt) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (B + C::NS - 1 < NB) issue_block<B + C::NS - 1>(c);
 }
 
-template <int n>
-__device__ __forceinline__ bf16x8 ring_frag(const Ctx &c) {
-    return *reinterpret_cast<const bf16x8 *>(c.ring_lane + ((n % (RING_SLOTS * BLOCK_FRAGS)) << 10));
+template <int NB, class C>
+__device__ __forceinline__ void pipeline_prologue(const C &c) {
+    if constexpr (C::ABL & 1) return;
+    static_for<C::NS - 1 - C::LOOKAHEAD>([&](auto b_) { constexpr int b = b_; if constexpr (b < NB) issue_block<b>(c); });
+}
+
+template <int n, class C>
+__device__ __forceinline__ bf16x8 ring_frag(const C &c) {
+    return *reinterpret_cast<const bf16x8 *>(c.ring_lane + ((n % (C::NS * C::BF)) << 10));
+}
+
+template <int n, int NB, class C>
+__device__ __forceinline__ void maybe_sync(const C &c) {
+    if constexpr (n % C::BF == C::PHASE && (n / C::BF + C::LOOKAHEAD) < NB) block_sync<n / C::BF, NB>(c);
+}
+
+// Fragment n of the stream, in consumption order (syncs included).
+template <int n, int NB, int NFRAGS, class C>
+__device__ __forceinline__ bf16x8 take(C &c) {
+    maybe_sync<n, NB>(c);
+    if constexpr (C::ABL & 2) {
+        bf16x8 f = c.q[0];
+        asm volatile("" : "+v"(f));     // opaque: keeps one MFMA per fragment without an LDS read
+        return f;
+    } else if constexpr (C::LA == 0) {
+        return ring_frag<n>(c);
+    } else {
+        const bf16x8 f = c.q[n % C::LA];
+        if constexpr (n + C::LA < NFRAGS) c.q[n % C::LA] = ring_frag<n + C::LA>(c);
+        return f;
+    }
 }
 
 // One 32-row output tile: acc = bias + sum over K1 k-steps of x1 and K2 of x2.
-template <int F0, int T, int K1, int K2, int NB>
-__device__ __forceinline__ f32x16 tile(const Ctx &c, const bf16x8 *x1, const bf16x8 *x2) {
+template <int F0, int T, int K1, int K2, int NB, int NFRAGS, class C>
+__device__ __forceinline__ f32x16 tile(C &c, const bf16x8 *x1, const bf16x8 *x2) {
     f32x16 acc;
     {
         const f32x4 *b = reinterpret_cast<const f32x4 *>(c.bias_half + T * 32);
@@ -111,13 +160,11 @@ __device__ __forceinline__ f32x16 tile(const Ctx &c, const bf16x8 *x1, const bf1
     }
     static_for<K1>([&](auto k_) {
         constexpr int k = k_, n = F0 + k;
-        if constexpr (n % BLOCK_FRAGS == 0) block_sync<n / BLOCK_FRAGS, NB>(c);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring_frag<n>(c), x1[k], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(take<n, NB, NFRAGS>(c), x1[k], acc, 0, 0, 0);
     });
     static_for<K2>([&](auto k_) {
         constexpr int k = k_, n = F0 + K1 + k;
-        if constexpr (n % BLOCK_FRAGS == 0) block_sync<n / BLOCK_FRAGS, NB>(c);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring_frag<n>(c), x2[k], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(take<n, NB, NFRAGS>(c), x2[k], acc, 0, 0, 0);
     });
     return acc;
 }
@@ -141,11 +188,11 @@ __device__ __forceinline__ void pack_tile(const f32x16 &acc, bf16x8 &lo, bf16x8 
 }
 
 // A full hidden layer: NT output tiles -> y[2*NT] (next layer's B fragments).
-template <int F0, int T0, int NT, int K1, int K2, bool RELU, int NB>
-__device__ __forceinline__ void layer(const Ctx &c, const bf16x8 *x1, const bf16x8 *x2, bf16x8 *y) {
+template <int F0, int T0, int NT, int K1, int K2, bool RELU, int NB, int NFRAGS, class C>
+__device__ __forceinline__ void layer(C &c, const bf16x8 *x1, const bf16x8 *x2, bf16x8 *y) {
     static_for<NT>([&](auto t_) {
         constexpr int t = t_;
-        f32x16 acc = tile<F0 + t * (K1 + K2), T0 + t, K1, K2, NB>(c, x1, x2);
+        f32x16 acc = tile<F0 + t * (K1 + K2), T0 + t, K1, K2, NB, NFRAGS>(c, x1, x2);
         pack_tile<RELU>(acc, y[2 * t], y[2 * t + 1]);
     });
 }
@@ -203,29 +250,29 @@ struct Layout {
     static constexpr int F_VIEWS = F_ALPHA + 16;
     static constexpr int F_RGB = F_VIEWS + 4 * (16 + KD);
     static constexpr int F_END = VD ? F_RGB + 8 : F_HEAD + 16;
-    static constexpr int NB = (F_END + BLOCK_FRAGS - 1) / BLOCK_FRAGS;
     static constexpr int T_HEAD = 64;
     static constexpr int N_TILES = VD ? 64 + 8 + 1 + 4 + 1 : 64 + 1;
 };
 
-template <int LX, int LD, bool VD>
-__global__ __launch_bounds__(WG_THREADS, 2) void mlp_bf16_kernel(MlpArgs a) {
+template <int LX, int LD, bool VD, class C>
+__global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_kernel(MlpArgs a) {
+    constexpr int WG_THREADS = C::WAVES * 64, WG_POINTS = C::WAVES * 32;
     using Lay = Layout<LX, LD, VD>;
-    constexpr int KE = Lay::KE, KD = Lay::KD, NB = Lay::NB;
+    constexpr int KE = Lay::KE, KD = Lay::KD, NF = Lay::F_END, NB = (NF + C::BF - 1) / C::BF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *bias_lds = reinterpret_cast<float *>(smem + RING_BYTES);
+    float *bias_lds = reinterpret_cast<float *>(smem + C::RING_BYTES);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int h = lane >> 5;
-    Ctx c;
+    C c;
     c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     c.gstream = reinterpret_cast<const char *>(a.stream_bf16) + lane * 16;
     c.ring_lane = smem + lane * 16;
     c.ring_u32 = (uint32_t)(uintptr_t)smem;
     c.bias_half = bias_lds + h * 16;
 
-    static_for<PREFETCH>([&](auto b_) { constexpr int b = b_; if constexpr (b < NB) issue_block<b>(c); });
+    pipeline_prologue<NB>(c);
 
     for (int i = tid; i < Lay::N_TILES * 32; i += WG_THREADS) bias_lds[i] = a.bias_bf16[i];
 
@@ -245,34 +292,44 @@ __global__ __launch_bounds__(WG_THREADS, 2) void mlp_bf16_kernel(MlpArgs a) {
         x2 = __fadd_rn(r[2], __fmul_rn(r[5], z));
     }
     bf16x8 E[KE];
-    encode<LX, KE>(x0, x1, x2, h, E);
     bf16x8 Dv[VD ? KD : 1];
-    if constexpr (VD) {
-        const float *d = a.viewdirs + ray * a.vd_stride;
-        encode<LD, KD>(d[0], d[1], d[2], h, Dv);
+    if constexpr (C::ABL & 4) {
+        static_for<KE>([&](auto k_) { constexpr int k = k_; for (int j = 0; j < 8; ++j) E[k][j] = (__bf16)(x0 + j); });
+        if constexpr (VD) static_for<KD>([&](auto k_) { constexpr int k = k_; for (int j = 0; j < 8; ++j) Dv[k][j] = (__bf16)(x1 + j); });
+    } else {
+        encode<LX, KE>(x0, x1, x2, h, E);
+        if constexpr (VD) {
+            const float *d = a.viewdirs + ray * a.vd_stride;
+            encode<LD, KD>(d[0], d[1], d[2], h, Dv);
+        }
     }
 
+    if constexpr (C::PHASE > 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // bias table stores, before the barrier publishes them
+        block_sync<-1, NB>(c);                                 // publishes block 0
+        static_for<C::LA>([&](auto i_) { constexpr int i = i_; c.q[i] = ring_frag<i>(c); });
+    }
     bf16x8 A[16], B[16];
-    layer<Lay::F_L0, 0, 8, KE, 0, true, NB>(c, E, E, A);
-    layer<Lay::F_L1 + 0 * 128, 8, 8, 16, 0, true, NB>(c, A, A, B);
-    layer<Lay::F_L1 + 1 * 128, 16, 8, 16, 0, true, NB>(c, B, B, A);
-    layer<Lay::F_L1 + 2 * 128, 24, 8, 16, 0, true, NB>(c, A, A, B);
-    layer<Lay::F_L1 + 3 * 128, 32, 8, 16, 0, true, NB>(c, B, B, A);
-    layer<Lay::F_L5, 40, 8, KE, 16, true, NB>(c, E, A, B);          // skip: [input_pts | h]
-    layer<Lay::F_L6, 48, 8, 16, 0, true, NB>(c, B, B, A);
-    layer<Lay::F_L6 + 128, 56, 8, 16, 0, true, NB>(c, A, A, B);     // h7 in B
+    layer<Lay::F_L0, 0, 8, KE, 0, true, NB, NF>(c, E, E, A);
+    layer<Lay::F_L1 + 0 * 128, 8, 8, 16, 0, true, NB, NF>(c, A, A, B);
+    layer<Lay::F_L1 + 1 * 128, 16, 8, 16, 0, true, NB, NF>(c, B, B, A);
+    layer<Lay::F_L1 + 2 * 128, 24, 8, 16, 0, true, NB, NF>(c, A, A, B);
+    layer<Lay::F_L1 + 3 * 128, 32, 8, 16, 0, true, NB, NF>(c, B, B, A);
+    layer<Lay::F_L5, 40, 8, KE, 16, true, NB, NF>(c, E, A, B);          // skip: [input_pts | h]
+    layer<Lay::F_L6, 48, 8, 16, 0, true, NB, NF>(c, B, B, A);
+    layer<Lay::F_L6 + 128, 56, 8, 16, 0, true, NB, NF>(c, A, A, B);     // h7 in B
 
     if constexpr (VD) {
-        layer<Lay::F_FEAT, 64, 8, 16, 0, false, NB>(c, B, B, A);                       // feature (no activation)
-        f32x16 alpha = tile<Lay::F_ALPHA, 72, 16, 0, NB>(c, B, B);                     // row 0 = sigma
-        layer<Lay::F_VIEWS, 73, 4, 16, KD, true, NB>(c, A, Dv, B);                     // views_linears.0
-        f32x16 rgb = tile<Lay::F_RGB, 77, 8, 0, NB>(c, B, B);                          // rows 0..2
+        layer<Lay::F_FEAT, 64, 8, 16, 0, false, NB, NF>(c, B, B, A);                       // feature (no activation)
+        f32x16 alpha = tile<Lay::F_ALPHA, 72, 16, 0, NB, NF>(c, B, B);                     // row 0 = sigma
+        layer<Lay::F_VIEWS, 73, 4, 16, KD, true, NB, NF>(c, A, Dv, B);                     // views_linears.0
+        f32x16 rgb = tile<Lay::F_RGB, 77, 8, 0, NB, NF>(c, B, B);                          // rows 0..2
         if (valid && h == 0) {
             f32x4 o = {rgb[0], rgb[1], rgb[2], alpha[0]};
             *reinterpret_cast<f32x4 *>(a.out + 4 * p) = o;
         }
     } else {
-        f32x16 o = tile<Lay::F_HEAD, 64, 16, 0, NB>(c, B, B);
+        f32x16 o = tile<Lay::F_HEAD, 64, 16, 0, NB, NF>(c, B, B);
         if (valid) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -283,14 +340,17 @@ __global__ __launch_bounds__(WG_THREADS, 2) void mlp_bf16_kernel(MlpArgs a) {
     }
 }
 
-template <int LX, int LD, bool VD>
-static int launch_one(const MlpArgs &a, int n_frags_used, int n_tiles, hipStream_t s) {
+int g_variant = 0;   // tuning knob (nerf_amd_set_tuning key 0): pipeline shape, see launch_one
+
+template <int LX, int LD, bool VD, class C>
+static int launch_wg(const MlpArgs &a, int n_frags_used, int n_tiles, hipStream_t s) {
+    constexpr int WG_THREADS = C::WAVES * 64, WG_POINTS = C::WAVES * 32;
     using Lay = Layout<LX, LD, VD>;
     if (n_frags_used != Lay::F_END || n_tiles != Lay::N_TILES) return NERF_AMD_EINVAL;
-    const size_t lds = RING_BYTES + (size_t)Lay::N_TILES * 32 * sizeof(float);
+    const size_t lds = C::RING_BYTES + (size_t)Lay::N_TILES * 32 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_bf16_kernel<LX, LD, VD>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_bf16_kernel<LX, LD, VD, C>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return NERF_AMD_EHIP;
         attr_set = true;
@@ -298,8 +358,31 @@ static int launch_one(const MlpArgs &a, int n_frags_used, int n_tiles, hipStream
     const int64_t groups = (a.P + WG_POINTS - 1) / WG_POINTS;
     if (groups <= 0) return NERF_AMD_OK;
     if (a.P >= (int64_t)1 << 31) return NERF_AMD_EINVAL;
-    hipLaunchKernelGGL((mlp_bf16_kernel<LX, LD, VD>), dim3((unsigned)groups), dim3(WG_THREADS), lds, s, a);
+    hipLaunchKernelGGL((mlp_bf16_kernel<LX, LD, VD, C>), dim3((unsigned)groups), dim3(WG_THREADS), lds, s, a);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
+}
+
+using CfgDefault = Ctx<8, 16, 4, 8, 2>;   // 64-KiB ring, mid-block sync, 2-deep read-ahead (fastest of tools/mlp_ab.py)
+
+template <int LX, int LD, bool VD>
+static int launch_one(const MlpArgs &a, int n_frags_used, int n_tiles, hipStream_t s) {
+    if constexpr (LX == 10 && LD == 4 && VD) {      // experimental shapes exist for the benchmark architecture only
+        switch (g_variant) {
+            case 1: return launch_wg<LX, LD, VD, Ctx<8, 16, 3, 0>>(a, n_frags_used, n_tiles, s);          // round-1 v1 shape
+            case 2: return launch_wg<LX, LD, VD, Ctx<8, 16, 6, 8, 2>>(a, n_frags_used, n_tiles, s);
+            case 3: return launch_wg<LX, LD, VD, Ctx<8, 32, 3, 0>>(a, n_frags_used, n_tiles, s);
+            case 4: return launch_wg<LX, LD, VD, Ctx<8, 16, 4, 8, 4>>(a, n_frags_used, n_tiles, s);
+            case 5: return launch_wg<LX, LD, VD, Ctx<8, 16, 4, 0>>(a, n_frags_used, n_tiles, s);
+            case 6: return launch_wg<LX, LD, VD, Ctx<8, 32, 4, 16, 3>>(a, n_frags_used, n_tiles, s);
+            case 7: return launch_wg<LX, LD, VD, Ctx<8, 16, 4, 8, 0>>(a, n_frags_used, n_tiles, s);
+            case 11: return launch_wg<LX, LD, VD, Ctx<8, 16, 4, 8, 2, 1>>(a, n_frags_used, n_tiles, s);   // no sync/DMA
+            case 12: return launch_wg<LX, LD, VD, Ctx<8, 16, 4, 8, 2, 3>>(a, n_frags_used, n_tiles, s);   // + no LDS reads
+            case 13: return launch_wg<LX, LD, VD, Ctx<8, 16, 4, 8, 2, 7>>(a, n_frags_used, n_tiles, s);   // + no encoding
+            case 14: return launch_wg<LX, LD, VD, Ctx<8, 16, 4, 8, 2, 4>>(a, n_frags_used, n_tiles, s);   // only: no encoding
+            default: break;
+        }
+    }
+    return launch_wg<LX, LD, VD, CfgDefault>(a, n_frags_used, n_tiles, s);
 }
 
 bool mlp_bf16_supported(int multires, int multires_views, int use_viewdirs) {

@@ -100,8 +100,7 @@ int build_program(const nerf_amd_arch &a, Program &p, const char **err) {
             add_layer(8, {H});                                                         // output_linear
         }
         p.n_frags_used = (int)p.frags.size();
-        const int turn = RING_SLOTS * BLOCK_FRAGS;
-        while (p.frags.size() % turn) p.frags.push_back({0, FRAG_ZERO, 0, 0, 0, 0, 0, 0});
+        while (p.frags.size() % STREAM_PAD_FRAGS) p.frags.push_back({0, FRAG_ZERO, 0, 0, 0, 0, 0, 0});
     }
     return 0;
 }

@@ -109,8 +109,7 @@ struct Program {
     int lds_rows = 0;                // rows of one ping-pong buffer
 };
 
-constexpr int RING_SLOTS = 3;        // 16-KiB blocks in the LDS weight ring
-constexpr int BLOCK_FRAGS = 16;      // fragments per block (one barrier per block)
+constexpr int STREAM_PAD_FRAGS = 192;   // the bf16 stream is zero-padded to a multiple of this (any block size <= 64)
 
 int build_program(const nerf_amd_arch &arch, Program &p, const char **err);
 
