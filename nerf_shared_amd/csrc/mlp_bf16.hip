@@ -53,9 +53,12 @@ __device__ __forceinline__ void static_for(F &&f) {
 //          when the barrier is reached (legal while LA <= PHASE <= BF - LA).
 //   ABL    timing-only ablations for A/B measurements (results are WRONG when non-zero):
 //          1 = no syncs/DMA, 2 = no LDS fragment reads, 4 = no positional encoding
-template <int WAVES_, int BF_, int NS_, int PHASE_, int LA_ = 0, int ABL_ = 0>
+//   NP     32-point column tiles per wave: every A fragment read from LDS feeds NP MFMAs
+//          (NP = 2 halves the LDS read traffic; needs one wave per SIMD for its registers)
+template <int WAVES_, int BF_, int NS_, int PHASE_, int LA_ = 0, int ABL_ = 0, int NP_ = 1>
 struct Ctx {
-    static constexpr int WAVES = WAVES_, BF = BF_, NS = NS_, PHASE = PHASE_, LA = LA_, ABL = ABL_;
+    static constexpr int WAVES = WAVES_, BF = BF_, NS = NS_, PHASE = PHASE_, LA = LA_, ABL = ABL_, NP = NP_;
+    static constexpr int WAVES_PER_SIMD = (WAVES_ * NP_ >= 8 && NP_ == 1) ? 2 : 1;
     static_assert(LA_ == 0 || (PHASE_ > 0 && LA_ <= PHASE_ && PHASE_ + LA_ <= BF_), "read-ahead would cross an unpublished block");
     bf16x8 q[LA_ > 0 ? LA_ : 1];
     static constexpr int PIECES = BF / WAVES;            // 1-KiB DMA pieces per wave per block
@@ -148,25 +151,30 @@ __device__ __forceinline__ bf16x8 take(C &c) {
     }
 }
 
-// One 32-row output tile: acc = bias + sum over K1 k-steps of x1 and K2 of x2.
+// One 32-row output tile for the wave's NP column tiles: acc[i] = bias + sum over K1 k-steps
+// of x1 and K2 of x2.  Activation fragment k of column tile i is x[k * NP + i].
 template <int F0, int T, int K1, int K2, int NB, int NFRAGS, class C>
-__device__ __forceinline__ f32x16 tile(C &c, const bf16x8 *x1, const bf16x8 *x2) {
-    f32x16 acc;
+__device__ __forceinline__ void tile(C &c, const bf16x8 *x1, const bf16x8 *x2, f32x16 (&acc)[C::NP]) {
     {
         const f32x4 *b = reinterpret_cast<const f32x4 *>(c.bias_half + T * 32);
         f32x4 b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { acc[i] = b0[i]; acc[4 + i] = b1[i]; acc[8 + i] = b2[i]; acc[12 + i] = b3[i]; }
+        for (int p = 0; p < C::NP; ++p)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { acc[p][i] = b0[i]; acc[p][4 + i] = b1[i]; acc[p][8 + i] = b2[i]; acc[p][12 + i] = b3[i]; }
     }
     static_for<K1>([&](auto k_) {
         constexpr int k = k_, n = F0 + k;
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(take<n, NB, NFRAGS>(c), x1[k], acc, 0, 0, 0);
+        const bf16x8 w = take<n, NB, NFRAGS>(c);
+        static_for<C::NP>([&](auto p_) { constexpr int p = p_;
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x1[k * C::NP + p], acc[p], 0, 0, 0); });
     });
     static_for<K2>([&](auto k_) {
         constexpr int k = k_, n = F0 + K1 + k;
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(take<n, NB, NFRAGS>(c), x2[k], acc, 0, 0, 0);
+        const bf16x8 w = take<n, NB, NFRAGS>(c);
+        static_for<C::NP>([&](auto p_) { constexpr int p = p_;
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x2[k * C::NP + p], acc[p], 0, 0, 0); });
     });
-    return acc;
 }
 
 // ReLU as one integer max on the fp32 bits (negative floats are negative ints);
@@ -187,13 +195,15 @@ __device__ __forceinline__ void pack_tile(const f32x16 &acc, bf16x8 &lo, bf16x8 
     }
 }
 
-// A full hidden layer: NT output tiles -> y[2*NT] (next layer's B fragments).
+// A full hidden layer: NT output tiles -> y[2*NT*NP] (next layer's B fragments).
 template <int F0, int T0, int NT, int K1, int K2, bool RELU, int NB, int NFRAGS, class C>
 __device__ __forceinline__ void layer(C &c, const bf16x8 *x1, const bf16x8 *x2, bf16x8 *y) {
     static_for<NT>([&](auto t_) {
         constexpr int t = t_;
-        f32x16 acc = tile<F0 + t * (K1 + K2), T0 + t, K1, K2, NB, NFRAGS>(c, x1, x2);
-        pack_tile<RELU>(acc, y[2 * t], y[2 * t + 1]);
+        f32x16 acc[C::NP];
+        tile<F0 + t * (K1 + K2), T0 + t, K1, K2, NB, NFRAGS>(c, x1, x2, acc);
+        static_for<C::NP>([&](auto p_) { constexpr int p = p_;
+            pack_tile<RELU>(acc[p], y[(2 * t) * C::NP + p], y[(2 * t + 1) * C::NP + p]); });
     });
 }
 
@@ -202,7 +212,7 @@ __device__ __forceinline__ void layer(C &c, const bf16x8 *x1, const bf16x8 *x2, 
 // The argument is reduced exactly: t = x/(2 pi) is kept as an unevaluated fp32
 // sum th + tl, doubling th and taking v_fract is exact, and v_sin_f32 takes
 // revolutions.  Absolute error is ~1e-6, far below the bf16 quantum (4e-3).
-template <int L, int K>
+template <int L, int K, int STRIDE>
 __device__ __forceinline__ void encode(float x0, float x1, float x2, int h, bf16x8 *out) {
     constexpr float INV2PI_HI = 0.15915494f;                       // fl32(1/(2 pi))
     constexpr float INV2PI_LO = (float)(0.15915494309189535 - (double)INV2PI_HI);
@@ -232,7 +242,7 @@ __device__ __forceinline__ void encode(float x0, float x1, float x2, int h, bf16
 #pragma unroll
     for (int k = 0; k < K; ++k)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) out[k][j] = (__bf16)vals[8 * k + j];
+        for (int j = 0; j < 8; ++j) out[k * STRIDE][j] = (__bf16)vals[8 * k + j];
 }
 
 template <int LX, int LD, bool VD>
@@ -255,8 +265,9 @@ struct Layout {
 };
 
 template <int LX, int LD, bool VD, class C>
-__global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_kernel(MlpArgs a) {
-    constexpr int WG_THREADS = C::WAVES * 64, WG_POINTS = C::WAVES * 32;
+__global__ __launch_bounds__(C::WAVES * 64, C::WAVES_PER_SIMD) void mlp_bf16_kernel(MlpArgs a) {
+    constexpr int NP = C::NP;
+    constexpr int WG_THREADS = C::WAVES * 64, WG_POINTS = C::WAVES * 32 * NP;
     using Lay = Layout<LX, LD, VD>;
     constexpr int KE = Lay::KE, KD = Lay::KD, NF = Lay::F_END, NB = (NF + C::BF - 1) / C::BF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -276,40 +287,46 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_kernel(MlpArgs a) {
 
     for (int i = tid; i < Lay::N_TILES * 32; i += WG_THREADS) bias_lds[i] = a.bias_bf16[i];
 
-    // ---- this lane's point (both lane halves hold the same point)
-    const int64_t p = (int64_t)blockIdx.x * WG_POINTS + c.wave * 32 + (lane & 31);
-    const bool valid = p < a.P;
-    const int64_t pc = valid ? p : a.P - 1;
-    const int64_t ray = (int64_t)((uint32_t)pc / (uint32_t)a.S);   // P < 2^31 (checked at launch)
-    float x0, x1, x2;
-    if (a.pts) {
-        x0 = a.pts[3 * pc + 0]; x1 = a.pts[3 * pc + 1]; x2 = a.pts[3 * pc + 2];
-    } else {
-        const float *r = a.rays + ray * a.ray_stride;
-        const float z = a.z_vals[pc];
-        x0 = __fadd_rn(r[0], __fmul_rn(r[3], z));
-        x1 = __fadd_rn(r[1], __fmul_rn(r[4], z));
-        x2 = __fadd_rn(r[2], __fmul_rn(r[5], z));
-    }
-    bf16x8 E[KE];
-    bf16x8 Dv[VD ? KD : 1];
-    if constexpr (C::ABL & 4) {
-        static_for<KE>([&](auto k_) { constexpr int k = k_; for (int j = 0; j < 8; ++j) E[k][j] = (__bf16)(x0 + j); });
-        if constexpr (VD) static_for<KD>([&](auto k_) { constexpr int k = k_; for (int j = 0; j < 8; ++j) Dv[k][j] = (__bf16)(x1 + j); });
-    } else {
-        encode<LX, KE>(x0, x1, x2, h, E);
-        if constexpr (VD) {
-            const float *d = a.viewdirs + ray * a.vd_stride;
-            encode<LD, KD>(d[0], d[1], d[2], h, Dv);
+    // ---- this lane's NP points (both lane halves hold the same points)
+    bf16x8 E[KE * NP];
+    bf16x8 Dv[(VD ? KD : 1) * NP];
+    int64_t pidx[NP];
+    bool valid[NP];
+    static_for<NP>([&](auto i_) {
+        constexpr int i = i_;
+        const int64_t p = (int64_t)blockIdx.x * WG_POINTS + (c.wave * NP + i) * 32 + (lane & 31);
+        pidx[i] = p;
+        valid[i] = p < a.P;
+        const int64_t pc = valid[i] ? p : a.P - 1;
+        const int64_t ray = (int64_t)((uint32_t)pc / (uint32_t)a.S);   // P < 2^31 (checked at launch)
+        float x0, x1, x2;
+        if (a.pts) {
+            x0 = a.pts[3 * pc + 0]; x1 = a.pts[3 * pc + 1]; x2 = a.pts[3 * pc + 2];
+        } else {
+            const float *r = a.rays + ray * a.ray_stride;
+            const float z = a.z_vals[pc];
+            x0 = __fadd_rn(r[0], __fmul_rn(r[3], z));
+            x1 = __fadd_rn(r[1], __fmul_rn(r[4], z));
+            x2 = __fadd_rn(r[2], __fmul_rn(r[5], z));
         }
-    }
+        if constexpr (C::ABL & 4) {
+            static_for<KE>([&](auto k_) { constexpr int k = k_; for (int j = 0; j < 8; ++j) E[k * NP + i][j] = (__bf16)(x0 + j); });
+            if constexpr (VD) static_for<KD>([&](auto k_) { constexpr int k = k_; for (int j = 0; j < 8; ++j) Dv[k * NP + i][j] = (__bf16)(x1 + j); });
+        } else {
+            encode<LX, KE, NP>(x0, x1, x2, h, E + i);
+            if constexpr (VD) {
+                const float *d = a.viewdirs + ray * a.vd_stride;
+                encode<LD, KD, NP>(d[0], d[1], d[2], h, Dv + i);
+            }
+        }
+    });
 
     if constexpr (C::PHASE > 0) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // bias table stores, before the barrier publishes them
         block_sync<-1, NB>(c);                                 // publishes block 0
         static_for<C::LA>([&](auto i_) { constexpr int i = i_; c.q[i] = ring_frag<i>(c); });
     }
-    bf16x8 A[16], B[16];
+    bf16x8 A[16 * NP], B[16 * NP];
     layer<Lay::F_L0, 0, 8, KE, 0, true, NB, NF>(c, E, E, A);
     layer<Lay::F_L1 + 0 * 128, 8, 8, 16, 0, true, NB, NF>(c, A, A, B);
     layer<Lay::F_L1 + 1 * 128, 16, 8, 16, 0, true, NB, NF>(c, B, B, A);
@@ -321,30 +338,39 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_kernel(MlpArgs a) {
 
     if constexpr (VD) {
         layer<Lay::F_FEAT, 64, 8, 16, 0, false, NB, NF>(c, B, B, A);                       // feature (no activation)
-        f32x16 alpha = tile<Lay::F_ALPHA, 72, 16, 0, NB, NF>(c, B, B);                     // row 0 = sigma
+        f32x16 alpha[NP], rgb[NP];
+        tile<Lay::F_ALPHA, 72, 16, 0, NB, NF>(c, B, B, alpha);                             // row 0 = sigma
         layer<Lay::F_VIEWS, 73, 4, 16, KD, true, NB, NF>(c, A, Dv, B);                     // views_linears.0
-        f32x16 rgb = tile<Lay::F_RGB, 77, 8, 0, NB, NF>(c, B, B);                          // rows 0..2
-        if (valid && h == 0) {
-            f32x4 o = {rgb[0], rgb[1], rgb[2], alpha[0]};
-            *reinterpret_cast<f32x4 *>(a.out + 4 * p) = o;
-        }
-    } else {
-        f32x16 o = tile<Lay::F_HEAD, 64, 16, 0, NB, NF>(c, B, B);
-        if (valid) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = acc_row(r, h);
-                if (row < a.out_ch) a.out[(int64_t)a.out_ch * p + row] = o[r];
+        tile<Lay::F_RGB, 77, 8, 0, NB, NF>(c, B, B, rgb);                                  // rows 0..2
+        static_for<NP>([&](auto i_) {
+            constexpr int i = i_;
+            if (valid[i] && h == 0) {
+                f32x4 o = {rgb[i][0], rgb[i][1], rgb[i][2], alpha[i][0]};
+                *reinterpret_cast<f32x4 *>(a.out + 4 * pidx[i]) = o;
             }
-        }
+        });
+    } else {
+        f32x16 o[NP];
+        tile<Lay::F_HEAD, 64, 16, 0, NB, NF>(c, B, B, o);
+        static_for<NP>([&](auto i_) {
+            constexpr int i = i_;
+            if (valid[i]) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = acc_row(r, h);
+                    if (row < a.out_ch) a.out[(int64_t)a.out_ch * pidx[i] + row] = o[i][r];
+                }
+            }
+        });
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // no LDS-DMA may outlive the workgroup
 }
 
 int g_variant = 0;   // tuning knob (nerf_amd_set_tuning key 0): pipeline shape, see launch_one
 
 template <int LX, int LD, bool VD, class C>
 static int launch_wg(const MlpArgs &a, int n_frags_used, int n_tiles, hipStream_t s) {
-    constexpr int WG_THREADS = C::WAVES * 64, WG_POINTS = C::WAVES * 32;
+    constexpr int WG_THREADS = C::WAVES * 64, WG_POINTS = C::WAVES * 32 * C::NP;
     using Lay = Layout<LX, LD, VD>;
     if (n_frags_used != Lay::F_END || n_tiles != Lay::N_TILES) return NERF_AMD_EINVAL;
     const size_t lds = C::RING_BYTES + (size_t)Lay::N_TILES * 32 * sizeof(float);
@@ -366,15 +392,15 @@ using CfgDefault = Ctx<8, 16, 4, 8, 2>;   // 64-KiB ring, mid-block sync, 2-deep
 
 template <int LX, int LD, bool VD>
 static int launch_one(const MlpArgs &a, int n_frags_used, int n_tiles, hipStream_t s) {
-    if constexpr (LX == 10 && LD == 4 && VD) {      // experimental shapes exist for the benchmark architecture only
+#ifdef NERF_AMD_EXPERIMENTS   // extra pipeline shapes and timing-only ablations for tools/mlp_ab.py (slow to compile)
+    if constexpr (LX == 10 && LD == 4 && VD) {
         switch (g_variant) {
-            case 1: return launch_wg<LX, LD, VD, Ctx<8, 16, 3, 0>>(a, n_frags_used, n_tiles, s);          // round-1 v1 shape
             case 2: return launch_wg<LX, LD, VD, Ctx<8, 16, 6, 8, 2>>(a, n_frags_used, n_tiles, s);
             case 3: return launch_wg<LX, LD, VD, Ctx<8, 32, 3, 0>>(a, n_frags_used, n_tiles, s);
             case 4: return launch_wg<LX, LD, VD, Ctx<8, 16, 4, 8, 4>>(a, n_frags_used, n_tiles, s);
             case 5: return launch_wg<LX, LD, VD, Ctx<8, 16, 4, 0>>(a, n_frags_used, n_tiles, s);
-            case 6: return launch_wg<LX, LD, VD, Ctx<8, 32, 4, 16, 3>>(a, n_frags_used, n_tiles, s);
             case 7: return launch_wg<LX, LD, VD, Ctx<8, 16, 4, 8, 0>>(a, n_frags_used, n_tiles, s);
+            case 8: return launch_wg<LX, LD, VD, Ctx<4, 16, 4, 8, 2, 0, 2>>(a, n_frags_used, n_tiles, s);   // 64 points per wave, 1 wave/SIMD
             case 11: return launch_wg<LX, LD, VD, Ctx<8, 16, 4, 8, 2, 1>>(a, n_frags_used, n_tiles, s);   // no sync/DMA
             case 12: return launch_wg<LX, LD, VD, Ctx<8, 16, 4, 8, 2, 3>>(a, n_frags_used, n_tiles, s);   // + no LDS reads
             case 13: return launch_wg<LX, LD, VD, Ctx<8, 16, 4, 8, 2, 7>>(a, n_frags_used, n_tiles, s);   // + no encoding
@@ -382,6 +408,9 @@ static int launch_one(const MlpArgs &a, int n_frags_used, int n_tiles, hipStream
             default: break;
         }
     }
+#endif
+    if constexpr (LX == 10 && LD == 4 && VD)
+        if (g_variant == 1) return launch_wg<LX, LD, VD, Ctx<8, 16, 3, 0>>(a, n_frags_used, n_tiles, s);   // round-1 first shape (A/B reference)
     return launch_wg<LX, LD, VD, CfgDefault>(a, n_frags_used, n_tiles, s);
 }
 

@@ -16,6 +16,14 @@ namespace na {
 
 constexpr int RAYS_PER_WG = 4;   // one wave per ray, 4 waves per workgroup
 
+// Each ray's scratch lives in LDS that only its own wave touches, so ordering LDS
+// traffic inside the wave is all that is needed: wait for this wave's LDS
+// operations and stop the compiler from moving memory accesses across.
+__device__ __forceinline__ void wave_lds_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ double wave_incl_prod(double v, int lane) {
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -204,7 +212,7 @@ __global__ __launch_bounds__(64 * RAYS_PER_WG) void sample_pdf_kernel(const floa
     const float *wr = weights + r * (nb - 1);
     build_cdf([&](int i) { return wr[i]; }, nb, cdf, lane);
     for (int i = lane; i < nb; i += 64) bl[i] = bins[r * nb + i];
-    __syncthreads();
+    wave_lds_sync();
     if (!live) return;
     for (int i = lane; i < N; i += 64) {
         const float uu = u ? u[r * N + i] : t_lin[i];
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(64 * RAYS_PER_WG) void resample_kernel(const float 
     for (int i = lane; i < nb; i += 64) bl[i] = 0.5f * (zr[i + 1] + zr[i]);
     for (int i = lane; i < Nc; i += 64) sb[i] = zr[i];
     for (int i = Nc + Ni + lane; i < npad; i += 64) sb[i] = INFINITY;
-    __syncthreads();
+    wave_lds_sync();
     double sum = 0.0;
     for (int i = lane; i < Ni; i += 64) {
         const float uu = u ? u[r * Ni + i] : t_lin[i];
@@ -262,8 +270,8 @@ __global__ __launch_bounds__(64 * RAYS_PER_WG) void resample_kernel(const float 
     }
     ss = wave_sum(ss);
     if (live && lane == 0 && z_std) z_std[r] = (float)sqrt(ss / (double)Ni);
-    __syncthreads();
-    // bitonic sort of sb[0..npad), ascending; every wave runs the same step count
+    wave_lds_sync();
+    // bitonic sort of sb[0..npad), ascending, private to this wave
     for (int k = 2; k <= npad; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = lane; i < npad; i += 64) {
@@ -274,7 +282,7 @@ __global__ __launch_bounds__(64 * RAYS_PER_WG) void resample_kernel(const float 
                     if ((a > b) == up) { sb[i] = b; sb[p] = a; }
                 }
             }
-            __syncthreads();
+            wave_lds_sync();
         }
     }
     if (!live) return;

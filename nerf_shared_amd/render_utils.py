@@ -29,16 +29,26 @@ _KEYS_MAIN = ('rgb_map', 'disp_map', 'acc_map')
 
 
 class _Workspace:
-    """Grow-only scratch buffer per device (raw/z/weights of the two passes)."""
+    """Grow-only scratch buffers per (device, slot): raw/z/weights of the two passes.
+    Slot 0 belongs to the caller's stream, slots 1.. to the chunk-overlap streams."""
     _bufs = {}
+    _streams = {}
 
     @classmethod
-    def get(cls, device, nbytes):
-        buf = cls._bufs.get(device)
+    def get(cls, device, nbytes, slot=0):
+        buf = cls._bufs.get((device, slot))
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
-            cls._bufs[device] = buf
+            cls._bufs[(device, slot)] = buf
         return buf
+
+    @classmethod
+    def side_streams(cls, device, n=2):
+        s = cls._streams.get(device)
+        if s is None:
+            s = [torch.cuda.Stream(device=device) for _ in range(n)]
+            cls._streams[device] = s
+        return s
 
 
 _linspace_cache = {}
@@ -110,7 +120,7 @@ class Renderer(torch.nn.Module):
             raise TypeError("%s must be a nerf_shared_amd.nerf.NeRF (got %s); load a reference model's "
                             "state_dict into one" % (name, type(m).__name__))
 
-    def _launch(self, rays, coarse_model, fine_model, outs, retraw, retweights, pytest):
+    def _launch(self, rays, coarse_model, fine_model, outs, retraw, retweights, pytest, slot=0):
         """Enqueue render_rays for contiguous fp32 rays [R, 8|11]; writes into the
         tensors of ``outs`` (rows [0, R))."""
         R, dev = rays.shape[0], rays.device
@@ -158,7 +168,7 @@ class Renderer(torch.nn.Module):
         for k in ('rgb_map', 'disp_map', 'acc_map', 'rgb0', 'disp0', 'acc0', 'z_std', 'raw', 'weights', 'z_vals'):
             setattr(io, k, _lib.ptr(outs.get(k)))
         nbytes = lib.nerf_amd_render_rays_workspace(cfg, R, out_ch)
-        ws = _Workspace.get(dev, nbytes)
+        ws = _Workspace.get(dev, nbytes, slot)
         io.workspace, io.workspace_bytes = ws.data_ptr(), ws.numel()
         with torch.cuda.device(dev):
             _lib.check(lib.nerf_amd_render_rays(cfg, hc, hf, io, R, _lib.stream_of(dev)), "nerf_amd_render_rays")
@@ -205,20 +215,48 @@ class Renderer(torch.nn.Module):
                     print(f"! [Numerical Error] {k} contains nan or inf.")
         return ret
 
+    overlap_chunks = False    # opt-in: two-stream chunk pipeline of render_batch (+~2 % at 4096-ray chunks)
+
     def render_batch(self, coarse_model, fine_model, rays_flat, chunk=1024 * 32, retraw=False):
-        """Render rays in chunks (render_utils.py:51-65).  Outputs of every chunk
-        land directly in one preallocated tensor per key (the reference's
-        per-key torch.cat, without the copy)."""
+        """Render rays in chunks (render_utils.py:51-65).  Outputs of every chunk land
+        directly in one preallocated tensor per key (the reference's per-key torch.cat,
+        without the copy).  With ``Renderer.overlap_chunks = True`` consecutive chunks
+        alternate between two HIP streams (each with its own workspace) so the small
+        per-ray kernels and launch/drain gaps of one chunk hide under the field kernel
+        of the other; results do not depend on it.  Off by default: the gain is ~2 % and
+        concurrent kernels blur per-kernel timings."""
         _lib.require_device(rays_flat, "rays_flat")
         rays = rays_flat.detach().contiguous().float()
         self._check_model(coarse_model, "coarse_model")
-        N = rays.shape[0]
+        N, dev = rays.shape[0], rays.device
         out_ch = 4 if coarse_model.use_viewdirs else coarse_model.output_ch
-        full = self._alloc_outputs(N, rays.device, out_ch, retraw, False)
-        keep = []
-        for i in range(0, N, chunk):
-            part = {k: v[i:i + chunk] for k, v in full.items()}
-            keep.append(self._launch(rays[i:i + chunk], coarse_model, fine_model, part, retraw, False, False))
+        full = self._alloc_outputs(N, dev, out_ch, retraw, False)
+        starts = list(range(0, N, chunk))
+        if not (self.overlap_chunks and len(starts) > 1):
+            for i in starts:
+                part = {k: v[i:i + chunk] for k, v in full.items()}
+                self._launch(rays[i:i + chunk], coarse_model, fine_model, part, retraw, False, False)
+            return full
+        # pack parameters and build the cached linspaces on the caller's stream first, then fan out
+        _linspace01(int(self.N_samples), dev)
+        if self.N_importance > 0:
+            _linspace01(int(self.N_importance), dev)
+        coarse_model._model_handle(dev)
+        if fine_model is not None:
+            fine_model._model_handle(dev)
+        cur = torch.cuda.current_stream(dev)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        side = _Workspace.side_streams(dev)
+        for s in side:
+            s.wait_event(ready)
+        for n, i in enumerate(starts):
+            slot = n % len(side)
+            with torch.cuda.stream(side[slot]):
+                part = {k: v[i:i + chunk] for k, v in full.items()}
+                self._launch(rays[i:i + chunk], coarse_model, fine_model, part, retraw, False, False, slot=slot + 1)
+        for s in side:
+            cur.wait_stream(s)
         return full
 
     def render(self, H, W, K, coarse_model, fine_model, chunk=1024 * 32, rays=None, retraw=True,
