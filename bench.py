@@ -165,7 +165,7 @@ def main():
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": None,
-                         "kernel": "mlp_bf16_kernel" if cls == 1 else "mlp_f32_kernel",
+                         "kernel": "mlp_bf16_s16_kernel" if cls == 1 else "mlp_f32_kernel",
                          "launches": int(launches[cls]),
                          "avg_launch_ms": (ms[cls] / launches[cls]) if launches[cls] else None,
                          "flop_per_point": FLOP_PER_POINT, "points": pts[cls], "rank": 0},

@@ -90,7 +90,8 @@ int  nerf_amd_model_out_ch(const nerf_amd_model *m);       /* 4 with viewdirs, e
  * CPU tests check the fragment layout without a GPU).  Weights/biases are HOST
  * pointers here.  `stream_out` receives n_frags*512 uint16 (bf16 bits) and
  * `bias_out` the fp32 bias table; pass NULL to query sizes only. */
-int  nerf_amd_pack_bf16_host(const nerf_amd_arch *arch, const float *const *weights,
+int  nerf_amd_pack_bf16_host(const nerf_amd_arch *arch, int shape /* 32: 32x32x16 stream, 16: 16x16x32 stream */,
+                             const float *const *weights,
                              const float *const *biases, int n_tensors,
                              uint16_t *stream_out, int64_t *n_frags, float *bias_out, int64_t *n_bias);
 

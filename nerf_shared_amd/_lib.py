@@ -63,7 +63,7 @@ def _load():
         "nerf_amd_model_destroy": (None, [c_void_p]),
         "nerf_amd_model_supports_bf16": (c_int, [c_void_p]),
         "nerf_amd_model_out_ch": (c_int, [c_void_p]),
-        "nerf_amd_pack_bf16_host": (c_int, [POINTER(Arch), pp_f, pp_f, c_int, POINTER(c_uint16), POINTER(c_int64),
+        "nerf_amd_pack_bf16_host": (c_int, [POINTER(Arch), c_int, pp_f, pp_f, c_int, POINTER(c_uint16), POINTER(c_int64),
                                             POINTER(c_float), POINTER(c_int64)]),
         "nerf_amd_embed": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
         "nerf_amd_nerf_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int, c_void_p]),

@@ -57,8 +57,10 @@ struct nerf_amd_model {
     TensorDesc *d_tensors = nullptr;
     const float **d_wptrs = nullptr, **d_bptrs = nullptr;
     std::vector<const float *> h_wptrs, h_bptrs;
-    uint16_t *stream_bf16 = nullptr;
-    float *bias_bf16 = nullptr, *stream_f32 = nullptr, *bias_f32 = nullptr;
+    uint16_t *stream_bf16 = nullptr, *stream_s16 = nullptr;
+    float *bias_bf16 = nullptr, *stream_f32 = nullptr, *bias_f32 = nullptr, *bias_s16 = nullptr;
+    FragDesc *d_frags16 = nullptr;
+    TileDesc *d_tiles16 = nullptr;
     bool packed = false;
 };
 
@@ -82,6 +84,7 @@ int nerf_amd_model_create(const nerf_amd_arch *arch, int device, nerf_amd_model 
     const Program &p = m->prog;
     int rc;
     if ((rc = upload(&m->d_frags, p.frags)) || (rc = upload(&m->d_tiles, p.tiles)) ||
+        (rc = upload(&m->d_frags16, p.frags16)) || (rc = upload(&m->d_tiles16, p.tiles16)) ||
         (rc = upload(&m->d_layers, p.layers)) || (rc = upload(&m->d_tensors, p.tensors))) {
         nerf_amd_model_destroy(m);
         return rc;
@@ -92,6 +95,8 @@ int nerf_amd_model_create(const nerf_amd_arch *arch, int device, nerf_amd_model 
     if (e == hipSuccess && p.bf16_ok) {
         e = hipMalloc(reinterpret_cast<void **>(&m->stream_bf16), p.frags.size() * 1024);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->bias_bf16), p.tiles.size() * 32 * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->stream_s16), p.frags16.size() * 1024);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->bias_s16), p.tiles16.size() * 16 * sizeof(float));
     }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->stream_f32), (size_t)p.f32_stream_floats * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->bias_f32), (size_t)p.f32_bias_floats * sizeof(float));
@@ -117,7 +122,8 @@ int nerf_amd_model_update(nerf_amd_model *m, const float *const *weights, const 
     HIP_TRY(hipMemcpyAsync(m->d_wptrs, m->h_wptrs.data(), n_tensors * sizeof(float *), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(m->d_bptrs, m->h_bptrs.data(), n_tensors * sizeof(float *), hipMemcpyHostToDevice, s));
     int rc = launch_pack(p, m->d_frags, m->d_tiles, m->d_layers, m->d_tensors, m->d_wptrs, m->d_bptrs,
-                         m->stream_bf16, m->bias_bf16, m->stream_f32, m->bias_f32, s);
+                         m->stream_bf16, m->bias_bf16, m->stream_f32, m->bias_f32,
+                         m->d_frags16, m->d_tiles16, m->stream_s16, m->bias_s16, s);
     if (rc) return fail(rc, "pack launch failed");
     m->packed = true;
     return NERF_AMD_OK;
@@ -127,6 +133,7 @@ void nerf_amd_model_destroy(nerf_amd_model *m) {
     if (!m) return;
     (void)hipFree(m->d_frags); (void)hipFree(m->d_tiles); (void)hipFree(m->d_layers); (void)hipFree(m->d_tensors);
     (void)hipFree(m->d_wptrs); (void)hipFree(m->d_bptrs);
+    (void)hipFree(m->d_frags16); (void)hipFree(m->d_tiles16); (void)hipFree(m->stream_s16); (void)hipFree(m->bias_s16);
     (void)hipFree(m->stream_bf16); (void)hipFree(m->bias_bf16); (void)hipFree(m->stream_f32); (void)hipFree(m->bias_f32);
     delete m;
 }
@@ -138,18 +145,19 @@ int nerf_amd_model_supports_bf16(const nerf_amd_model *m) {
 }
 int nerf_amd_model_out_ch(const nerf_amd_model *m) { return m ? m->prog.out_ch : 0; }
 
-int nerf_amd_pack_bf16_host(const nerf_amd_arch *arch, const float *const *weights, const float *const *biases,
+int nerf_amd_pack_bf16_host(const nerf_amd_arch *arch, int shape, const float *const *weights, const float *const *biases,
                             int n_tensors, uint16_t *stream_out, int64_t *n_frags, float *bias_out, int64_t *n_bias) {
+    if (shape != 16 && shape != 32) return fail(NERF_AMD_EINVAL, "shape must be 32 (32x32x16 stream) or 16 (16x16x32 stream)");
     if (!arch) return fail(NERF_AMD_EINVAL, "null argument");
     Program p;
     const char *err = "";
     if (build_program(*arch, p, &err) != 0) return fail(NERF_AMD_EINVAL, err);
     if (!p.bf16_ok) return fail(NERF_AMD_EUNSUPPORTED, "architecture has no fused bf16 program (needs D=8, W=256, skips=[4])");
-    if (n_frags) *n_frags = (int64_t)p.frags.size();
-    if (n_bias) *n_bias = (int64_t)p.tiles.size() * 32;
+    if (n_frags) *n_frags = (int64_t)(shape == 16 ? p.frags16.size() : p.frags.size());
+    if (n_bias) *n_bias = shape == 16 ? (int64_t)p.tiles16.size() * 16 : (int64_t)p.tiles.size() * 32;
     if (stream_out || bias_out) {
         if (!weights || !biases || n_tensors != (int)p.tensors.size()) return fail(NERF_AMD_EINVAL, "bad parameter list");
-        pack_bf16_host(p, weights, biases, stream_out, bias_out);
+        pack_bf16_host(p, shape, weights, biases, stream_out, bias_out);
     }
     return NERF_AMD_OK;
 }
@@ -168,6 +176,7 @@ int run_field(const nerf_amd_model *m, MlpArgs a, int precision, hipStream_t s) 
     const Program &p = m->prog;
     if (!m->packed) return fail(NERF_AMD_EINVAL, "model has no parameters yet (call nerf_amd_model_update)");
     a.stream_bf16 = m->stream_bf16; a.bias_bf16 = m->bias_bf16;
+    a.stream_s16 = m->stream_s16; a.bias_s16 = m->bias_s16;
     a.stream_f32 = m->stream_f32; a.bias_f32 = m->bias_f32;
     a.layers = m->d_layers; a.n_layers = (int)p.layers.size();
     a.input_ch = p.input_ch; a.input_ch_views = p.input_ch_views; a.W = p.arch.W; a.lds_rows = p.lds_rows;
@@ -203,7 +212,13 @@ int run_field(const nerf_amd_model *m, MlpArgs a, int precision, hipStream_t s) 
     if (precision == NERF_AMD_PREC_BF16) {
         if (!nerf_amd_model_supports_bf16(m))
             return fail(NERF_AMD_EUNSUPPORTED, "fused bf16 kernel needs D=8, W=256, skips=[4], multires/views in {(10,4),(15,6)}; use NERF_AMD_PREC_FP32");
-        rc = launch_mlp_bf16(a, p.arch.multires, p.arch.multires_views, p.arch.use_viewdirs, p.n_frags_used, (int)p.tiles.size(), s);
+        if (g_variant >= 100)   // A/B: the first-generation 32x32x16 kernel
+            rc = launch_mlp_bf16(a, p.arch.multires, p.arch.multires_views, p.arch.use_viewdirs, p.n_frags_used, (int)p.tiles.size(), s);
+        else {
+            rc = launch_mlp_bf16_s16(a, p.arch.multires, p.arch.multires_views, p.arch.use_viewdirs, p.n_frags16_used, (int)p.tiles16.size(), s);
+            if (rc == NERF_AMD_EUNSUPPORTED)   // e.g. output_ch > 16: the 32x32x16 kernel covers it
+                rc = launch_mlp_bf16(a, p.arch.multires, p.arch.multires_views, p.arch.use_viewdirs, p.n_frags_used, (int)p.tiles.size(), s);
+        }
     } else if (precision == NERF_AMD_PREC_FP32) {
         rc = launch_mlp_f32(a, s);
     } else {
@@ -330,7 +345,7 @@ int nerf_amd_render_rays(const nerf_amd_render_cfg *cfg, const nerf_amd_model *c
 }
 
 int nerf_amd_set_tuning(int key, int value) {
-    if (key == 0 && value >= 0 && value <= 15) { g_variant = value; return NERF_AMD_OK; }
+    if (key == 0 && value >= 0 && value <= 115) { g_variant = value; return NERF_AMD_OK; }
     return fail(NERF_AMD_EINVAL, "unknown tuning key/value");
 }
 

@@ -12,6 +12,8 @@ struct MlpArgs {
     // packed parameters (device)
     const uint16_t *stream_bf16;   // bf16 A-fragment stream
     const float *bias_bf16;        // [n_tiles][2][16]
+    const uint16_t *stream_s16;    // bf16 A-fragment stream for the 16x16x32 kernel
+    const float *bias_s16;         // [n_tiles16][16]
     const float *stream_f32;       // fp32 fragment stream
     const float *bias_f32;
     const LayerF32 *layers;        // device copy of the fp32 program
@@ -40,8 +42,12 @@ int launch_embed(const float *x, int64_t n, int multires, float *out, hipStream_
 // pack.hip
 int launch_pack(const Program &p, const FragDesc *d_frags, const TileDesc *d_tiles, const LayerF32 *d_layers,
                 const TensorDesc *d_tensors, const float *const *d_weight_ptrs, const float *const *d_bias_ptrs,
-                uint16_t *stream_bf16, float *bias_bf16, float *stream_f32, float *bias_f32, hipStream_t s);
-void pack_bf16_host(const Program &p, const float *const *w, const float *const *b, uint16_t *stream, float *bias);
+                uint16_t *stream_bf16, float *bias_bf16, float *stream_f32, float *bias_f32,
+                const FragDesc *d_frags16, const TileDesc *d_tiles16, uint16_t *stream_s16, float *bias_s16,
+                hipStream_t s);
+void pack_bf16_host(const Program &p, int shape, const float *const *w, const float *const *b, uint16_t *stream, float *bias);
+int launch_mlp_bf16_s16(const MlpArgs &a, int multires, int multires_views, int use_viewdirs,
+                        int n_frags_used, int n_tiles, hipStream_t s);
 
 // render.hip
 struct RenderCfgK {

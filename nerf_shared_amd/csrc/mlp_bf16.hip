@@ -24,132 +24,10 @@
 #include <utility>
 
 #include "kernels.h"
+#include "pipeline.h"
 #include "program.h"
 
 namespace na {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-
-template <int N, class F, int... Is>
-__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) {
-    (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-    static_for_impl<N>(f, std::make_integer_sequence<int, N>{});
-}
-
-// Compile-time shape of the weight pipeline.
-//   WAVES  waves per workgroup (each owns 32 points)
-//   BF     fragments per ring block (one workgroup barrier per block)
-//   NS     ring slots (blocks resident in LDS)
-//   PHASE  0: the sync for block b sits at its first fragment (drains this wave's LDS reads).
-//          p>0: the sync that publishes block b+1 sits p fragments into block b, so the
-//          reads of the next block's first fragments are not fenced behind a barrier.
-//   LA     with PHASE > 0: A fragments are read LA MFMAs ahead of their use through a register
-//          queue, so the reads for the MFMAs right after a barrier are already in flight
-//          when the barrier is reached (legal while LA <= PHASE <= BF - LA).
-//   ABL    timing-only ablations for A/B measurements (results are WRONG when non-zero):
-//          1 = no syncs/DMA, 2 = no LDS fragment reads, 4 = no positional encoding
-//   NP     32-point column tiles per wave: every A fragment read from LDS feeds NP MFMAs
-//          (NP = 2 halves the LDS read traffic; needs one wave per SIMD for its registers)
-template <int WAVES_, int BF_, int NS_, int PHASE_, int LA_ = 0, int ABL_ = 0, int NP_ = 1>
-struct Ctx {
-    static constexpr int WAVES = WAVES_, BF = BF_, NS = NS_, PHASE = PHASE_, LA = LA_, ABL = ABL_, NP = NP_;
-    static constexpr int WAVES_PER_SIMD = (WAVES_ * NP_ >= 8 && NP_ == 1) ? 2 : 1;
-    static_assert(LA_ == 0 || (PHASE_ > 0 && LA_ <= PHASE_ && PHASE_ + LA_ <= BF_), "read-ahead would cross an unpublished block");
-    bf16x8 q[LA_ > 0 ? LA_ : 1];
-    static constexpr int PIECES = BF / WAVES;            // 1-KiB DMA pieces per wave per block
-    static constexpr int BLOCK_BYTES = BF * 1024;
-    static constexpr int RING_BYTES = NS * BLOCK_BYTES;
-    static constexpr int LOOKAHEAD = PHASE > 0 ? 1 : 0;  // a sync at block b publishes block b + LOOKAHEAD
-    static_assert(BF % WAVES == 0 && NS >= 3 && PHASE < BF, "bad pipeline shape");
-    const char *gstream;     // this lane's view of the fragment stream (base + lane*16)
-    const char *ring_lane;   // LDS ring + lane*16
-    uint32_t ring_u32;       // LDS byte address of the ring
-    const float *bias_half;  // LDS bias table + (lane>>5)*16
-    int wave;
-};
-
-// LDS-DMA of this wave's share of stream block BB into its ring slot.
-template <int BB, class C>
-__device__ __forceinline__ void issue_block(const C &c) {
-    constexpr int slot = BB % C::NS;
-#pragma unroll
-    for (int i = 0; i < C::PIECES; ++i) {
-        const int piece = c.wave * C::PIECES + i;
-        const char *g = c.gstream + (size_t)BB * C::BLOCK_BYTES + piece * 1024;
-        const uint32_t l = c.ring_u32 + slot * C::BLOCK_BYTES + piece * 1024;   // wave-uniform
-        unsigned keep;
-        asm volatile(
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %2\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, off\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "v"(g), "s"(l)
-            : "memory");
-    }
-}
-
-// Sync S_b (b >= -LOOKAHEAD): this wave's pieces of block b+LOOKAHEAD have landed
-// (counted vmcnt: younger blocks stay in flight), everyone agrees (s_barrier), then
-// the slot of block b-1 -- which every wave has finished reading -- is refilled with
-// block b+NS-1.  With PHASE == 0 the slot being refilled was read up to the previous
-// instruction, so this wave's LDS reads are drained first (lgkmcnt(0)); with PHASE > 0
-// its last read is PHASE MFMAs old and already consumed, and only instruction motion
-// across the sync has to be prevented.
-template <int B, int NB, class C>
-__device__ __forceinline__ void block_sync(const C &c) {
-    if constexpr (C::ABL & 1) return;
-    constexpr int need = B + C::LOOKAHEAD;
-    constexpr int last_issued = (B + C::NS - 2) < (NB - 1) ? (B + C::NS - 2) : (NB - 1);
-    constexpr int cnt = (last_issued > need ? last_issued - need : 0) * C::PIECES;
-    if constexpr (C::PHASE == 0) {
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(cnt) : "memory");
-    } else {
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(cnt) : "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (B + C::NS - 1 < NB) issue_block<B + C::NS - 1>(c);
-}
-
-template <int NB, class C>
-__device__ __forceinline__ void pipeline_prologue(const C &c) {
-    if constexpr (C::ABL & 1) return;
-    static_for<C::NS - 1 - C::LOOKAHEAD>([&](auto b_) { constexpr int b = b_; if constexpr (b < NB) issue_block<b>(c); });
-}
-
-template <int n, class C>
-__device__ __forceinline__ bf16x8 ring_frag(const C &c) {
-    return *reinterpret_cast<const bf16x8 *>(c.ring_lane + ((n % (C::NS * C::BF)) << 10));
-}
-
-template <int n, int NB, class C>
-__device__ __forceinline__ void maybe_sync(const C &c) {
-    if constexpr (n % C::BF == C::PHASE && (n / C::BF + C::LOOKAHEAD) < NB) block_sync<n / C::BF, NB>(c);
-}
-
-// Fragment n of the stream, in consumption order (syncs included).
-template <int n, int NB, int NFRAGS, class C>
-__device__ __forceinline__ bf16x8 take(C &c) {
-    maybe_sync<n, NB>(c);
-    if constexpr (C::ABL & 2) {
-        bf16x8 f = c.q[0];
-        asm volatile("" : "+v"(f));     // opaque: keeps one MFMA per fragment without an LDS read
-        return f;
-    } else if constexpr (C::LA == 0) {
-        return ring_frag<n>(c);
-    } else {
-        const bf16x8 f = c.q[n % C::LA];
-        if constexpr (n + C::LA < NFRAGS) c.q[n % C::LA] = ring_frag<n + C::LA>(c);
-        return f;
-    }
-}
 
 // One 32-row output tile for the wave's NP column tiles: acc[i] = bias + sum over K1 k-steps
 // of x1 and K2 of x2.  Activation fragment k of column tile i is x[k * NP + i].
@@ -175,13 +53,6 @@ __device__ __forceinline__ void tile(C &c, const bf16x8 *x1, const bf16x8 *x2, f
         static_for<C::NP>([&](auto p_) { constexpr int p = p_;
             acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x2[k * C::NP + p], acc[p], 0, 0, 0); });
     });
-}
-
-// ReLU as one integer max on the fp32 bits (negative floats are negative ints);
-// fmaxf would cost a second v_max to canonicalise a possible sNaN.
-__device__ __forceinline__ float relu_bits(float v) {
-    int i = __builtin_bit_cast(int, v);
-    return __builtin_bit_cast(float, i > 0 ? i : 0);
 }
 
 template <bool RELU>
@@ -366,7 +237,7 @@ __global__ __launch_bounds__(C::WAVES * 64, C::WAVES_PER_SIMD) void mlp_bf16_ker
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // no LDS-DMA may outlive the workgroup
 }
 
-int g_variant = 0;   // tuning knob (nerf_amd_set_tuning key 0): pipeline shape, see launch_one
+int g_variant = 0;   // tuning knob (nerf_amd_set_tuning key 0): 0 = 16x16x32 kernel, 100+ = this file's shapes (launch_one)
 
 template <int LX, int LD, bool VD, class C>
 static int launch_wg(const MlpArgs &a, int n_frags_used, int n_tiles, hipStream_t s) {
@@ -394,7 +265,7 @@ template <int LX, int LD, bool VD>
 static int launch_one(const MlpArgs &a, int n_frags_used, int n_tiles, hipStream_t s) {
 #ifdef NERF_AMD_EXPERIMENTS   // extra pipeline shapes and timing-only ablations for tools/mlp_ab.py (slow to compile)
     if constexpr (LX == 10 && LD == 4 && VD) {
-        switch (g_variant) {
+        switch (g_variant - 100) {
             case 2: return launch_wg<LX, LD, VD, Ctx<8, 16, 6, 8, 2>>(a, n_frags_used, n_tiles, s);
             case 3: return launch_wg<LX, LD, VD, Ctx<8, 32, 3, 0>>(a, n_frags_used, n_tiles, s);
             case 4: return launch_wg<LX, LD, VD, Ctx<8, 16, 4, 8, 4>>(a, n_frags_used, n_tiles, s);
@@ -410,7 +281,7 @@ static int launch_one(const MlpArgs &a, int n_frags_used, int n_tiles, hipStream
     }
 #endif
     if constexpr (LX == 10 && LD == 4 && VD)
-        if (g_variant == 1) return launch_wg<LX, LD, VD, Ctx<8, 16, 3, 0>>(a, n_frags_used, n_tiles, s);   // round-1 first shape (A/B reference)
+        if (g_variant == 101) return launch_wg<LX, LD, VD, Ctx<8, 16, 3, 0>>(a, n_frags_used, n_tiles, s);   // round-1 first shape (A/B reference)
     return launch_wg<LX, LD, VD, CfgDefault>(a, n_frags_used, n_tiles, s);
 }
 

@@ -1,0 +1,285 @@
+// mlp_bf16_s16.hip -- the fused positional-encoding + 8x256 NeRF MLP on
+// v_mfma_f32_16x16x32_bf16 (second generation of mlp_bf16.hip; same algorithm,
+// same pipeline, different MFMA shape).
+//
+// Why a second shape: this kernel is power-bound, not issue-bound.  On MI355X the
+// 16x16x32 form sustains ~15 % more FLOP/s than 32x32x16 at equal cycles per FLOP
+// (tools/micro/mfma_shape.hip: 2.1 vs 1.84 PFLOP/s from registers, 1.70 vs 1.50 with
+// one LDS fragment read per two MFMAs), so the same work finishes sooner.
+//
+// Layout (program.h, "s16"): a wave owns 32 points as two 16-column tiles c = 0,1.
+// Output features come in 16-row tiles; two consecutive tiles (a pair) share the B
+// operands, and their accumulators -- lane (col, q) holds rows 4q..4q+3 -- convert in
+// place into the next layer's 32-deep k-step: elements 0-3 from the even tile, 4-7 from
+// the odd tile.  Each 1-KiB A fragment (16 rows x 32 k) feeds two MFMAs (c = 0,1).
+#include <hip/hip_runtime.h>
+#include <utility>
+
+#include "kernels.h"
+#include "pipeline.h"
+#include "program.h"
+
+namespace na {
+
+#define MFMA16(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, b_, c_, 0, 0, 0)
+
+// Pair of 16-row output tiles T, T+1 over K1 k-steps of x1 and K2 of x2.
+// Activation fragment of k-step k, column tile c is x[2*k + c].  acc[u][c]: tile u, column tile c.
+template <int F0, int T, int K1, int K2, int NB, int NFRAGS, class C>
+__device__ __forceinline__ void tile_pair(C &c, const bf16x8 *x1, const bf16x8 *x2, f32x4 (&acc)[2][2]) {
+    {
+        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(c.bias_half + T * 16);
+        const f32x4 b1 = *reinterpret_cast<const f32x4 *>(c.bias_half + (T + 1) * 16);
+        acc[0][0] = b0; acc[0][1] = b0; acc[1][0] = b1; acc[1][1] = b1;
+    }
+    static_for<K1>([&](auto k_) {
+        constexpr int k = k_, n = F0 + 2 * k;
+        const bf16x8 w0 = take<n, NB, NFRAGS>(c);
+        const bf16x8 w1 = take<n + 1, NB, NFRAGS>(c);
+        acc[0][0] = MFMA16(w0, x1[2 * k], acc[0][0]);
+        acc[0][1] = MFMA16(w0, x1[2 * k + 1], acc[0][1]);
+        acc[1][0] = MFMA16(w1, x1[2 * k], acc[1][0]);
+        acc[1][1] = MFMA16(w1, x1[2 * k + 1], acc[1][1]);
+    });
+    static_for<K2>([&](auto k_) {
+        constexpr int k = k_, n = F0 + 2 * K1 + 2 * k;
+        const bf16x8 w0 = take<n, NB, NFRAGS>(c);
+        const bf16x8 w1 = take<n + 1, NB, NFRAGS>(c);
+        acc[0][0] = MFMA16(w0, x2[2 * k], acc[0][0]);
+        acc[0][1] = MFMA16(w0, x2[2 * k + 1], acc[0][1]);
+        acc[1][0] = MFMA16(w1, x2[2 * k], acc[1][0]);
+        acc[1][1] = MFMA16(w1, x2[2 * k + 1], acc[1][1]);
+    });
+}
+
+// A single 16-row tile (the 1-row sigma head, the 3-row rgb head, output_linear).
+template <int F0, int T, int K1, int NB, int NFRAGS, class C>
+__device__ __forceinline__ void tile_single(C &c, const bf16x8 *x1, f32x4 (&acc)[2]) {
+    const f32x4 b0 = *reinterpret_cast<const f32x4 *>(c.bias_half + T * 16);
+    acc[0] = b0; acc[1] = b0;
+    static_for<K1>([&](auto k_) {
+        constexpr int k = k_, n = F0 + k;
+        const bf16x8 w0 = take<n, NB, NFRAGS>(c);
+        acc[0] = MFMA16(w0, x1[2 * k], acc[0]);
+        acc[1] = MFMA16(w0, x1[2 * k + 1], acc[1]);
+    });
+}
+
+template <bool RELU>
+__device__ __forceinline__ bf16x8 pack_pair(const f32x4 &even, const f32x4 &odd) {
+    bf16x8 y;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float a = even[r], b = odd[r];
+        if (RELU) { a = relu_bits(a); b = relu_bits(b); }
+        y[r] = (__bf16)a;
+        y[4 + r] = (__bf16)b;
+    }
+    return y;
+}
+
+// A hidden layer of NPAIR tile pairs -> y[2 * NPAIR] (k-step p, column tile c at y[2p + c]).
+template <int F0, int T0, int NPAIR, int K1, int K2, bool RELU, int NB, int NFRAGS, class C>
+__device__ __forceinline__ void layer16(C &c, const bf16x8 *x1, const bf16x8 *x2, bf16x8 *y) {
+    static_for<NPAIR>([&](auto p_) {
+        constexpr int p = p_;
+        f32x4 acc[2][2];
+        tile_pair<F0 + p * 2 * (K1 + K2), T0 + 2 * p, K1, K2, NB, NFRAGS>(c, x1, x2, acc);
+        y[2 * p] = pack_pair<RELU>(acc[0][0], acc[1][0]);
+        y[2 * p + 1] = pack_pair<RELU>(acc[0][1], acc[1][1]);
+    });
+}
+
+// Positional encoding into FRAG_GEN16 layout (program.h: gen16_col).  h = sin/cos family,
+// b = frequency parity of this lane quarter.  th + tl = x / (2 pi) as an exact fp32 pair;
+// multiplying by 4 and v_fract are exact, v_sin_f32 takes revolutions.
+template <int L, int K, int STRIDE>
+__device__ __forceinline__ void encode16(float x0, float x1, float x2, int h, int b, bf16x8 *out) {
+    constexpr float INV2PI_HI = 0.15915494f;
+    constexpr float INV2PI_LO = (float)(0.15915494309189535 - (double)INV2PI_HI);
+    constexpr int NSTEP = (L + 1) / 2, CAP = 8 * K;
+    constexpr int N_EVEN = gen16_ntrig(L, 0), N_ODD = gen16_ntrig(L, 1);
+    const float x[3] = {x0, x1, x2};
+    const float phase = h ? 0.25f : 0.0f;
+    const float s0 = b ? 2.0f : 1.0f;
+    float ra[3], tl[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float th = x[c] * INV2PI_HI;
+        tl[c] = (__builtin_fmaf(x[c], INV2PI_HI, -th) + x[c] * INV2PI_LO) * s0;
+        ra[c] = __builtin_amdgcn_fractf(th * s0);
+    }
+    float vals[CAP];
+#pragma unroll
+    for (int i = 0; i < CAP; ++i) vals[i] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (3 * s + c < CAP) vals[3 * s + c] = __builtin_amdgcn_sinf(ra[c] + (tl[c] + phase));
+            ra[c] = __builtin_amdgcn_fractf(ra[c] * 4.0f);
+            tl[c] *= 4.0f;
+        }
+    }
+    // slots past a group's trig count hold raw coordinates (or nothing)
+    auto coord = [&](int mc) { return mc == 0 ? x0 : mc == 1 ? x1 : mc == 2 ? x2 : 0.0f; };
+#pragma unroll
+    for (int i = (N_ODD < N_EVEN ? N_ODD : N_EVEN); i < CAP; ++i) {
+        const float v_even = i < N_EVEN ? vals[i] : (h ? coord(gen16_misc(L, 1, 0, i - N_EVEN)) : coord(gen16_misc(L, 0, 0, i - N_EVEN)));
+        const float v_odd = i < N_ODD ? vals[i] : (h ? coord(gen16_misc(L, 1, 1, i - N_ODD)) : coord(gen16_misc(L, 0, 1, i - N_ODD)));
+        vals[i] = b ? v_odd : v_even;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[k * STRIDE][j] = (__bf16)vals[8 * k + j];
+}
+
+template <int LX, int LD, bool VD>
+struct Layout16 {
+    static constexpr int KE = gen16_ksteps(LX);
+    static constexpr int KD = VD ? gen16_ksteps(LD) : 0;
+    static constexpr int F_L0 = 0;
+    static constexpr int F_L1 = F_L0 + 16 * KE;
+    static constexpr int F_L5 = F_L1 + 4 * 128;
+    static constexpr int F_L6 = F_L5 + 16 * (KE + 8);
+    static constexpr int F_HEAD = F_L6 + 2 * 128;
+    static constexpr int F_FEAT = F_HEAD;
+    static constexpr int F_ALPHA = F_FEAT + 128;
+    static constexpr int F_VIEWS = F_ALPHA + 8;
+    static constexpr int F_RGB = F_VIEWS + 8 * (8 + KD);
+    static constexpr int F_END = VD ? F_RGB + 4 : F_HEAD + 8;
+    static constexpr int N_TILES = VD ? 128 + 16 + 1 + 8 + 1 : 128 + 1;
+};
+
+template <int LX, int LD, bool VD, class C>
+__global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16_kernel(MlpArgs a) {
+    constexpr int WG_THREADS = C::WAVES * 64, WG_POINTS = C::WAVES * 32;
+    using Lay = Layout16<LX, LD, VD>;
+    constexpr int KE = Lay::KE, KD = Lay::KD, NF = Lay::F_END, NB = (NF + C::BF - 1) / C::BF;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *bias_lds = reinterpret_cast<float *>(smem + C::RING_BYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int q = lane >> 4;
+    C c;
+    c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    c.gstream = reinterpret_cast<const char *>(a.stream_s16) + lane * 16;
+    c.ring_lane = smem + lane * 16;
+    c.ring_u32 = (uint32_t)(uintptr_t)smem;
+    c.bias_half = bias_lds + q * 4;          // this lane's 4 rows of every 16-row tile
+
+    pipeline_prologue<NB>(c);
+
+    for (int i = tid; i < Lay::N_TILES * 16; i += WG_THREADS) bias_lds[i] = a.bias_s16[i];
+
+    // ---- this lane's two points: column tile cc, column lane&15 (all four lane quarters hold the same points)
+    bf16x8 E[KE * 2];
+    bf16x8 Dv[(VD ? KD : 1) * 2];
+    int64_t pidx[2];
+    bool valid[2];
+    static_for<2>([&](auto cc_) {
+        constexpr int cc = cc_;
+        const int64_t p = (int64_t)blockIdx.x * WG_POINTS + c.wave * 32 + cc * 16 + (lane & 15);
+        pidx[cc] = p;
+        valid[cc] = p < a.P;
+        const int64_t pc = valid[cc] ? p : a.P - 1;
+        const int64_t ray = (int64_t)((uint32_t)pc / (uint32_t)a.S);   // P < 2^31 (checked at launch)
+        float x0, x1, x2;
+        if (a.pts) {
+            x0 = a.pts[3 * pc + 0]; x1 = a.pts[3 * pc + 1]; x2 = a.pts[3 * pc + 2];
+        } else {
+            const float *r = a.rays + ray * a.ray_stride;
+            const float z = a.z_vals[pc];
+            x0 = __fadd_rn(r[0], __fmul_rn(r[3], z));
+            x1 = __fadd_rn(r[1], __fmul_rn(r[4], z));
+            x2 = __fadd_rn(r[2], __fmul_rn(r[5], z));
+        }
+        encode16<LX, KE, 2>(x0, x1, x2, q >> 1, q & 1, E + cc);
+        if constexpr (VD) {
+            const float *d = a.viewdirs + ray * a.vd_stride;
+            encode16<LD, KD, 2>(d[0], d[1], d[2], q >> 1, q & 1, Dv + cc);
+        }
+    });
+
+    if constexpr (C::PHASE > 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // bias table stores, before the barrier publishes them
+        block_sync<-1, NB>(c);                                 // publishes block 0
+        static_for<C::LA>([&](auto i_) { constexpr int i = i_; c.q[i] = ring_frag<i>(c); });
+    }
+    bf16x8 A[16], B[16];
+    layer16<Lay::F_L0, 0, 8, KE, 0, true, NB, NF>(c, E, E, A);
+    layer16<Lay::F_L1 + 0 * 128, 16, 8, 8, 0, true, NB, NF>(c, A, A, B);
+    layer16<Lay::F_L1 + 1 * 128, 32, 8, 8, 0, true, NB, NF>(c, B, B, A);
+    layer16<Lay::F_L1 + 2 * 128, 48, 8, 8, 0, true, NB, NF>(c, A, A, B);
+    layer16<Lay::F_L1 + 3 * 128, 64, 8, 8, 0, true, NB, NF>(c, B, B, A);
+    layer16<Lay::F_L5, 80, 8, KE, 8, true, NB, NF>(c, E, A, B);            // skip: [input_pts | h]
+    layer16<Lay::F_L6, 96, 8, 8, 0, true, NB, NF>(c, B, B, A);
+    layer16<Lay::F_L6 + 128, 112, 8, 8, 0, true, NB, NF>(c, A, A, B);      // h7 in B
+
+    if constexpr (VD) {
+        layer16<Lay::F_FEAT, 128, 8, 8, 0, false, NB, NF>(c, B, B, A);     // feature (no activation)
+        f32x4 alpha[2], rgb[2];
+        tile_single<Lay::F_ALPHA, 144, 8, NB, NF>(c, B, alpha);            // row 0 = sigma
+        layer16<Lay::F_VIEWS, 145, 4, 8, KD, true, NB, NF>(c, A, Dv, B);   // views_linears.0 (128 rows)
+        tile_single<Lay::F_RGB, 153, 4, NB, NF>(c, B, rgb);                // rows 0..2
+        static_for<2>([&](auto cc_) {
+            constexpr int cc = cc_;
+            if (valid[cc] && q == 0) {
+                f32x4 o = {rgb[cc][0], rgb[cc][1], rgb[cc][2], alpha[cc][0]};
+                *reinterpret_cast<f32x4 *>(a.out + 4 * pidx[cc]) = o;
+            }
+        });
+    } else {
+        f32x4 o[2];
+        tile_single<Lay::F_HEAD, 128, 8, NB, NF>(c, B, o);
+        static_for<2>([&](auto cc_) {
+            constexpr int cc = cc_;
+            if (valid[cc]) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * q + r;
+                    if (row < a.out_ch) a.out[(int64_t)a.out_ch * pidx[cc] + row] = o[cc][r];
+                }
+            }
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // no LDS-DMA may outlive the workgroup
+}
+
+template <int LX, int LD, bool VD, class C>
+static int launch_wg16(const MlpArgs &a, int n_frags_used, int n_tiles, hipStream_t s) {
+    constexpr int WG_THREADS = C::WAVES * 64, WG_POINTS = C::WAVES * 32;
+    using Lay = Layout16<LX, LD, VD>;
+    if (n_frags_used != Lay::F_END || n_tiles != Lay::N_TILES) return NERF_AMD_EINVAL;
+    const size_t lds = C::RING_BYTES + (size_t)Lay::N_TILES * 16 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_bf16_s16_kernel<LX, LD, VD, C>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return NERF_AMD_EHIP;
+        attr_set = true;
+    }
+    const int64_t groups = (a.P + WG_POINTS - 1) / WG_POINTS;
+    if (groups <= 0) return NERF_AMD_OK;
+    if (a.P >= (int64_t)1 << 31) return NERF_AMD_EINVAL;
+    hipLaunchKernelGGL((mlp_bf16_s16_kernel<LX, LD, VD, C>), dim3((unsigned)groups), dim3(WG_THREADS), lds, s, a);
+    return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
+}
+
+using Cfg16 = Ctx<8, 16, 4, 8, 2>;
+
+int launch_mlp_bf16_s16(const MlpArgs &a, int multires, int multires_views, int use_viewdirs,
+                        int n_frags_used, int n_tiles, hipStream_t s) {
+    if (use_viewdirs) {
+        if (multires == 10 && multires_views == 4) return launch_wg16<10, 4, true, Cfg16>(a, n_frags_used, n_tiles, s);
+        if (multires == 15 && multires_views == 6) return launch_wg16<15, 6, true, Cfg16>(a, n_frags_used, n_tiles, s);
+    } else if (a.out_ch <= 16) {
+        if (multires == 10) return launch_wg16<10, 0, false, Cfg16>(a, n_frags_used, n_tiles, s);
+        if (multires == 15) return launch_wg16<15, 0, false, Cfg16>(a, n_frags_used, n_tiles, s);
+    }
+    return NERF_AMD_EUNSUPPORTED;
+}
+
+}  // namespace na

@@ -19,10 +19,13 @@ NA_HD inline uint16_t f32_to_bf16_rne(float f) {
 
 // Weight column (inside the tensor) held by element j of lane `lane` of fragment d, or -1.
 NA_HD inline int frag_source(const FragDesc &d, int lane, int j, int n_out, int *row) {
-    const int o = lane & 31, h = lane >> 5;
+    const bool s16 = d.kind == FRAG_ACC16 || d.kind == FRAG_GEN16;
+    const int o = s16 ? (lane & 15) : (lane & 31), h = s16 ? (lane >> 4) : (lane >> 5);
     *row = d.row0 + o;
     if (d.kind == FRAG_ZERO || *row >= n_out) return -1;
-    const int c = d.kind == FRAG_GEN ? gen_col(d.ks, h, j, d.L) : acc_col(d.ks, h, j);
+    const int c = d.kind == FRAG_GEN ? gen_col(d.ks, h, j, d.L)
+                : d.kind == FRAG_ACC ? acc_col(d.ks, h, j)
+                : d.kind == FRAG_GEN16 ? gen16_col(d.ks, h, j, d.L) : acc16_col(d.ks, h, j);
     if (c < 0 || c >= d.seg_len) return -1;
     return d.col_base + c;
 }
@@ -46,6 +49,13 @@ __global__ __launch_bounds__(32) void pack_bias_bf16_kernel(const TileDesc *tile
     table[blockIdx.x * 32 + threadIdx.x] = row < tensors[t.tensor].n_out ? biases[t.tensor][row] : 0.0f;
 }
 
+__global__ __launch_bounds__(16) void pack_bias_s16_kernel(const TileDesc *tiles, const TensorDesc *tensors,
+                                                           const float *const *biases, float *table) {
+    const TileDesc t = tiles[blockIdx.x];
+    const int row = t.row0 + threadIdx.x;           // [q][r] with row = 4q + r is just the natural order
+    table[blockIdx.x * 16 + threadIdx.x] = row < tensors[t.tensor].n_out ? biases[t.tensor][row] : 0.0f;
+}
+
 // fp32 stream: one block per (layer, tile, group); 256 threads = 64 lanes x 4 k-pairs.
 __global__ __launch_bounds__(256) void pack_f32_kernel(const LayerF32 *layers, int n_layers,
                                                        const float *const *weights, const float *const *biases,
@@ -65,8 +75,14 @@ __global__ __launch_bounds__(256) void pack_f32_kernel(const LayerF32 *layers, i
 
 int launch_pack(const Program &p, const FragDesc *d_frags, const TileDesc *d_tiles, const LayerF32 *d_layers,
                 const TensorDesc *d_tensors, const float *const *d_w, const float *const *d_b,
-                uint16_t *stream_bf16, float *bias_bf16, float *stream_f32, float *bias_f32, hipStream_t s) {
+                uint16_t *stream_bf16, float *bias_bf16, float *stream_f32, float *bias_f32,
+                const FragDesc *d_frags16, const TileDesc *d_tiles16, uint16_t *stream_s16, float *bias_s16,
+                hipStream_t s) {
     if (p.bf16_ok) {
+        hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)p.frags16.size()), dim3(512), 0, s,
+                           d_frags16, d_tensors, d_w, stream_s16);
+        hipLaunchKernelGGL(pack_bias_s16_kernel, dim3((unsigned)p.tiles16.size()), dim3(16), 0, s,
+                           d_tiles16, d_tensors, d_b, bias_s16);
         hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)p.frags.size()), dim3(512), 0, s,
                            d_frags, d_tensors, d_w, stream_bf16);
         hipLaunchKernelGGL(pack_bias_bf16_kernel, dim3((unsigned)p.tiles.size()), dim3(32), 0, s,
@@ -77,8 +93,27 @@ int launch_pack(const Program &p, const FragDesc *d_frags, const TileDesc *d_til
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
 
-void pack_bf16_host(const Program &p, const float *const *w, const float *const *b,
+void pack_bf16_host(const Program &p, int shape, const float *const *w, const float *const *b,
                     uint16_t *stream, float *bias) {
+    if (shape == 16) {
+        if (stream)
+            for (size_t n = 0; n < p.frags16.size(); ++n)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        int row;
+                        const TensorDesc &t = p.tensors[p.frags16[n].tensor];
+                        const int col = frag_source(p.frags16[n], lane, j, t.n_out, &row);
+                        stream[n * 512 + lane * 8 + j] =
+                            f32_to_bf16_rne(col < 0 ? 0.0f : w[p.frags16[n].tensor][(int64_t)row * t.n_in + col]);
+                    }
+        if (bias)
+            for (size_t ti = 0; ti < p.tiles16.size(); ++ti)
+                for (int r = 0; r < 16; ++r) {
+                    const int row = p.tiles16[ti].row0 + r;
+                    bias[ti * 16 + r] = row < p.tensors[p.tiles16[ti].tensor].n_out ? b[p.tiles16[ti].tensor][row] : 0.0f;
+                }
+        return;
+    }
     if (stream)
         for (size_t n = 0; n < p.frags.size(); ++n)
             for (int lane = 0; lane < 64; ++lane)

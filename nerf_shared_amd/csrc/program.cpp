@@ -101,6 +101,39 @@ int build_program(const nerf_amd_arch &a, Program &p, const char **err) {
         }
         p.n_frags_used = (int)p.frags.size();
         while (p.frags.size() % STREAM_PAD_FRAGS) p.frags.push_back({0, FRAG_ZERO, 0, 0, 0, 0, 0, 0});
+
+        // ---- s16 program: layer -> pair of 16-row tiles -> k-step -> tile of the pair
+        p.KE16 = gen16_ksteps(Lx);
+        p.KD16 = a.use_viewdirs ? gen16_ksteps(Ld) : 0;
+        auto add_layer16 = [&](int tensor, std::initializer_list<Seg> segs) {
+            const int n_out = p.tensors[tensor].n_out;
+            const int n_tiles = (n_out + 15) / 16;
+            for (int t = 0; t < n_tiles; t += 2) {
+                const int in_pair = (t + 1 < n_tiles) ? 2 : 1;
+                for (int u = 0; u < in_pair; ++u) p.tiles16.push_back({tensor, 16 * (t + u)});
+                for (const Seg &s : segs)
+                    for (int ks = 0; ks < s.nk; ++ks)
+                        for (int u = 0; u < in_pair; ++u)
+                            p.frags16.push_back({tensor, s.kind, 16 * (t + u), s.col_base, ks, s.len, s.L, 0});
+            }
+        };
+        const Seg E16{FRAG_GEN16, 0, p.input_ch, p.KE16, Lx};
+        const Seg H16{FRAG_ACC16, 0, W, 8, 0};
+        add_layer16(0, {E16});
+        for (int i = 1; i <= 4; ++i) add_layer16(i, {H16});
+        add_layer16(5, {E16, Seg{FRAG_ACC16, p.input_ch, W, 8, 0}});
+        add_layer16(6, {H16});
+        add_layer16(7, {H16});
+        if (a.use_viewdirs) {
+            add_layer16(8, {H16});
+            add_layer16(9, {H16});
+            add_layer16(10, {H16, Seg{FRAG_GEN16, W, p.input_ch_views, p.KD16, Ld}});
+            add_layer16(11, {Seg{FRAG_ACC16, 0, W / 2, 4, 0}});
+        } else {
+            add_layer16(8, {H16});
+        }
+        p.n_frags16_used = (int)p.frags16.size();
+        while (p.frags16.size() % STREAM_PAD_FRAGS) p.frags16.push_back({0, FRAG_ZERO, 0, 0, 0, 0, 0, 0});
     }
     return 0;
 }

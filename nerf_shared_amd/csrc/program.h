@@ -21,6 +21,15 @@
 //                          e = 3L+1-> column 1 (h=0) / none (h=1)   (raw y)
 //      (column = index into the reference embedding, nerf.py:16-41).
 //
+// bf16 "s16" stream (mlp_bf16_s16.hip): same idea on v_mfma_f32_16x16x32_bf16
+//   (lane l holds A[row = l&15][k = 8*(l>>4) + j]; C/D: col = l&15, row = 4*(l>>4) + r, r<4).
+//   A wave still owns 32 points, as two 16-column tiles.  Fragments are 16 out rows x 32 k
+//   (1 KiB), ordered layer -> pair of output tiles -> k-step -> tile of the pair.
+//    * FRAG_ACC16: k-step ks is fed by the accumulators of output tiles 2ks and 2ks+1 of the
+//      previous layer, so k slot (q = l>>4, j) means input column 32*ks + 16*(j>>2) + 4*q + (j&3).
+//    * FRAG_GEN16: lane quarter q = 2h + b evaluates sin (h=0) or cos (h=1) of the frequencies
+//      of parity b; see gen16_col below.
+//
 // fp32 stream (generic kernel, mlp_fp32.hip)
 //   v_mfma_f32_32x32x2_f32: lane l holds A[row = l&31][k = l>>5].  Fragments are
 //   grouped four k-pairs at a time so a lane loads 16 bytes: group g of tile t
@@ -39,7 +48,7 @@
 
 namespace na {
 
-enum { FRAG_ACC = 0, FRAG_GEN = 1, FRAG_ZERO = 2 };
+enum { FRAG_ACC = 0, FRAG_GEN = 1, FRAG_ZERO = 2, FRAG_ACC16 = 3, FRAG_GEN16 = 4 };
 
 struct FragDesc {        // one bf16 A fragment: 32 out rows x 16 k
     int32_t tensor;      // index into the parameter list (nerf_amd.h order)
@@ -91,6 +100,29 @@ NA_HD constexpr inline int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2)
 
 NA_HD constexpr inline int gen_ksteps(int L) { return (3 * L + 2 + 7) / 8; }   // k-steps of a generated encoding
 
+// --- 16x16x32 ("s16") layout
+// Generated encodings: lane quarter q = 2h + b.  h picks sin (0) / cos (1); b picks the
+// frequency parity, so that every lane walks f = b, b+2, b+4, ... with one exact x4 step.
+// Slot i = 8*ks + j of group (h,b) holds trig feature (f = 2*(i/3) + b, coordinate i%3) while
+// i < gen16_ntrig(L,b); the free slots after that hold the raw coordinates x,y,z, handed
+// out in the fixed group order (h,b) = (0,1), (1,1), (0,0), (1,0).
+NA_HD constexpr inline int gen16_ksteps(int L) { return (3 * L + 2 + 15) / 16; }
+NA_HD constexpr inline int gen16_ntrig(int L, int b) { return 3 * ((L - b + 1) / 2); }
+NA_HD constexpr inline int gen16_misc(int L, int h, int b, int m) {
+    const int cap = 8 * gen16_ksteps(L);
+    const int g = b ? h : 2 + h;                      // position in the hand-out order
+    int offset = 0;
+    for (int gg = 0; gg < g; ++gg) offset += cap - gen16_ntrig(L, gg < 2 ? 1 : 0);
+    const int idx = offset + m;
+    return idx < 3 ? idx : -1;
+}
+NA_HD constexpr inline int gen16_col(int ks, int q, int j, int L) {
+    const int h = q >> 1, b = q & 1, i = 8 * ks + j, n = gen16_ntrig(L, b);
+    if (i < n) return 3 + 6 * (2 * (i / 3) + b) + 3 * h + (i % 3);
+    return gen16_misc(L, h, b, i - n);
+}
+NA_HD constexpr inline int acc16_col(int ks, int q, int j) { return 32 * ks + 16 * (j >> 2) + 4 * q + (j & 3); }
+
 inline int embed_dim(int L, int i_embed) { return i_embed == -1 ? 3 : 3 + 6 * L; }
 
 struct Program {
@@ -103,6 +135,11 @@ struct Program {
     std::vector<FragDesc> frags;     // padded to a whole number of ring turns
     std::vector<TileDesc> tiles;
     int n_frags_used = 0;
+    // bf16 s16 program (16x16x32 MFMA); tiles16 are 16-row tiles
+    int KE16 = 0, KD16 = 0;
+    std::vector<FragDesc> frags16;
+    std::vector<TileDesc> tiles16;
+    int n_frags16_used = 0;
     // fp32 generic program
     std::vector<LayerF32> layers;
     int64_t f32_stream_floats = 0, f32_bias_floats = 0;

@@ -44,10 +44,10 @@ def test_program_validation_errors():
     h = ctypes.c_void_p()
     bad = _lib.make_arch(8, 250, 4, [4], True, 10, 4, 0)        # W not a multiple of 32
     nf = ctypes.c_int64()
-    assert lib.nerf_amd_pack_bf16_host(ctypes.byref(bad), None, None, 0, None, ctypes.byref(nf), None, None) == -1
+    assert lib.nerf_amd_pack_bf16_host(ctypes.byref(bad), 32, None, None, 0, None, ctypes.byref(nf), None, None) == -1
     assert b"multiple of 32" in lib.nerf_amd_last_error()
     bad = _lib.make_arch(8, 256, 4, [7], True, 10, 4, 0)        # skip on the last layer: the reference fails too
-    assert lib.nerf_amd_pack_bf16_host(ctypes.byref(bad), None, None, 0, None, ctypes.byref(nf), None, None) == -1
+    assert lib.nerf_amd_pack_bf16_host(ctypes.byref(bad), 32, None, None, 0, None, ctypes.byref(nf), None, None) == -1
     with pytest.raises(ValueError):
         _lib.make_arch(8, 256, 4, list(range(9)), True, 10, 4, 0)
     del h

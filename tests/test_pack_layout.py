@@ -50,7 +50,7 @@ def gen_ksteps(L):
     return (3 * L + 2 + 7) // 8
 
 
-def host_pack(arch_kwargs, sd):
+def host_pack(arch_kwargs, sd, shape=32):
     names = ["pts_linears.%d" % i for i in range(arch_kwargs["D"])]
     if arch_kwargs["use_viewdirs"]:
         names += ["feature_linear", "alpha_linear", "views_linears.0", "rgb_linear"]
@@ -64,13 +64,155 @@ def host_pack(arch_kwargs, sd):
     wp = (ctypes.c_void_p * n)(*[w.ctypes.data for w in ws])
     bp = (ctypes.c_void_p * n)(*[b.ctypes.data for b in bs])
     nf, nb = ctypes.c_int64(), ctypes.c_int64()
-    _lib.check(lib.nerf_amd_pack_bf16_host(ctypes.byref(arch), wp, bp, n, None, ctypes.byref(nf), None, ctypes.byref(nb)), "size query")
+    _lib.check(lib.nerf_amd_pack_bf16_host(ctypes.byref(arch), shape, wp, bp, n, None, ctypes.byref(nf), None, ctypes.byref(nb)), "size query")
     stream = np.zeros(nf.value * 512, np.uint16)
     bias = np.zeros(nb.value, np.float32)
-    _lib.check(lib.nerf_amd_pack_bf16_host(ctypes.byref(arch), wp, bp, n,
+    _lib.check(lib.nerf_amd_pack_bf16_host(ctypes.byref(arch), shape, wp, bp, n,
                                            stream.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)), ctypes.byref(nf),
                                            bias.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), ctypes.byref(nb)), "pack")
+    if shape == 16:
+        return bf16_bits_to_f32(stream).reshape(nf.value, 64, 8), bias.reshape(-1, 16)
     return bf16_bits_to_f32(stream).reshape(nf.value, 64, 8), bias.reshape(-1, 2, 16)
+
+
+# ---------------------------------------------------------------- 16x16x32 ("s16") twin of program.h
+def gen16_ksteps(L):
+    return (3 * L + 2 + 15) // 16
+
+
+def gen16_ntrig(L, b):
+    return 3 * ((L - b + 1) // 2)
+
+
+def gen16_misc(L, h, b, m):
+    cap = 8 * gen16_ksteps(L)
+    g = h if b else 2 + h
+    offset = sum(cap - gen16_ntrig(L, 1 if gg < 2 else 0) for gg in range(g))
+    idx = offset + m
+    return idx if idx < 3 else -1
+
+
+def gen16_col(ks, q, j, L):
+    h, b, i = q >> 1, q & 1, 8 * ks + j
+    n = gen16_ntrig(L, b)
+    if i < n:
+        return 3 + 6 * (2 * (i // 3) + b) + 3 * h + (i % 3)
+    return gen16_misc(L, h, b, i - n)
+
+
+class WaveEmu16:
+    """One wave = 32 points as two 16-column tiles, walked as mlp_bf16_s16.hip does."""
+
+    def __init__(self, stream, bias):
+        self.stream, self.bias = stream, bias
+
+    @staticmethod
+    def mfma(a_frag, b_frag, acc):
+        # A[row = l&15][k = 8*(l>>4)+j], B[k = 8*(l>>4)+j][col = l&15]; D: col = l&15, row = 4*(l>>4)+r
+        A = np.zeros((16, 32), np.float32)
+        B = np.zeros((32, 16), np.float32)
+        for l in range(64):
+            A[l & 15, 8 * (l >> 4):8 * (l >> 4) + 8] = a_frag[l]
+            B[8 * (l >> 4):8 * (l >> 4) + 8, l & 15] = b_frag[l]
+        D = A.astype(np.float64) @ B.astype(np.float64)
+        out = acc.copy()
+        for l in range(64):
+            for r in range(4):
+                out[l, r] += D[4 * (l >> 4) + r, l & 15]
+        return out
+
+    def bias_init(self, t):
+        acc = np.zeros((64, 4), np.float64)
+        for l in range(64):
+            acc[l] = self.bias[t, 4 * (l >> 4):4 * (l >> 4) + 4]
+        return acc
+
+    def tile_pair(self, f0, t, x1, k1, x2=None, k2=0):
+        acc = [[self.bias_init(t), self.bias_init(t)], [self.bias_init(t + 1), self.bias_init(t + 1)]]
+        n = f0
+        for xs, kk in ((x1, k1), (x2, k2)):
+            for k in range(kk):
+                for u in range(2):
+                    w = self.stream[n]
+                    n += 1
+                    for cc in range(2):
+                        acc[u][cc] = self.mfma(w, xs[2 * k + cc], acc[u][cc])
+        return acc
+
+    def tile_single(self, f0, t, x1, k1):
+        acc = [self.bias_init(t), self.bias_init(t)]
+        for k in range(k1):
+            for cc in range(2):
+                acc[cc] = self.mfma(self.stream[f0 + k], x1[2 * k + cc], acc[cc])
+        return [a.astype(np.float32) for a in acc]
+
+    def layer(self, f0, t0, npair, x1, k1, x2=None, k2=0, relu=True):
+        y = []
+        for p in range(npair):
+            acc = self.tile_pair(f0 + p * 2 * (k1 + k2), t0 + 2 * p, x1, k1, x2, k2)
+            for cc in range(2):
+                ev, od = acc[0][cc].astype(np.float32), acc[1][cc].astype(np.float32)
+                if relu:
+                    ev, od = np.maximum(ev, 0), np.maximum(od, 0)
+                y.append(bf16_round(np.concatenate([ev, od], -1)))
+        return y
+
+    @staticmethod
+    def encode(emb, L, K):
+        """emb [32, 3+6L] -> fragments [2*K] of [64, 8]: index 2*ks + cc (FRAG_GEN16 order)."""
+        out = []
+        for ks in range(K):
+            for cc in range(2):
+                f = np.zeros((64, 8), np.float32)
+                for l in range(64):
+                    for j in range(8):
+                        c = gen16_col(ks, l >> 4, j, L)
+                        f[l, j] = emb[16 * cc + (l & 15), c] if c >= 0 else 0.0
+                out.append(bf16_round(f))
+        return out
+
+
+def emulate16(arch, sd, pts, dirs):
+    LX, LD, VD = arch["multires"], arch["multires_views"], arch["use_viewdirs"]
+    KE, KD = gen16_ksteps(LX), (gen16_ksteps(LD) if VD else 0)
+    stream, bias = host_pack(arch, sd, 16)
+    F_L1 = 16 * KE
+    F_L5 = F_L1 + 4 * 128
+    F_L6 = F_L5 + 16 * (KE + 8)
+    F_HEAD = F_L6 + 256
+    w = WaveEmu16(stream, bias)
+    E = w.encode(O.embed(torch.from_numpy(pts), LX).numpy(), LX, KE)
+    A = w.layer(0, 0, 8, E, KE)
+    B = w.layer(F_L1, 16, 8, A, 8)
+    A = w.layer(F_L1 + 128, 32, 8, B, 8)
+    B = w.layer(F_L1 + 256, 48, 8, A, 8)
+    A = w.layer(F_L1 + 384, 64, 8, B, 8)
+    B = w.layer(F_L5, 80, 8, E, KE, A, 8)
+    A = w.layer(F_L6, 96, 8, B, 8)
+    B = w.layer(F_L6 + 128, 112, 8, A, 8)
+    out = np.zeros((32, 4 if VD else arch["output_ch"]), np.float32)
+    if VD:
+        Dv = w.encode(O.embed(torch.from_numpy(dirs), LD).numpy(), LD, KD)
+        F_ALPHA = F_HEAD + 128
+        F_VIEWS = F_ALPHA + 8
+        F_RGB = F_VIEWS + 8 * (8 + KD)
+        assert F_RGB + 4 <= stream.shape[0]
+        A = w.layer(F_HEAD, 128, 8, B, 8, relu=False)
+        alpha = w.tile_single(F_ALPHA, 144, B, 8)
+        B2 = w.layer(F_VIEWS, 145, 4, A, 8, Dv, KD)
+        rgb = w.tile_single(F_RGB, 153, B2, 4)
+        for cc in range(2):
+            out[16 * cc:16 * cc + 16, 0:3] = rgb[cc][:16, 0:3]
+            out[16 * cc:16 * cc + 16, 3] = alpha[cc][:16, 0]
+        return out
+    o = w.tile_single(F_HEAD, 128, B, 8)
+    for cc in range(2):
+        for qq in range(4):
+            for r in range(4):
+                row = 4 * qq + r
+                if row < arch["output_ch"]:
+                    out[16 * cc:16 * cc + 16, row] = o[cc][16 * qq:16 * qq + 16, r]
+    return out
 
 
 class WaveEmu:
@@ -195,6 +337,25 @@ CASES = [
 
 
 @pytest.mark.parametrize("arch", CASES, ids=["vd_10_4", "vd_15_6", "novd_10"])
+def test_s16_stream_matches_kernel_dataflow(arch):
+    """The 16x16x32 stream against the same plain evaluation (and so against the 32x32x16 one)."""
+    rng = np.random.default_rng(7)
+    pts = rng.uniform(-3, 3, size=(32, 3)).astype(np.float32)
+    dirs = rng.normal(size=(32, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    sd = synth.make_state_dict(3, 3.0, **{**arch, "skips": tuple(arch["skips"])})
+    np.testing.assert_allclose(emulate16(arch, sd, pts, dirs), plain_bf16(arch, sd, pts, dirs), atol=2e-3, rtol=2e-3)
+
+
+def test_gen16_layout_is_a_bijection():
+    """Every encoding column appears in exactly one (ks, q, j) slot, for every multires in use."""
+    for L in (4, 6, 10, 15, 1, 2, 3, 5, 7, 20):
+        cols = [gen16_col(ks, q, j, L) for ks in range(gen16_ksteps(L)) for q in range(4) for j in range(8)]
+        real = sorted(c for c in cols if c >= 0)
+        assert real == list(range(3 + 6 * L)), L
+
+
+@pytest.mark.parametrize("arch", CASES, ids=["vd_10_4", "vd_15_6", "novd_10"])
 def test_stream_matches_kernel_dataflow(arch):
     rng = np.random.default_rng(7)
     pts = rng.uniform(-3, 3, size=(32, 3)).astype(np.float32)
@@ -217,7 +378,7 @@ def test_stream_sizes_and_padding():
     arch = CASES[0]
     sd = synth.make_state_dict(3, 1.0, **{**arch, "skips": tuple(arch["skips"])})
     stream, bias = host_pack(arch, sd)
-    assert stream.shape[0] % 48 == 0 and stream.shape[0] >= 1184     # whole ring turns
+    assert stream.shape[0] % 192 == 0 and stream.shape[0] >= 1184    # padded to whole blocks of any shape
     assert bias.shape[0] == 78
     assert np.all(stream[1184:] == 0)                                 # padding fragments are zero
     # alpha tile: only output row 0 carries weights
@@ -229,5 +390,5 @@ def test_stream_sizes_and_padding():
 def test_unsupported_arch_reports_error():
     arch = _lib.make_arch(4, 128, 4, [1], True, 6, 2, 0)
     nf = ctypes.c_int64()
-    rc = lib.nerf_amd_pack_bf16_host(ctypes.byref(arch), None, None, 0, None, ctypes.byref(nf), None, None)
+    rc = lib.nerf_amd_pack_bf16_host(ctypes.byref(arch), 32, None, None, 0, None, ctypes.byref(nf), None, None)
     assert rc == -3 and b"D=8" in lib.nerf_amd_last_error()
