@@ -91,11 +91,13 @@ def main():
                          % (args.gpus, args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device; there is no CPU path")
-    dev = torch.device("cuda", local_rank)
+    # NERF_AMD_DIST_BACKEND=gloo rehearses the N>1 path with several ranks on one GPU (no RCCL)
+    backend = os.environ.get("NERF_AMD_DIST_BACKEND", "nccl")
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(backend)
 
     models = []
     for seed in (0, 10):
@@ -142,7 +144,7 @@ def main():
     _lib.lib.nerf_amd_profile_collect(launches, ms, pts)
     cls = 1 if args.precision == "bf16" else 0
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())

@@ -33,6 +33,10 @@ def gather_rows(local, n_total, dst=0, group=None):
     sizes = shard_sizes(n_total, world)
     assert local.shape[0] == sizes[rank], (local.shape, sizes, rank)
     C = local.shape[1]
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal path (several ranks sharing one GPU, no RCCL): stage through the host
+        out = gather_rows(local.cpu(), n_total, dst, group)
+        return out.to(local.device) if out is not None else None
     if max(sizes) == min(sizes):
         out = torch.empty(n_total, C, device=local.device, dtype=local.dtype) if rank == dst else None
         dist.gather(local.contiguous(), list(out.split(sizes[0])) if rank == dst else None, dst=dst, group=group)
