@@ -111,6 +111,19 @@ int nerf_amd_nerf_forward(const nerf_amd_model *m, const float *pts, const float
                           int64_t n_rays, int32_t n_samples, float *out, int precision, void *stream);
 
 /* ------------------------------------------------------------------------
+ * a4  NeRF.MLP on already-embedded rows       nerf.py:110-134
+ * x [n, input_ch + input_ch_views] -> out [n, out_ch]; exact-fp32 kernel.
+ * ------------------------------------------------------------------------ */
+int nerf_amd_mlp_embedded(const nerf_amd_model *m, const float *x, int64_t n, float *out, void *stream);
+
+/* ------------------------------------------------------------------------
+ * a13  utils.ndc_rays on explicit rays        utils.py:54-71
+ * rays_o, rays_d [n,3] -> out_o, out_d [n,3]; focal is the Python float K[0][0].
+ * ------------------------------------------------------------------------ */
+int nerf_amd_ndc_rays(int32_t H, int32_t W, double focal, float near, const float *rays_o, const float *rays_d,
+                      int64_t n, float *out_o, float *out_d, void *stream);
+
+/* ------------------------------------------------------------------------
  * a10  Renderer.raw2outputs                   render_utils.py:241-290
  * raw [R,S,raw_ch] (channels 0..2 rgb, 3 sigma), z_vals [R,S], rays_d with row
  * stride `rays_d_stride` floats, noise [R,S] or NULL (already scaled by

@@ -20,7 +20,7 @@ EXPORTS = (
     "nerf_amd_abi_version", "nerf_amd_last_error",
     "nerf_amd_model_create", "nerf_amd_model_update", "nerf_amd_model_destroy",
     "nerf_amd_model_supports_bf16", "nerf_amd_model_out_ch", "nerf_amd_pack_bf16_host",
-    "nerf_amd_embed", "nerf_amd_nerf_forward", "nerf_amd_raw2outputs", "nerf_amd_sample_pdf",
+    "nerf_amd_embed", "nerf_amd_nerf_forward", "nerf_amd_mlp_embedded", "nerf_amd_ndc_rays", "nerf_amd_raw2outputs", "nerf_amd_sample_pdf",
     "nerf_amd_render_rays_workspace", "nerf_amd_render_rays", "nerf_amd_make_rays",
     "nerf_amd_profile_enable", "nerf_amd_profile_collect", "nerf_amd_set_tuning",
 )
@@ -67,6 +67,9 @@ def _load():
                                             POINTER(c_float), POINTER(c_int64)]),
         "nerf_amd_embed": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
         "nerf_amd_nerf_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int, c_void_p]),
+        "nerf_amd_mlp_embedded": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+        "nerf_amd_ndc_rays": (c_int, [c_int32, c_int32, c_double, c_float, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                      c_void_p]),
         "nerf_amd_raw2outputs": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32,
                                          c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
         "nerf_amd_sample_pdf": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,

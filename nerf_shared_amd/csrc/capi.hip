@@ -243,6 +243,27 @@ int nerf_amd_nerf_forward(const nerf_amd_model *m, const float *pts, const float
     return run_field(m, a, precision, static_cast<hipStream_t>(stream));
 }
 
+int nerf_amd_mlp_embedded(const nerf_amd_model *m, const float *x, int64_t n, float *out, void *stream) {
+    if (!m || n < 0) return fail(NERF_AMD_EINVAL, "bad MLP arguments");
+    if (n == 0) return NERF_AMD_OK;
+    if (!x || !out) return fail(NERF_AMD_EINVAL, "null x/out");
+    MlpArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.embedded = x;
+    a.viewdirs = x;            // non-null marker: the view columns are inside x
+    a.vd_stride = 0;
+    a.P = n; a.S = 1; a.out = out;
+    return run_field(m, a, NERF_AMD_PREC_FP32, static_cast<hipStream_t>(stream));
+}
+
+int nerf_amd_ndc_rays(int32_t H, int32_t W, double focal, float near, const float *rays_o, const float *rays_d,
+                      int64_t n, float *out_o, float *out_d, void *stream) {
+    if (H < 1 || W < 1 || n < 0 || (n > 0 && (!rays_o || !rays_d || !out_o || !out_d)))
+        return fail(NERF_AMD_EINVAL, "bad ndc_rays arguments");
+    int rc = launch_ndc_rays(H, W, focal, near, rays_o, rays_d, n, out_o, out_d, static_cast<hipStream_t>(stream));
+    return rc ? fail(rc, "ndc_rays launch failed") : NERF_AMD_OK;
+}
+
 int nerf_amd_raw2outputs(const float *raw, int32_t raw_ch, const float *z_vals, const float *rays_d,
                          int32_t rays_d_stride, const float *noise, int64_t R, int32_t S, int white_bkgd,
                          float *rgb_map, float *disp_map, float *acc_map, float *weights, float *depth_map,

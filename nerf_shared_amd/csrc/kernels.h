@@ -20,7 +20,9 @@ struct MlpArgs {
     int32_t n_layers;
     int32_t input_ch, input_ch_views, W, lds_rows;
     int32_t multires, multires_views, i_embed;
-    // points: either explicit pts [P,3], or rays + z_vals (pts = o + d*z)
+    // points: pre-embedded rows [P, input_ch + input_ch_views] (fp32 kernel only), or explicit
+    // pts [P,3], or rays + z_vals (pts = o + d*z)
+    const float *embedded;
     const float *pts;
     const float *rays;             // [R, ray_stride]: o(3) d(3) ...
     const float *z_vals;           // [R, S]
@@ -62,6 +64,8 @@ int launch_sample_pdf(const float *bins, const float *weights, const float *u, c
                       int64_t R, int n_bins, int n_samples, float *samples, hipStream_t s);
 int launch_resample(const float *z_coarse, const float *weights, const float *u, const float *t_lin,
                     int64_t R, int Nc, int Ni, float *z_fine, float *z_std, hipStream_t s);
+int launch_ndc_rays(int H, int W, double focal, float near, const float *rays_o, const float *rays_d, int64_t n,
+                    float *out_o, float *out_d, hipStream_t s);
 int launch_make_rays(int H, int W, const double *K4, const float *c2w, const float *c2w_static,
                      int64_t pix0, int64_t n, float near, float far, int use_viewdirs, int ndc,
                      float *rays_out, hipStream_t s);

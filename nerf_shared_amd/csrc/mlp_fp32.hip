@@ -73,7 +73,12 @@ __global__ __launch_bounds__(256) void mlp_f32_kernel(MlpArgs a) {
         const int64_t ray = (int64_t)((uint32_t)p / (uint32_t)a.S);
         float v[3];
         float val;
-        if (row < a.input_ch) {
+        if (a.embedded) {
+            val = a.embedded[p * (a.input_ch + a.input_ch_views) + row];
+            const int dst = row < a.input_ch ? row : a.input_ch + a.W + (row - a.input_ch);
+            buf[0][dst * 32 + q] = val;
+            buf[1][dst * 32 + q] = val;
+        } else if (row < a.input_ch) {
             if (a.pts) {
                 v[0] = a.pts[3 * p]; v[1] = a.pts[3 * p + 1]; v[2] = a.pts[3 * p + 2];
             } else {

@@ -355,6 +355,35 @@ __global__ __launch_bounds__(256) void make_rays_kernel(RayGen g, int64_t pix0, 
     row[6] = g.near; row[7] = g.far;
 }
 
+// ---------------------------------------------------------------------------
+// utils.ndc_rays (utils.py:54-71) on explicit ray arrays; one thread per ray.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ndc_rays_kernel(float sx, float sy, float nearp, const float *ro, const float *rd,
+                                                       int64_t n, float *oo, float *od) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float o[3] = {ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]};
+    const float d[3] = {rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]};
+    const float t = -(nearp + o[2]) / d[2];
+    o[0] = o[0] + t * d[0]; o[1] = o[1] + t * d[1]; o[2] = o[2] + t * d[2];
+    oo[3 * i] = sx * o[0] / o[2];
+    oo[3 * i + 1] = sy * o[1] / o[2];
+    oo[3 * i + 2] = 1.0f + 2.0f * nearp / o[2];
+    od[3 * i] = sx * (d[0] / d[2] - o[0] / o[2]);
+    od[3 * i + 1] = sy * (d[1] / d[2] - o[1] / o[2]);
+    od[3 * i + 2] = -2.0f * nearp / o[2];
+}
+
+int launch_ndc_rays(int H, int W, double focal, float near, const float *rays_o, const float *rays_d, int64_t n,
+                    float *out_o, float *out_d, hipStream_t s) {
+    if (n <= 0) return NERF_AMD_OK;
+    const float sx = (float)(-1.0 / ((double)W / (2.0 * focal)));
+    const float sy = (float)(-1.0 / ((double)H / (2.0 * focal)));
+    hipLaunchKernelGGL(ndc_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sx, sy, near, rays_o, rays_d,
+                       n, out_o, out_d);
+    return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
+}
+
 int launch_make_rays(int H, int W, const double *K4, const float *c2w, const float *c2w_static,
                      int64_t pix0, int64_t n, float near, float far, int use_viewdirs, int ndc,
                      float *rays_out, hipStream_t s) {

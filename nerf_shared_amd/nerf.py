@@ -210,10 +210,22 @@ class NeRF(nn.Module):
         return out.reshape(list(inputs.shape[:-1]) + [out_ch])
 
     def MLP(self, x):
-        """Embedded rows [P, input_ch + input_ch_views] -> [P, 4|output_ch] (nerf.py:110-134).
-        Kept for API parity; the kernels fuse the encoding, so this entry point
-        is the one place that cannot: it is not provided."""
-        raise NotImplementedError("NeRF.MLP on pre-embedded rows is not exposed; call forward(inputs, viewdirs)")
+        """Already-embedded rows [P, input_ch + input_ch_views] -> [P, 4|output_ch]
+        (nerf.py:110-134).  Runs on the exact-fp32 kernel (the fused bf16 kernel
+        generates the encoding itself and is reached through forward())."""
+        _lib.require_device(x, "x")
+        dev = x.device
+        width = self.input_ch + self.input_ch_views
+        xe = x.detach().reshape(-1, x.shape[-1]).contiguous().float()
+        if xe.shape[-1] != width:
+            raise _lib.NerfAmdError("MLP expects %d embedded columns, got %d" % (width, xe.shape[-1]))
+        handle = self._model_handle(dev)
+        out_ch = 4 if self.use_viewdirs else self.output_ch
+        out = torch.empty(xe.shape[0], out_ch, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(lib.nerf_amd_mlp_embedded(handle, xe.data_ptr(), xe.shape[0], out.data_ptr(),
+                                                 _lib.stream_of(dev)), "nerf_amd_mlp_embedded")
+        return out.reshape(list(x.shape[:-1]) + [out_ch])
 
     def get_density(self, points, chunk=1024 * 64):
         """Raw sigma with an all-ones view direction (nerf.py:136-143)."""

@@ -76,20 +76,18 @@ def get_rays_np(H, W, K, c2w):
 
 
 def ndc_rays(H, W, focal, near, rays_o, rays_d):
-    """Forward-facing NDC warp (utils.py:54-71).  Twelve flops per ray: plain
-    device tensor arithmetic (the fused image path applies the same warp inside
-    nerf_amd_make_rays)."""
-    t = -(near + rays_o[..., 2]) / rays_d[..., 2]
-    rays_o = rays_o + t[..., None] * rays_d
-    sx = -1. / (W / (2. * focal))
-    sy = -1. / (H / (2. * focal))
-    o0 = sx * rays_o[..., 0] / rays_o[..., 2]
-    o1 = sy * rays_o[..., 1] / rays_o[..., 2]
-    o2 = 1. + 2. * near / rays_o[..., 2]
-    d0 = sx * (rays_d[..., 0] / rays_d[..., 2] - rays_o[..., 0] / rays_o[..., 2])
-    d1 = sy * (rays_d[..., 1] / rays_d[..., 2] - rays_o[..., 1] / rays_o[..., 2])
-    d2 = -2. * near / rays_o[..., 2]
-    return torch.stack([o0, o1, o2], -1), torch.stack([d0, d1, d2], -1)
+    """Forward-facing NDC warp of explicit rays (utils.py:54-71)."""
+    _lib.require_device(rays_d, "rays_d")
+    dev = rays_d.device
+    shape = rays_d.shape
+    o = rays_o.detach().expand(shape).reshape(-1, 3).contiguous().float()
+    d = rays_d.detach().reshape(-1, 3).contiguous().float()
+    oo, od = torch.empty_like(o), torch.empty_like(d)
+    with torch.cuda.device(dev):
+        _lib.check(lib.nerf_amd_ndc_rays(int(H), int(W), float(focal), float(near), o.data_ptr(), d.data_ptr(),
+                                         o.shape[0], oo.data_ptr(), od.data_ptr(), _lib.stream_of(dev)),
+                   "nerf_amd_ndc_rays")
+    return oo.reshape(shape), od.reshape(shape)
 
 
 def sample_pdf(bins, weights, N_samples, det=False, pytest=False):

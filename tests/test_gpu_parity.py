@@ -162,6 +162,21 @@ def test_nerf_forward_bf16_golden(dev, golden, tag, seed, sharpen):
         assert rel_l2(gpu_model(dev, 6, 3.0, "bf16", **wide)(pts, vd), g["wide_s1"]) < 3e-2
 
 
+def test_mlp_on_embedded_rows(dev, golden):
+    """NeRF.MLP(x) (nerf.py:110-134) on rows embedded by the HIP embedder == forward()."""
+    nerf, _, _ = amd()
+    g = golden("g2_nerf")
+    pts, vd = torch.from_numpy(g["pts"]).to(dev), torch.from_numpy(g["viewdirs"]).to(dev)
+    m = gpu_model(dev, 1, 3.0, "fp32", **VD)
+    e = m.embed_fn(pts.reshape(-1, 3))
+    ed = m.embeddirs_fn(vd[:, None].expand(pts.shape).reshape(-1, 3))
+    out = m.MLP(torch.cat([e, ed], -1))
+    assert out.shape == (256, 4)
+    close(out.reshape(32, 8, 4), g["vd_s1"], atol=1e-4, rtol=1e-4)
+    m2 = gpu_model(dev, 1, 3.0, "fp32", **NOVD)
+    close(m2.MLP(m2.embed_fn(pts.reshape(-1, 3))).reshape(32, 8, 5), g["novd_s1"], atol=1e-4, rtol=1e-4)
+
+
 def test_nerf_forward_ragged_and_large(dev, golden):
     """Point counts that are not multiples of the 256-point workgroup tile, and the
     reference's > netchunk case (70400 points, strided subset pinned by the golden)."""
