@@ -70,6 +70,32 @@ def cpu_baseline(torch, synth):
             "sample": "one %d-ray batch, 64+128 samples, torch-CPU oracle fp32, best of 2 after warm-up (%.2f s)" % (CHUNK, best)}
 
 
+def measured_traffic(kernel_tag, chunk_points):
+    """HBM bytes per launch of the field kernel from the committed rocprofv3 --pmc passes
+    (profiles/r01_pmc_summary_*.json, made by tools/pmc_summary.py: FETCH_SIZE x2 + WRITE_SIZE per
+    MI355X_MICROARCH.md), averaged over the coarse and fine launch shapes like `achieved`.
+    PMC counters cannot be read from inside the timed run; None if no summary is present."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_summary_*.json"))):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        for name, grids in d.items():
+            if kernel_tag not in name:
+                continue
+            vals = []
+            for pts in chunk_points:
+                g = grids.get(str((pts // 256) * 512))
+                if g and "hbm_bytes_per_launch" in g:
+                    vals.append(g["hbm_bytes_per_launch"]["total"])
+            if len(vals) == len(chunk_points):
+                best = (sum(vals) / len(vals), os.path.basename(path))
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,6 +181,7 @@ def main():
         kern_s = ms[cls] / 1e3
         achieved = (pts[cls] * FLOP_PER_POINT / kern_s / 1e12) if kern_s > 0 else 0.0
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3
+        traffic = measured_traffic("mlp_bf16_s16_kernel", [CHUNK * N_SAMPLES, CHUNK * (N_SAMPLES + N_IMPORTANCE)]) if cls == 1 else None
         out = {
             "metric": "rays_per_sec", "value": value, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -166,7 +193,10 @@ def main():
                        "parallelism": "ray-range shards x%d, one gather of [rays,5] to rank 0 per step" % world
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None,
+                         "frac": achieved / peak, "traffic": traffic[0] if traffic else None,
+                         "traffic_unit": "bytes per launch (HBM, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)",
+                         "traffic_source": ("profiles/" + traffic[1]) if traffic else None,
+                         "algorithmic_bytes_per_launch": CHUNK * 44 + (CHUNK * (2 * N_SAMPLES + N_IMPORTANCE) // 2) * 20,
                          "kernel": "mlp_bf16_s16_kernel" if cls == 1 else "mlp_f32_kernel",
                          "launches": int(launches[cls]),
                          "avg_launch_ms": (ms[cls] / launches[cls]) if launches[cls] else None,

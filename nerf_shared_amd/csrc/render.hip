@@ -271,16 +271,15 @@ __global__ __launch_bounds__(64 * RAYS_PER_WG) void resample_kernel(const float 
     ss = wave_sum(ss);
     if (live && lane == 0 && z_std) z_std[r] = (float)sqrt(ss / (double)Ni);
     wave_lds_sync();
-    // bitonic sort of sb[0..npad), ascending, private to this wave
+    // bitonic sort of sb[0..npad), ascending, private to this wave.  Every lane owns one
+    // compare-exchange per pass: pair t <-> elements (i, i + j), i = 2j*(t / j) + t % j.
     for (int k = 2; k <= npad; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = lane; i < npad; i += 64) {
-                const int p = i ^ j;
-                if (p > i) {
-                    const float a = sb[i], b = sb[p];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { sb[i] = b; sb[p] = a; }
-                }
+            for (int t = lane; t < (npad >> 1); t += 64) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const float a = sb[i], b = sb[i + j];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) { sb[i] = b; sb[i + j] = a; }
             }
             wave_lds_sync();
         }
