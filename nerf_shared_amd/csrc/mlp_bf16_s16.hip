@@ -65,15 +65,30 @@ __device__ __forceinline__ void tile_single(C &c, const bf16x8 *x1, f32x4 (&acc)
     });
 }
 
-template <bool RELU>
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+// bias/MFMA result -> next layer's B fragment.  ReLU is applied after the bf16 rounding, on the
+// packed halves: one packed signed-16-bit max per register (negative bf16 = negative int16);
+// round-to-nearest is monotonic and sign-symmetric, so relu(round(x)) == round(relu(x)).
+template <bool RELU, bool PKRELU = true>
 __device__ __forceinline__ bf16x8 pack_pair(const f32x4 &even, const f32x4 &odd) {
     bf16x8 y;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         float a = even[r], b = odd[r];
-        if (RELU) { a = relu_bits(a); b = relu_bits(b); }
+        if (RELU && !PKRELU) { a = relu_bits(a); b = relu_bits(b); }
         y[r] = (__bf16)a;
         y[4 + r] = (__bf16)b;
+    }
+    if (RELU && PKRELU) {
+        u32x4 v = __builtin_bit_cast(u32x4, y);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned d = v[i];
+            asm("v_pk_max_i16 %0, %1, 0" : "=v"(d) : "v"(d));
+            v[i] = d;
+        }
+        y = __builtin_bit_cast(bf16x8, v);
     }
     return y;
 }
@@ -85,8 +100,8 @@ __device__ __forceinline__ void layer16(C &c, const bf16x8 *x1, const bf16x8 *x2
         constexpr int p = p_;
         f32x4 acc[2][2];
         tile_pair<F0 + p * 2 * (K1 + K2), T0 + 2 * p, K1, K2, NB, NFRAGS>(c, x1, x2, acc);
-        y[2 * p] = pack_pair<RELU>(acc[0][0], acc[1][0]);
-        y[2 * p + 1] = pack_pair<RELU>(acc[0][1], acc[1][1]);
+        y[2 * p] = pack_pair<RELU, !(C::OPT & 1)>(acc[0][0], acc[1][0]);
+        y[2 * p + 1] = pack_pair<RELU, !(C::OPT & 1)>(acc[0][1], acc[1][1]);
     });
 }
 
@@ -272,6 +287,19 @@ using Cfg16 = Ctx<8, 16, 4, 8, 2>;
 
 int launch_mlp_bf16_s16(const MlpArgs &a, int multires, int multires_views, int use_viewdirs,
                         int n_frags_used, int n_tiles, hipStream_t s) {
+#ifdef NERF_AMD_EXPERIMENTS
+    if (use_viewdirs && multires == 10 && multires_views == 4) {
+        switch (g_variant) {
+            case 20: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 2, 0, 1, 1>>(a, n_frags_used, n_tiles, s);   // fp32 ReLU
+            case 21: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 4>>(a, n_frags_used, n_tiles, s);            // 4-deep read-ahead
+            case 22: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 4, 4>>(a, n_frags_used, n_tiles, s);            // sync 4 fragments in
+            case 23: return launch_wg16<10, 4, true, Ctx<8, 16, 6, 8, 2>>(a, n_frags_used, n_tiles, s);            // 96-KiB ring
+            case 24: return launch_wg16<10, 4, true, Ctx<8, 32, 4, 16, 4>>(a, n_frags_used, n_tiles, s);           // 32-fragment blocks
+            case 25: return launch_wg16<10, 4, true, Ctx<8, 16, 3, 0>>(a, n_frags_used, n_tiles, s);               // block-boundary sync
+            default: break;
+        }
+    }
+#endif
     if (use_viewdirs) {
         if (multires == 10 && multires_views == 4) return launch_wg16<10, 4, true, Cfg16>(a, n_frags_used, n_tiles, s);
         if (multires == 15 && multires_views == 6) return launch_wg16<15, 6, true, Cfg16>(a, n_frags_used, n_tiles, s);

@@ -33,9 +33,11 @@ __device__ __forceinline__ void static_for(F &&f) {
 //          1 = no syncs/DMA, 2 = no LDS fragment reads, 4 = no positional encoding
 //   NP     32-point column tiles per wave: every A fragment read from LDS feeds NP MFMAs
 //          (NP = 2 halves the LDS read traffic; needs one wave per SIMD for its registers)
-template <int WAVES_, int BF_, int NS_, int PHASE_, int LA_ = 0, int ABL_ = 0, int NP_ = 1>
+//   OPT    code-generation options for A/B runs: 1 = ReLU on fp32 registers (one integer max per
+//          value) instead of one packed 16-bit max per converted pair
+template <int WAVES_, int BF_, int NS_, int PHASE_, int LA_ = 0, int ABL_ = 0, int NP_ = 1, int OPT_ = 0>
 struct Ctx {
-    static constexpr int WAVES = WAVES_, BF = BF_, NS = NS_, PHASE = PHASE_, LA = LA_, ABL = ABL_, NP = NP_;
+    static constexpr int WAVES = WAVES_, BF = BF_, NS = NS_, PHASE = PHASE_, LA = LA_, ABL = ABL_, NP = NP_, OPT = OPT_;
     static constexpr int WAVES_PER_SIMD = (WAVES_ * NP_ >= 8 && NP_ == 1) ? 2 : 1;
     static_assert(LA_ == 0 || (PHASE_ > 0 && LA_ <= PHASE_ && PHASE_ + LA_ <= BF_), "read-ahead would cross an unpublished block");
     bf16x8 q[LA_ > 0 ? LA_ : 1];
