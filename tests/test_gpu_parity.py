@@ -590,3 +590,36 @@ def test_sharded_render_two_ranks_matches_single(dev, tmp_path):
     procs = [subprocess.Popen([sys.executable, str(script), str(rk), "2", port]) for rk in range(2)]
     codes = [p.wait(timeout=170) for p in procs]
     assert codes == [0, 0]
+
+
+def test_staticcam_overlap_and_batch_poses(dev, tmp_path):
+    """c2w_staticcam (render_utils.py:208-210), the opt-in two-stream chunk pipeline, and
+    render_from_batch_poses (render_utils.py:293-319)."""
+    _, render_utils, _ = amd()
+    H = W = 24
+    K = synth.lego_intrinsics(H, W)
+    c2w, c2w_s = torch.from_numpy(synth.LEGO_C2W), torch.from_numpy(synth.pose_spherical(20.0))
+    cfg = dict(BASE, N_samples=32, N_importance=32)
+    coarse_gpu, fine_gpu = gpu_model(dev, 1, 3.0, "fp32", **VD), gpu_model(dev, 11, 3.0, "fp32", **VD)
+    r = render_utils.Renderer(**cfg)
+    rgb, disp, acc, extras = r.render(H, W, K, coarse_gpu, fine_gpu, chunk=200, c2w=c2w, c2w_staticcam=c2w_s, retraw=False)
+    ref = O.render(O.RenderCfg(**cfg), H, W, K, cpu_model(1, 3.0, **VD), cpu_model(11, 3.0, **VD), chunk=200,
+                   c2w=c2w, c2w_staticcam=c2w_s, retraw=False)
+    close(extras["rgb0"], ref[3]["rgb0"], atol=2e-4)          # coarse pass: tight
+    close_frac(rgb, ref[0], atol=2e-4, frac=0.9)
+    # the static-camera image differs from the plain one (view directions come from c2w, rays from c2w_s)
+    plain = r.render(H, W, K, coarse_gpu, fine_gpu, chunk=200, c2w=c2w_s, retraw=False)[0]
+    assert not torch.equal(plain, rgb)
+    # two-stream chunk overlap: bit-identical results
+    try:
+        render_utils.Renderer.overlap_chunks = True
+        rgb2 = r.render(H, W, K, coarse_gpu, fine_gpu, chunk=100, c2w=c2w, c2w_staticcam=c2w_s, retraw=False)[0]
+    finally:
+        render_utils.Renderer.overlap_chunks = False
+    rgb1 = r.render(H, W, K, coarse_gpu, fine_gpu, chunk=100, c2w=c2w, c2w_staticcam=c2w_s, retraw=False)[0]
+    close(rgb2, rgb1, atol=0)
+    # batch of poses -> frames on disk
+    out = r.render_from_batch_poses(H, W, K, 4096, [c2w, c2w_s], coarse_gpu, fine_gpu, False, str(tmp_path / "frames"))
+    assert len(out) == 2 and out[0].shape == (H, W, 3)
+    assert len(os.listdir(tmp_path / "frames")) == 2
+    close(torch.from_numpy(out[1]), plain.cpu(), atol=0)
