@@ -135,6 +135,13 @@ int nerf_amd_raw2outputs(const float *raw, int32_t raw_ch, const float *z_vals,
                          float *rgb_map, float *disp_map, float *acc_map, float *weights,
                          float *depth_map, void *stream);
 
+/* Backward of raw2outputs with respect to raw (what autograd derives from render_utils.py:241-290):
+ * upstream gradients of the five outputs (any may be NULL) -> g_raw [R,S,raw_ch].  SURVEY.md section 8f-1. */
+int nerf_amd_raw2outputs_backward(const float *raw, int32_t raw_ch, const float *z_vals, const float *rays_d,
+                                  int32_t rays_d_stride, const float *noise, int64_t R, int32_t S, int white_bkgd,
+                                  const float *g_rgb_map, const float *g_disp_map, const float *g_acc_map,
+                                  const float *g_depth_map, const float *g_weights, float *g_raw, void *stream);
+
 /* ------------------------------------------------------------------------
  * a11  utils.sample_pdf                       utils.py:74-117
  * bins [R,n_bins], weights [R,n_bins-1], u [R,n_samples] or NULL (then

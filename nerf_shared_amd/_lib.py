@@ -20,7 +20,7 @@ EXPORTS = (
     "nerf_amd_abi_version", "nerf_amd_last_error",
     "nerf_amd_model_create", "nerf_amd_model_update", "nerf_amd_model_destroy",
     "nerf_amd_model_supports_bf16", "nerf_amd_model_out_ch", "nerf_amd_pack_bf16_host",
-    "nerf_amd_embed", "nerf_amd_nerf_forward", "nerf_amd_mlp_embedded", "nerf_amd_ndc_rays", "nerf_amd_raw2outputs", "nerf_amd_sample_pdf",
+    "nerf_amd_embed", "nerf_amd_nerf_forward", "nerf_amd_mlp_embedded", "nerf_amd_ndc_rays", "nerf_amd_raw2outputs", "nerf_amd_raw2outputs_backward", "nerf_amd_sample_pdf",
     "nerf_amd_render_rays_workspace", "nerf_amd_render_rays", "nerf_amd_make_rays",
     "nerf_amd_profile_enable", "nerf_amd_profile_collect", "nerf_amd_set_tuning",
 )
@@ -72,6 +72,9 @@ def _load():
                                       c_void_p]),
         "nerf_amd_raw2outputs": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32,
                                          c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+        "nerf_amd_raw2outputs_backward": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32,
+                                                  c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                  c_void_p]),
         "nerf_amd_sample_pdf": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
                                         c_void_p, c_void_p]),
         "nerf_amd_render_rays_workspace": (c_int64, [POINTER(RenderCfg), c_int64, c_int32]),

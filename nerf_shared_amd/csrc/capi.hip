@@ -274,6 +274,17 @@ int nerf_amd_raw2outputs(const float *raw, int32_t raw_ch, const float *z_vals, 
     return rc ? fail(rc, "composite launch failed") : NERF_AMD_OK;
 }
 
+int nerf_amd_raw2outputs_backward(const float *raw, int32_t raw_ch, const float *z_vals, const float *rays_d,
+                                  int32_t rays_d_stride, const float *noise, int64_t R, int32_t S, int white_bkgd,
+                                  const float *g_rgb_map, const float *g_disp_map, const float *g_acc_map,
+                                  const float *g_depth_map, const float *g_weights, float *g_raw, void *stream) {
+    if (R < 0 || S < 1 || raw_ch < 4 || (R > 0 && (!raw || !z_vals || !rays_d || !g_raw)))
+        return fail(NERF_AMD_EINVAL, "bad raw2outputs_backward arguments");
+    int rc = launch_composite_bwd(raw, raw_ch, z_vals, rays_d, rays_d_stride, noise, R, S, white_bkgd, g_rgb_map,
+                                  g_disp_map, g_acc_map, g_depth_map, g_weights, g_raw, static_cast<hipStream_t>(stream));
+    return rc ? fail(rc, "composite backward launch failed (S must be <= 2048)") : NERF_AMD_OK;
+}
+
 int nerf_amd_sample_pdf(const float *bins, const float *weights, const float *u, const float *t_lin,
                         int64_t R, int32_t n_bins, int32_t n_samples, float *samples, void *stream) {
     if (R < 0 || n_bins < 2 || n_samples < 0 || (R > 0 && (!bins || !weights || !samples || (!u && !t_lin))))

@@ -60,6 +60,9 @@ int launch_coarse_z(const float *rays, int ray_stride, const float *t_vals, cons
 int launch_composite(const float *raw, int raw_ch, const float *z, const float *rays_d, int rays_d_stride,
                      const float *noise, int64_t R, int S, int white_bkgd, float *rgb, float *disp, float *acc,
                      float *weights, float *depth, hipStream_t s);
+int launch_composite_bwd(const float *raw, int raw_ch, const float *z, const float *rays_d, int rays_d_stride,
+                         const float *noise, int64_t R, int S, int white_bkgd, const float *g_rgb, const float *g_disp,
+                         const float *g_acc, const float *g_depth, const float *g_weights, float *g_raw, hipStream_t s);
 int launch_sample_pdf(const float *bins, const float *weights, const float *u, const float *t_lin,
                       int64_t R, int n_bins, int n_samples, float *samples, hipStream_t s);
 int launch_resample(const float *z_coarse, const float *weights, const float *u, const float *t_lin,

@@ -161,6 +161,126 @@ int launch_composite(const float *raw, int raw_ch, const float *z, const float *
 }
 
 // ---------------------------------------------------------------------------
+// Backward of raw2outputs (render_utils.py:241-290) with respect to raw: what
+// torch.autograd produces for the reference's expression graph.  With
+//   w_s = a_s T_s,  T_s = prod_{j<s}(1 - a_j + 1e-10),  a_s = 1 - exp(-relu(sigma_s + n_s) d_s),
+//   rgb = sum w c + white (1 - sum w),  acc = sum w,  depth = sum w z,  disp = 1 / max(1e-10, depth / acc)
+// and v_s = dL/dw_s (direct dependence only), u_s = v_s w_s:
+//   dL/dsigma_s = d_s [sigma_s + n_s > 0] (1 - a_s) ( v_s T_s - (sum_{k>s} u_k) / (1 - a_s + 1e-10) )
+//   dL/draw_rgb = g_rgb w_s c (1 - c)
+// One wave per ray; a, T, w live in this wave's LDS slice between the two sweeps.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double wave_suffix_excl_sum(double v, int lane) {
+    double incl = v;                       // inclusive suffix sum: lanes lane..63
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        double o = __shfl_down(incl, d);
+        if (lane + d < 64) incl += o;
+    }
+    return incl - v;
+}
+
+__global__ __launch_bounds__(64 * RAYS_PER_WG) void composite_bwd_kernel(
+    const float *raw, int raw_ch, const float *z, const float *rays_d, int rays_d_stride, const float *noise,
+    int64_t R, int S, int white_bkgd, const float *g_rgb, const float *g_disp, const float *g_acc,
+    const float *g_depth, const float *g_weights, float *g_raw) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * RAYS_PER_WG + wv;
+    if (r >= R) return;
+    float *sa = lds + wv * 3 * S, *sT = sa + S, *sw = sT + S;
+    const float *d = rays_d + r * rays_d_stride;
+    const float dnorm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    const float *zr = z + r * S;
+    // ---- sweep 1: alpha, transmittance, weights; acc and depth totals
+    double carry = 1.0;
+    float sacc = 0.f, sdepth = 0.f;
+    for (int s0 = 0; s0 < S; s0 += 64) {
+        const int s = s0 + lane;
+        const bool in = s < S;
+        float alpha = 0.f, w = 0.f, zc = 0.f;
+        double term = 1.0;
+        if (in) {
+            zc = zr[s];
+            float dist = (s + 1 < S) ? zr[s + 1] - zc : 1e10f;
+            dist = dist * dnorm;
+            float sigma = raw[(r * S + s) * raw_ch + 3];
+            if (noise) sigma = sigma + noise[r * S + s];
+            sigma = fmaxf(sigma, 0.0f);
+            alpha = 1.0f - expf(-sigma * dist);
+            term = (double)(1.0f - alpha + 1e-10f);
+        }
+        const double incl = wave_incl_prod(term, lane);
+        double excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = 1.0;
+        const float T = (float)(carry * excl);
+        carry = carry * __shfl(incl, 63);
+        if (in) {
+            w = alpha * T;
+            sa[s] = alpha; sT[s] = T; sw[s] = w;
+        }
+        sacc += w; sdepth += w * zc;
+    }
+    sacc = wave_sum(sacc); sdepth = wave_sum(sdepth);
+    wave_lds_sync();
+    // ---- upstream gradients of the per-ray scalars
+    const float gr = g_rgb ? g_rgb[3 * r] : 0.f, gg = g_rgb ? g_rgb[3 * r + 1] : 0.f, gb = g_rgb ? g_rgb[3 * r + 2] : 0.f;
+    float gacc = g_acc ? g_acc[r] : 0.f, gdep = g_depth ? g_depth[r] : 0.f;
+    if (g_disp) {
+        const float q = sdepth / sacc;
+        const float m = (q != q) ? q : (q > 1e-10f ? q : 1e-10f);
+        const float gq = (q > 1e-10f || q != q) ? -g_disp[r] / (m * m) : 0.0f;   // d(1/max(1e-10, q))/dq
+        gdep += gq / sacc;
+        gacc += -gq * sdepth / (sacc * sacc);
+    }
+    if (white_bkgd) gacc -= gr + gg + gb;
+    // ---- sweep 2, last chunk first: suffix sums of u = v w
+    double tail = 0.0;                     // sum of u over all later chunks
+    for (int s0 = ((S - 1) / 64) * 64; s0 >= 0; s0 -= 64) {
+        const int s = s0 + lane;
+        const bool in = s < S;
+        float v = 0.f, w = 0.f, a = 0.f, T = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, sig = 0.f, dist = 0.f;
+        if (in) {
+            const float *qv = raw + (r * S + s) * raw_ch;
+            cr = 1.0f / (1.0f + expf(-qv[0]));
+            cg = 1.0f / (1.0f + expf(-qv[1]));
+            cb = 1.0f / (1.0f + expf(-qv[2]));
+            sig = qv[3];
+            if (noise) sig = sig + noise[r * S + s];
+            const float zc = zr[s];
+            dist = ((s + 1 < S) ? zr[s + 1] - zc : 1e10f) * dnorm;
+            a = sa[s]; T = sT[s]; w = sw[s];
+            v = gr * cr + gg * cg + gb * cb + gacc + gdep * zc;
+            if (g_weights) v += g_weights[r * S + s];
+        }
+        const double u = (double)v * (double)w;
+        const double later = wave_suffix_excl_sum(u, lane) + tail;
+        tail += wave_sum(u);
+        if (in) {
+            float *o = g_raw + (r * S + s) * raw_ch;
+            o[0] = gr * w * cr * (1.0f - cr);
+            o[1] = gg * w * cg * (1.0f - cg);
+            o[2] = gb * w * cb * (1.0f - cb);
+            const float oma = 1.0f - a;
+            o[3] = sig > 0.0f ? dist * oma * (v * T - (float)later / (oma + 1e-10f)) : 0.0f;
+            for (int c = 4; c < raw_ch; ++c) o[c] = 0.0f;
+        }
+    }
+}
+
+int launch_composite_bwd(const float *raw, int raw_ch, const float *z, const float *rays_d, int rays_d_stride,
+                         const float *noise, int64_t R, int S, int white_bkgd, const float *g_rgb, const float *g_disp,
+                         const float *g_acc, const float *g_depth, const float *g_weights, float *g_raw, hipStream_t s) {
+    if (R <= 0) return NERF_AMD_OK;
+    if (S < 1 || S > 2048 || raw_ch < 4) return NERF_AMD_EINVAL;
+    const int64_t blocks = (R + RAYS_PER_WG - 1) / RAYS_PER_WG;
+    const size_t lds = (size_t)RAYS_PER_WG * 3 * S * sizeof(float);
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)blocks), dim3(64 * RAYS_PER_WG), lds, s, raw, raw_ch, z,
+                       rays_d, rays_d_stride, noise, R, S, white_bkgd, g_rgb, g_disp, g_acc, g_depth, g_weights, g_raw);
+    return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
+}
+
+// ---------------------------------------------------------------------------
 // sample_pdf: utils.py:74-117.  cdf (fp64 running sum rounded to fp32 per bin,
 // like ATen's CPU cumsum) and bins of one ray live in this wave's LDS slice.
 // ---------------------------------------------------------------------------

@@ -69,6 +69,43 @@ def _pytest_uniform(shape, device):
     return torch.Tensor(np.random.rand(*list(shape))).to(device)
 
 
+class _Raw2OutputsFn(torch.autograd.Function):
+    """raw2outputs with a HIP backward with respect to ``raw`` (nerf_amd_raw2outputs_backward).
+    z_vals and rays_d are treated as constants (ray gradients come later)."""
+
+    @staticmethod
+    def forward(ctx, raw, z, d, noise, white):
+        dev = raw.device
+        R, S, ch = raw.shape
+        f = dict(device=dev, dtype=torch.float32)
+        rgb_map, disp_map, acc_map = torch.empty(R, 3, **f), torch.empty(R, **f), torch.empty(R, **f)
+        weights, depth_map = torch.empty(R, S, **f), torch.empty(R, **f)
+        with torch.cuda.device(dev):
+            _lib.check(lib.nerf_amd_raw2outputs(raw.data_ptr(), ch, z.data_ptr(), d.data_ptr(), d.stride(0), _lib.ptr(noise),
+                                                R, S, int(white), rgb_map.data_ptr(), disp_map.data_ptr(),
+                                                acc_map.data_ptr(), weights.data_ptr(), depth_map.data_ptr(),
+                                                _lib.stream_of(dev)), "nerf_amd_raw2outputs")
+        ctx.save_for_backward(raw, z, d, noise if noise is not None else torch.empty(0, device=dev))
+        ctx.white = white
+        ctx.set_materialize_grads(False)
+        return rgb_map, disp_map, acc_map, weights, depth_map
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_disp, g_acc, g_w, g_depth):
+        raw, z, d, noise = ctx.saved_tensors
+        noise = noise if noise.numel() else None
+        R, S, ch = raw.shape
+        g = [None if t is None else t.contiguous().float() for t in (g_rgb, g_disp, g_acc, g_depth, g_w)]
+        g_raw = torch.empty_like(raw)
+        with torch.cuda.device(raw.device):
+            _lib.check(lib.nerf_amd_raw2outputs_backward(raw.data_ptr(), ch, z.data_ptr(), d.data_ptr(), d.stride(0),
+                                                         _lib.ptr(noise), R, S, int(ctx.white), _lib.ptr(g[0]),
+                                                         _lib.ptr(g[1]), _lib.ptr(g[2]), _lib.ptr(g[3]), _lib.ptr(g[4]),
+                                                         g_raw.data_ptr(), _lib.stream_of(raw.device)),
+                       "nerf_amd_raw2outputs_backward")
+        return g_raw, None, None, None, None
+
+
 class Renderer(torch.nn.Module):
     def __init__(self, perturb=True, N_importance=128, N_samples=64, use_viewdirs=True,
                  white_bkgd=True, raw_noise_std=0.0, ndc=False, lindisp=False,
@@ -301,7 +338,8 @@ class Renderer(torch.nn.Module):
 
     def raw2outputs(self, raw, z_vals, rays_d, pytest=False):
         """raw [R,S,>=4], z_vals [R,S], rays_d [R,3] -> rgb_map, disp_map, acc_map,
-        weights, depth_map (render_utils.py:241-290)."""
+        weights, depth_map (render_utils.py:241-290).  Differentiable with respect to
+        ``raw`` (HIP backward kernel); z_vals and rays_d are constants."""
         _lib.require_device(raw, "raw")
         dev = raw.device
         raw_c = raw.detach().contiguous().float()
@@ -313,15 +351,10 @@ class Renderer(torch.nn.Module):
         noise = None
         if self.raw_noise_std > 0.:
             noise = (_pytest_uniform([R, S], dev) if pytest else torch.randn([R, S], device=dev)) * self.raw_noise_std
-        f = dict(device=dev, dtype=torch.float32)
-        rgb_map, disp_map, acc_map = torch.empty(R, 3, **f), torch.empty(R, **f), torch.empty(R, **f)
-        weights, depth_map = torch.empty(R, S, **f), torch.empty(R, **f)
-        with torch.cuda.device(dev):
-            _lib.check(lib.nerf_amd_raw2outputs(raw_c.data_ptr(), ch, z.data_ptr(), d.data_ptr(), 3, _lib.ptr(noise),
-                                                R, S, int(bool(self.white_bkgd)), rgb_map.data_ptr(),
-                                                disp_map.data_ptr(), acc_map.data_ptr(), weights.data_ptr(),
-                                                depth_map.data_ptr(), _lib.stream_of(dev)), "nerf_amd_raw2outputs")
-        return rgb_map, disp_map, acc_map, weights, depth_map
+        if torch.is_grad_enabled() and raw.requires_grad:
+            return _Raw2OutputsFn.apply(raw.contiguous().float(), z, d, noise, bool(self.white_bkgd))
+        with torch.no_grad():
+            return _Raw2OutputsFn.apply(raw_c, z, d, noise, bool(self.white_bkgd))
 
     def render_from_batch_poses(self, H, W, K, chunk, batch_c2w, coarse_model, fine_model,
                                 retraw, save_directory, b_combine_as_video=False, tb_writer=None):
