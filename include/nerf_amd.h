@@ -143,6 +143,25 @@ int nerf_amd_raw2outputs_backward(const float *raw, int32_t raw_ch, const float 
                                   const float *g_depth_map, const float *g_weights, float *g_raw, void *stream);
 
 /* ------------------------------------------------------------------------
+ * Training (what loss.backward() does through NeRF.forward, main.py:85-104).
+ * Covered: the D=8, W=256, skips=[4], multires 10/4 view-branch model, parameter gradients
+ * (the encodings are constants: no ray gradients yet), bf16 operands / fp32 accumulation.
+ *   forward_train : the fused bf16 forward (explicit pts + viewdirs, or rays + z_vals with pts = o + d z) that also saves every
+ *                   layer's activations in `workspace` (nerf_amd_train_workspace bytes, 256-B aligned)
+ *   backward      : dL/draw [P,4] -> gradients of every nn.Linear weight [out,in] and bias [out]
+ *                   (fp32 device tensors in nerf_amd_model_update order, overwritten)
+ * ------------------------------------------------------------------------ */
+int     nerf_amd_model_supports_training(const nerf_amd_model *m);
+int64_t nerf_amd_train_workspace(const nerf_amd_model *m, int64_t n_points);
+int     nerf_amd_field_forward_train(const nerf_amd_model *m, const float *pts /* [R*S,3] or NULL */,
+                                     const float *viewdirs /* [R,3], with pts */, const float *rays /* [R,11], without pts */,
+                                     int32_t ray_ch, const float *z_vals, int64_t R, int32_t S, float *raw,
+                                     void *workspace, int64_t workspace_bytes, void *stream);
+int     nerf_amd_field_backward(const nerf_amd_model *m, const float *g_raw, int64_t n_points, void *workspace,
+                                int64_t workspace_bytes, float *const *grad_weights, float *const *grad_biases,
+                                int n_tensors, void *stream);
+
+/* ------------------------------------------------------------------------
  * a11  utils.sample_pdf                       utils.py:74-117
  * bins [R,n_bins], weights [R,n_bins-1], u [R,n_samples] or NULL (then
  * u = t_lin[n_samples], the caller's torch.linspace(0,1,n_samples), det=True).
@@ -157,6 +176,15 @@ int nerf_amd_sample_pdf(const float *bins, const float *weights, const float *u,
  *   z_vals (lin / lindisp, optional stratified jitter) -> coarse field ->
  *   composite -> sample_pdf -> sort(cat) -> fine field -> composite.
  * ------------------------------------------------------------------------ */
+/* The two per-ray stages of render_rays that have no Python-level counterpart of their own, exported
+ * for the training path (which runs render_rays stage by stage so autograd can cut in):
+ *   coarse_z : z_vals of the coarse pass, lin / lindisp + stratified jitter   render_utils.py:105-129
+ *   resample : z_mid -> sample_pdf(weights[1:-1]) -> z_std -> sort(cat)       render_utils.py:140-148,168 */
+int nerf_amd_coarse_z(const float *rays, int32_t ray_ch, const float *t_vals, const float *t_rand, int64_t R,
+                      int32_t N_samples, int lindisp, int perturb, float *z_vals, void *stream);
+int nerf_amd_resample(const float *z_coarse, const float *weights, const float *u, const float *t_lin, int64_t R,
+                      int32_t N_samples, int32_t N_importance, float *z_fine, float *z_std, void *stream);
+
 typedef struct nerf_amd_render_cfg {
     int32_t N_samples;
     int32_t N_importance;

@@ -23,6 +23,8 @@ EXPORTS = (
     "nerf_amd_embed", "nerf_amd_nerf_forward", "nerf_amd_mlp_embedded", "nerf_amd_ndc_rays", "nerf_amd_raw2outputs", "nerf_amd_raw2outputs_backward", "nerf_amd_sample_pdf",
     "nerf_amd_render_rays_workspace", "nerf_amd_render_rays", "nerf_amd_make_rays",
     "nerf_amd_profile_enable", "nerf_amd_profile_collect", "nerf_amd_set_tuning",
+    "nerf_amd_model_supports_training", "nerf_amd_train_workspace", "nerf_amd_field_forward_train",
+    "nerf_amd_field_backward", "nerf_amd_coarse_z", "nerf_amd_resample",
 )
 
 
@@ -82,6 +84,14 @@ def _load():
         "nerf_amd_make_rays": (c_int, [c_int32, c_int32, POINTER(c_double), POINTER(c_float), POINTER(c_float),
                                        c_int64, c_int64, c_float, c_float, c_int, c_int, c_void_p, c_void_p]),
         "nerf_amd_set_tuning": (c_int, [c_int, c_int]),
+        "nerf_amd_coarse_z": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_int, c_int, c_void_p, c_void_p]),
+        "nerf_amd_resample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p,
+                                      c_void_p]),
+        "nerf_amd_model_supports_training": (c_int, [c_void_p]),
+        "nerf_amd_train_workspace": (c_int64, [c_void_p, c_int64]),
+        "nerf_amd_field_forward_train": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32,
+                                                 c_void_p, c_void_p, c_int64, c_void_p]),
+        "nerf_amd_field_backward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, pp_f, pp_f, c_int, c_void_p]),
         "nerf_amd_profile_enable": (c_int, [c_int]),
         "nerf_amd_profile_collect": (c_int, [POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),
     }

@@ -57,7 +57,8 @@ struct nerf_amd_model {
     TensorDesc *d_tensors = nullptr;
     const float **d_wptrs = nullptr, **d_bptrs = nullptr;
     std::vector<const float *> h_wptrs, h_bptrs;
-    uint16_t *stream_bf16 = nullptr, *stream_s16 = nullptr;
+    uint16_t *stream_bf16 = nullptr, *stream_s16 = nullptr, *stream_bwd = nullptr;
+    FragDesc *d_frags_bwd = nullptr;
     float *bias_bf16 = nullptr, *stream_f32 = nullptr, *bias_f32 = nullptr, *bias_s16 = nullptr;
     FragDesc *d_frags16 = nullptr;
     TileDesc *d_tiles16 = nullptr;
@@ -85,6 +86,7 @@ int nerf_amd_model_create(const nerf_amd_arch *arch, int device, nerf_amd_model 
     int rc;
     if ((rc = upload(&m->d_frags, p.frags)) || (rc = upload(&m->d_tiles, p.tiles)) ||
         (rc = upload(&m->d_frags16, p.frags16)) || (rc = upload(&m->d_tiles16, p.tiles16)) ||
+        (rc = upload(&m->d_frags_bwd, p.frags_bwd)) ||
         (rc = upload(&m->d_layers, p.layers)) || (rc = upload(&m->d_tensors, p.tensors))) {
         nerf_amd_model_destroy(m);
         return rc;
@@ -97,6 +99,8 @@ int nerf_amd_model_create(const nerf_amd_arch *arch, int device, nerf_amd_model 
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->bias_bf16), p.tiles.size() * 32 * sizeof(float));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->stream_s16), p.frags16.size() * 1024);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->bias_s16), p.tiles16.size() * 16 * sizeof(float));
+        if (e == hipSuccess && !p.frags_bwd.empty())
+            e = hipMalloc(reinterpret_cast<void **>(&m->stream_bwd), p.frags_bwd.size() * 1024);
     }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->stream_f32), (size_t)p.f32_stream_floats * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->bias_f32), (size_t)p.f32_bias_floats * sizeof(float));
@@ -123,7 +127,7 @@ int nerf_amd_model_update(nerf_amd_model *m, const float *const *weights, const 
     HIP_TRY(hipMemcpyAsync(m->d_bptrs, m->h_bptrs.data(), n_tensors * sizeof(float *), hipMemcpyHostToDevice, s));
     int rc = launch_pack(p, m->d_frags, m->d_tiles, m->d_layers, m->d_tensors, m->d_wptrs, m->d_bptrs,
                          m->stream_bf16, m->bias_bf16, m->stream_f32, m->bias_f32,
-                         m->d_frags16, m->d_tiles16, m->stream_s16, m->bias_s16, s);
+                         m->d_frags16, m->d_tiles16, m->stream_s16, m->bias_s16, m->d_frags_bwd, m->stream_bwd, s);
     if (rc) return fail(rc, "pack launch failed");
     m->packed = true;
     return NERF_AMD_OK;
@@ -133,6 +137,7 @@ void nerf_amd_model_destroy(nerf_amd_model *m) {
     if (!m) return;
     (void)hipFree(m->d_frags); (void)hipFree(m->d_tiles); (void)hipFree(m->d_layers); (void)hipFree(m->d_tensors);
     (void)hipFree(m->d_wptrs); (void)hipFree(m->d_bptrs);
+    (void)hipFree(m->d_frags_bwd); (void)hipFree(m->stream_bwd);
     (void)hipFree(m->d_frags16); (void)hipFree(m->d_tiles16); (void)hipFree(m->stream_s16); (void)hipFree(m->bias_s16);
     (void)hipFree(m->stream_bf16); (void)hipFree(m->bias_bf16); (void)hipFree(m->stream_f32); (void)hipFree(m->bias_f32);
     delete m;
@@ -147,14 +152,15 @@ int nerf_amd_model_out_ch(const nerf_amd_model *m) { return m ? m->prog.out_ch :
 
 int nerf_amd_pack_bf16_host(const nerf_amd_arch *arch, int shape, const float *const *weights, const float *const *biases,
                             int n_tensors, uint16_t *stream_out, int64_t *n_frags, float *bias_out, int64_t *n_bias) {
-    if (shape != 16 && shape != 32) return fail(NERF_AMD_EINVAL, "shape must be 32 (32x32x16 stream) or 16 (16x16x32 stream)");
+    if (shape != 16 && shape != 32 && shape != 17)
+        return fail(NERF_AMD_EINVAL, "shape must be 32 (32x32x16 stream), 16 (16x16x32 stream) or 17 (backward stream)");
     if (!arch) return fail(NERF_AMD_EINVAL, "null argument");
     Program p;
     const char *err = "";
     if (build_program(*arch, p, &err) != 0) return fail(NERF_AMD_EINVAL, err);
     if (!p.bf16_ok) return fail(NERF_AMD_EUNSUPPORTED, "architecture has no fused bf16 program (needs D=8, W=256, skips=[4])");
-    if (n_frags) *n_frags = (int64_t)(shape == 16 ? p.frags16.size() : p.frags.size());
-    if (n_bias) *n_bias = shape == 16 ? (int64_t)p.tiles16.size() * 16 : (int64_t)p.tiles.size() * 32;
+    if (n_frags) *n_frags = (int64_t)(shape == 17 ? p.frags_bwd.size() : shape == 16 ? p.frags16.size() : p.frags.size());
+    if (n_bias) *n_bias = shape == 17 ? 0 : shape == 16 ? (int64_t)p.tiles16.size() * 16 : (int64_t)p.tiles.size() * 32;
     if (stream_out || bias_out) {
         if (!weights || !biases || n_tensors != (int)p.tensors.size()) return fail(NERF_AMD_EINVAL, "bad parameter list");
         pack_bf16_host(p, shape, weights, biases, stream_out, bias_out);
@@ -264,6 +270,56 @@ int nerf_amd_ndc_rays(int32_t H, int32_t W, double focal, float near, const floa
     return rc ? fail(rc, "ndc_rays launch failed") : NERF_AMD_OK;
 }
 
+int nerf_amd_model_supports_training(const nerf_amd_model *m) { return m && train_supported(m->prog) ? 1 : 0; }
+
+int64_t nerf_amd_train_workspace(const nerf_amd_model *m, int64_t n_points) {
+    if (!m || n_points < 0 || !train_supported(m->prog)) return -1;
+    return train_workspace_bytes(m->prog, n_points);
+}
+
+int nerf_amd_field_forward_train(const nerf_amd_model *m, const float *pts, const float *viewdirs, const float *rays,
+                                 int32_t ray_ch, const float *z_vals, int64_t R, int32_t S, float *raw, void *workspace,
+                                 int64_t workspace_bytes, void *stream) {
+    if (!m || R < 0 || S < 1) return fail(NERF_AMD_EINVAL, "bad forward_train arguments");
+    if (!pts && ray_ch != 11) return fail(NERF_AMD_EINVAL, "rays must be [R,11]");
+    if (pts && !viewdirs) return fail(NERF_AMD_EINVAL, "pts mode needs viewdirs [R,3]");
+    if (!train_supported(m->prog)) return fail(NERF_AMD_EUNSUPPORTED, "training kernels cover the D=8, W=256, skips=[4], multires 10/4 view-branch model");
+    if (!m->packed) return fail(NERF_AMD_EINVAL, "model has no parameters yet");
+    if (R == 0) return NERF_AMD_OK;
+    const int64_t P = R * S;
+    if ((!pts && (!rays || !z_vals)) || !raw || !workspace || workspace_bytes < train_workspace_bytes(m->prog, P))
+        return fail(NERF_AMD_EINVAL, "null pointer or workspace too small");
+    MlpArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.stream_s16 = m->stream_s16; a.bias_s16 = m->bias_s16;
+    if (pts) { a.pts = pts; a.viewdirs = viewdirs; a.vd_stride = 3; }
+    else { a.rays = rays; a.ray_stride = ray_ch; a.z_vals = z_vals; a.viewdirs = rays + 8; a.vd_stride = ray_ch; }
+    a.P = P; a.S = S; a.out = raw; a.out_ch = 4;
+    train_fill_args(m->prog, P, workspace, &a);
+    int rc = launch_mlp_bf16_s16_save(a, m->prog.n_frags16_used, (int)m->prog.tiles16.size(), static_cast<hipStream_t>(stream));
+    return rc ? fail(rc, "training forward launch failed") : NERF_AMD_OK;
+}
+
+int nerf_amd_field_backward(const nerf_amd_model *m, const float *g_raw, int64_t n_points, void *workspace,
+                            int64_t workspace_bytes, float *const *grad_weights, float *const *grad_biases,
+                            int n_tensors, void *stream) {
+    if (!m || n_points < 0 || !grad_weights || !grad_biases) return fail(NERF_AMD_EINVAL, "bad backward arguments");
+    if (!train_supported(m->prog)) return fail(NERF_AMD_EUNSUPPORTED, "training kernels cover the D=8, W=256, skips=[4], multires 10/4 view-branch model");
+    if (n_tensors != (int)m->prog.tensors.size()) return fail(NERF_AMD_EINVAL, "wrong number of gradient tensors");
+    if (n_points == 0) return NERF_AMD_OK;
+    if (!g_raw || !workspace || workspace_bytes < train_workspace_bytes(m->prog, n_points))
+        return fail(NERF_AMD_EINVAL, "null pointer or workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    MlpArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.stream_bwd = m->stream_bwd; a.g_raw = g_raw; a.P = n_points;
+    train_fill_args(m->prog, n_points, workspace, &a);
+    int rc = launch_mlp_bwd_s16(a, m->prog.n_frags_bwd_used, s);
+    if (rc) return fail(rc, "backward kernel launch failed");
+    rc = train_param_grads(m->prog, n_points, workspace, grad_weights, grad_biases, s);
+    return rc ? fail(rc, "weight-gradient GEMMs failed") : NERF_AMD_OK;
+}
+
 int nerf_amd_raw2outputs(const float *raw, int32_t raw_ch, const float *z_vals, const float *rays_d,
                          int32_t rays_d_stride, const float *noise, int64_t R, int32_t S, int white_bkgd,
                          float *rgb_map, float *disp_map, float *acc_map, float *weights, float *depth_map,
@@ -291,6 +347,24 @@ int nerf_amd_sample_pdf(const float *bins, const float *weights, const float *u,
         return fail(NERF_AMD_EINVAL, "bad sample_pdf arguments");
     int rc = launch_sample_pdf(bins, weights, u, t_lin, R, n_bins, n_samples, samples, static_cast<hipStream_t>(stream));
     return rc ? fail(rc, "sample_pdf launch failed (n_bins must be <= 4096)") : NERF_AMD_OK;
+}
+
+int nerf_amd_coarse_z(const float *rays, int32_t ray_ch, const float *t_vals, const float *t_rand, int64_t R,
+                      int32_t N_samples, int lindisp, int perturb, float *z_vals, void *stream) {
+    if (R < 0 || N_samples < 1 || ray_ch < 8 || (R > 0 && (!rays || !t_vals || !z_vals || (perturb && !t_rand))))
+        return fail(NERF_AMD_EINVAL, "bad coarse_z arguments");
+    int rc = launch_coarse_z(rays, ray_ch, t_vals, perturb ? t_rand : nullptr, R, N_samples, lindisp, perturb, z_vals,
+                             static_cast<hipStream_t>(stream));
+    return rc ? fail(rc, "coarse_z launch failed") : NERF_AMD_OK;
+}
+
+int nerf_amd_resample(const float *z_coarse, const float *weights, const float *u, const float *t_lin, int64_t R,
+                      int32_t N_samples, int32_t N_importance, float *z_fine, float *z_std, void *stream) {
+    if (R < 0 || N_samples < 3 || N_importance < 1 || (R > 0 && (!z_coarse || !weights || !z_fine || (!u && !t_lin))))
+        return fail(NERF_AMD_EINVAL, "bad resample arguments");
+    int rc = launch_resample(z_coarse, weights, u, t_lin, R, N_samples, N_importance, z_fine, z_std,
+                             static_cast<hipStream_t>(stream));
+    return rc ? fail(rc, "resample launch failed (N_samples + N_importance must be <= 4096)") : NERF_AMD_OK;
 }
 
 int64_t nerf_amd_render_rays_workspace(const nerf_amd_render_cfg *cfg, int64_t R, int32_t out_ch) {

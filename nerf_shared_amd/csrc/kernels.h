@@ -32,6 +32,21 @@ struct MlpArgs {
     int32_t S;                     // samples per ray (ray index = p / S)
     int32_t out_ch;
     float *out;                    // [P, out_ch]
+    // training: activations saved by the forward for the backward pass, bf16, one row per point in
+    // the k-slot order of the fragments ("slot-major": position 32*ks + 8*q + j of a row holds the
+    // feature that slot (ks, q, j) of the B fragment holds; program.h acc16_col / gen16_col)
+    uint16_t *sv_e;                // [P, 32*KE16]  encoded xyz
+    uint16_t *sv_d;                // [P, 32*KD16]  encoded view direction
+    uint16_t *sv_h;                // [8][P, 256]   outputs of pts_linears.0..7 (post-ReLU)
+    uint16_t *sv_feat;             // [P, 256]      feature_linear output
+    uint16_t *sv_hv;               // [P, 128]      views_linears.0 output (post-ReLU)
+    // backward inputs / outputs
+    const float *g_raw;            // [P, 4] dL/draw
+    uint16_t *g_rawb;              // [P, 4] bf16 copy of g_raw (GEMM operand)
+    uint16_t *g_hv;                // [P, 128] dL/d(pre-activation) of views_linears.0, slot-major
+    uint16_t *g_feat;              // [P, 256]
+    uint16_t *g_h;                 // [8][P, 256]  dL/d(pre-activation) of pts_linears.0..7
+    const uint16_t *stream_bwd;    // transposed-weight fragment stream
 };
 
 extern int g_variant;
@@ -46,10 +61,18 @@ int launch_pack(const Program &p, const FragDesc *d_frags, const TileDesc *d_til
                 const TensorDesc *d_tensors, const float *const *d_weight_ptrs, const float *const *d_bias_ptrs,
                 uint16_t *stream_bf16, float *bias_bf16, float *stream_f32, float *bias_f32,
                 const FragDesc *d_frags16, const TileDesc *d_tiles16, uint16_t *stream_s16, float *bias_s16,
-                hipStream_t s);
+                const FragDesc *d_frags_bwd, uint16_t *stream_bwd, hipStream_t s);
 void pack_bf16_host(const Program &p, int shape, const float *const *w, const float *const *b, uint16_t *stream, float *bias);
 int launch_mlp_bf16_s16(const MlpArgs &a, int multires, int multires_views, int use_viewdirs,
                         int n_frags_used, int n_tiles, hipStream_t s);
+int launch_mlp_bf16_s16_save(const MlpArgs &a, int n_frags_used, int n_tiles, hipStream_t s);   // (10,4) view-branch model
+int launch_mlp_bwd_s16(const MlpArgs &a, int n_frags_used, hipStream_t s);
+
+// backward.hip
+bool train_supported(const Program &p);
+int64_t train_workspace_bytes(const Program &p, int64_t P);
+void train_fill_args(const Program &p, int64_t P, void *workspace, MlpArgs *a);
+int train_param_grads(const Program &p, int64_t P, void *workspace, float *const *gw, float *const *gb, hipStream_t s);
 
 // render.hip
 struct RenderCfgK {

@@ -150,6 +150,19 @@ __device__ __forceinline__ void encode16(float x0, float x1, float x2, int h, in
         for (int j = 0; j < 8; ++j) out[k * STRIDE][j] = (__bf16)vals[8 * k + j];
 }
 
+// Save NK k-steps of fragments (y[2*ks + cc]) as slot-major bf16 rows of ROW elements.
+template <int NK, int ROW>
+__device__ __forceinline__ void save_frags(uint16_t *base, const bf16x8 *y, const int64_t (&pidx)[2],
+                                           const bool (&valid)[2], int q) {
+    static_for<NK>([&](auto k_) {
+        constexpr int k = k_;
+        static_for<2>([&](auto cc_) {
+            constexpr int cc = cc_;
+            if (valid[cc]) *reinterpret_cast<bf16x8 *>(base + pidx[cc] * ROW + k * 32 + q * 8) = y[2 * k + cc];
+        });
+    });
+}
+
 template <int LX, int LD, bool VD>
 struct Layout16 {
     static constexpr int KE = gen16_ksteps(LX);
@@ -167,7 +180,7 @@ struct Layout16 {
     static constexpr int N_TILES = VD ? 128 + 16 + 1 + 8 + 1 : 128 + 1;
 };
 
-template <int LX, int LD, bool VD, class C>
+template <int LX, int LD, bool VD, class C, bool SAVE = false>
 __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16_kernel(MlpArgs a) {
     constexpr int WG_THREADS = C::WAVES * 64, WG_POINTS = C::WAVES * 32;
     using Lay = Layout16<LX, LD, VD>;
@@ -223,21 +236,38 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16_kernel(MlpArgs 
         block_sync<-1, NB>(c);                                 // publishes block 0
         static_for<C::LA>([&](auto i_) { constexpr int i = i_; c.q[i] = ring_frag<i>(c); });
     }
+    // training forward: every layer's output also goes to HBM for the backward pass.  (These stores
+    // sit in the same vmcnt queue as the ring DMA, so the counted waits become conservative.)
+    const int64_t HS = a.P * 256;                               // one saved hidden layer
+    if constexpr (SAVE) {
+        save_frags<KE, 32 * KE>(a.sv_e, E, pidx, valid, q);
+        if constexpr (VD) save_frags<KD, 32 * KD>(a.sv_d, Dv, pidx, valid, q);
+    }
     bf16x8 A[16], B[16];
     layer16<Lay::F_L0, 0, 8, KE, 0, true, NB, NF>(c, E, E, A);
+    if constexpr (SAVE) save_frags<8, 256>(a.sv_h + 0 * HS, A, pidx, valid, q);
     layer16<Lay::F_L1 + 0 * 128, 16, 8, 8, 0, true, NB, NF>(c, A, A, B);
+    if constexpr (SAVE) save_frags<8, 256>(a.sv_h + 1 * HS, B, pidx, valid, q);
     layer16<Lay::F_L1 + 1 * 128, 32, 8, 8, 0, true, NB, NF>(c, B, B, A);
+    if constexpr (SAVE) save_frags<8, 256>(a.sv_h + 2 * HS, A, pidx, valid, q);
     layer16<Lay::F_L1 + 2 * 128, 48, 8, 8, 0, true, NB, NF>(c, A, A, B);
+    if constexpr (SAVE) save_frags<8, 256>(a.sv_h + 3 * HS, B, pidx, valid, q);
     layer16<Lay::F_L1 + 3 * 128, 64, 8, 8, 0, true, NB, NF>(c, B, B, A);
+    if constexpr (SAVE) save_frags<8, 256>(a.sv_h + 4 * HS, A, pidx, valid, q);
     layer16<Lay::F_L5, 80, 8, KE, 8, true, NB, NF>(c, E, A, B);            // skip: [input_pts | h]
+    if constexpr (SAVE) save_frags<8, 256>(a.sv_h + 5 * HS, B, pidx, valid, q);
     layer16<Lay::F_L6, 96, 8, 8, 0, true, NB, NF>(c, B, B, A);
+    if constexpr (SAVE) save_frags<8, 256>(a.sv_h + 6 * HS, A, pidx, valid, q);
     layer16<Lay::F_L6 + 128, 112, 8, 8, 0, true, NB, NF>(c, A, A, B);      // h7 in B
+    if constexpr (SAVE) save_frags<8, 256>(a.sv_h + 7 * HS, B, pidx, valid, q);
 
     if constexpr (VD) {
         layer16<Lay::F_FEAT, 128, 8, 8, 0, false, NB, NF>(c, B, B, A);     // feature (no activation)
+        if constexpr (SAVE) save_frags<8, 256>(a.sv_feat, A, pidx, valid, q);
         f32x4 alpha[2], rgb[2];
         tile_single<Lay::F_ALPHA, 144, 8, NB, NF>(c, B, alpha);            // row 0 = sigma
         layer16<Lay::F_VIEWS, 145, 4, 8, KD, true, NB, NF>(c, A, Dv, B);   // views_linears.0 (128 rows)
+        if constexpr (SAVE) save_frags<4, 128>(a.sv_hv, B, pidx, valid, q);
         tile_single<Lay::F_RGB, 153, 4, NB, NF>(c, B, rgb);                // rows 0..2
         static_for<2>([&](auto cc_) {
             constexpr int cc = cc_;
@@ -263,7 +293,7 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16_kernel(MlpArgs 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // no LDS-DMA may outlive the workgroup
 }
 
-template <int LX, int LD, bool VD, class C>
+template <int LX, int LD, bool VD, class C, bool SAVE = false>
 static int launch_wg16(const MlpArgs &a, int n_frags_used, int n_tiles, hipStream_t s) {
     constexpr int WG_THREADS = C::WAVES * 64, WG_POINTS = C::WAVES * 32;
     using Lay = Layout16<LX, LD, VD>;
@@ -271,7 +301,7 @@ static int launch_wg16(const MlpArgs &a, int n_frags_used, int n_tiles, hipStrea
     const size_t lds = C::RING_BYTES + (size_t)Lay::N_TILES * 16 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_bf16_s16_kernel<LX, LD, VD, C>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_bf16_s16_kernel<LX, LD, VD, C, SAVE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return NERF_AMD_EHIP;
         attr_set = true;
@@ -279,7 +309,7 @@ static int launch_wg16(const MlpArgs &a, int n_frags_used, int n_tiles, hipStrea
     const int64_t groups = (a.P + WG_POINTS - 1) / WG_POINTS;
     if (groups <= 0) return NERF_AMD_OK;
     if (a.P >= (int64_t)1 << 31) return NERF_AMD_EINVAL;
-    hipLaunchKernelGGL((mlp_bf16_s16_kernel<LX, LD, VD, C>), dim3((unsigned)groups), dim3(WG_THREADS), lds, s, a);
+    hipLaunchKernelGGL((mlp_bf16_s16_kernel<LX, LD, VD, C, SAVE>), dim3((unsigned)groups), dim3(WG_THREADS), lds, s, a);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
 
@@ -308,6 +338,10 @@ int launch_mlp_bf16_s16(const MlpArgs &a, int multires, int multires_views, int 
         if (multires == 15) return launch_wg16<15, 0, false, Cfg16>(a, n_frags_used, n_tiles, s);
     }
     return NERF_AMD_EUNSUPPORTED;
+}
+
+int launch_mlp_bf16_s16_save(const MlpArgs &a, int n_frags_used, int n_tiles, hipStream_t s) {
+    return launch_wg16<10, 4, true, Cfg16, true>(a, n_frags_used, n_tiles, s);
 }
 
 }  // namespace na

@@ -19,6 +19,13 @@ NA_HD inline uint16_t f32_to_bf16_rne(float f) {
 
 // Weight column (inside the tensor) held by element j of lane `lane` of fragment d, or -1.
 NA_HD inline int frag_source(const FragDesc &d, int lane, int j, int n_out, int *row) {
+    if (d.kind == FRAG_T16 || d.kind == FRAG_TG16) {      // transposed: *row = output feature, column = input feature
+        const int i = lane & 15, q = lane >> 4;
+        const int o = d.kind == FRAG_T16 ? acc16_col(d.ks, q, j) : 32 * d.ks + 8 * q + j;
+        *row = o;
+        if (o >= d.seg_len || d.row0 + i >= d.L) return -1;
+        return d.col_base + d.row0 + i;
+    }
     const bool s16 = d.kind == FRAG_ACC16 || d.kind == FRAG_GEN16;
     const int o = s16 ? (lane & 15) : (lane & 31), h = s16 ? (lane >> 4) : (lane >> 5);
     *row = d.row0 + o;
@@ -77,7 +84,10 @@ int launch_pack(const Program &p, const FragDesc *d_frags, const TileDesc *d_til
                 const TensorDesc *d_tensors, const float *const *d_w, const float *const *d_b,
                 uint16_t *stream_bf16, float *bias_bf16, float *stream_f32, float *bias_f32,
                 const FragDesc *d_frags16, const TileDesc *d_tiles16, uint16_t *stream_s16, float *bias_s16,
-                hipStream_t s) {
+                const FragDesc *d_frags_bwd, uint16_t *stream_bwd, hipStream_t s) {
+    if (p.bf16_ok && !p.frags_bwd.empty())
+        hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)p.frags_bwd.size()), dim3(512), 0, s,
+                           d_frags_bwd, d_tensors, d_w, stream_bwd);
     if (p.bf16_ok) {
         hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)p.frags16.size()), dim3(512), 0, s,
                            d_frags16, d_tensors, d_w, stream_s16);
@@ -95,6 +105,19 @@ int launch_pack(const Program &p, const FragDesc *d_frags, const TileDesc *d_til
 
 void pack_bf16_host(const Program &p, int shape, const float *const *w, const float *const *b,
                     uint16_t *stream, float *bias) {
+    if (shape == 17) {       // backward (transposed) stream; no bias table
+        if (stream)
+            for (size_t n = 0; n < p.frags_bwd.size(); ++n)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        int row;
+                        const TensorDesc &t = p.tensors[p.frags_bwd[n].tensor];
+                        const int col = frag_source(p.frags_bwd[n], lane, j, t.n_out, &row);
+                        stream[n * 512 + lane * 8 + j] =
+                            f32_to_bf16_rne(col < 0 ? 0.0f : w[p.frags_bwd[n].tensor][(int64_t)row * t.n_in + col]);
+                    }
+        return;
+    }
     if (shape == 16) {
         if (stream)
             for (size_t n = 0; n < p.frags16.size(); ++n)

@@ -134,6 +134,28 @@ int build_program(const nerf_amd_arch &a, Program &p, const char **err) {
         }
         p.n_frags16_used = (int)p.frags16.size();
         while (p.frags16.size() % STREAM_PAD_FRAGS) p.frags16.push_back({0, FRAG_ZERO, 0, 0, 0, 0, 0, 0});
+
+        // ---- backward stream: g_in^T = W^T g_out^T, layer -> pair of 16-row input-feature tiles ->
+        //      segment -> k-step -> tile of the pair (parameter gradients only: the encodings' own
+        //      gradients, i.e. ray gradients, are not propagated)
+        if (a.use_viewdirs) {
+            struct SegT { int tensor, kind, col_base, nk; };
+            auto add_bwd = [&](int n_in, std::initializer_list<SegT> segs) {
+                for (int t = 0; t < n_in / 16; t += 2)
+                    for (const SegT &sg : segs)
+                        for (int ks = 0; ks < sg.nk; ++ks)
+                            for (int u = 0; u < 2; ++u)
+                                p.frags_bwd.push_back({sg.tensor, sg.kind, 16 * (t + u), sg.col_base, ks,
+                                                       p.tensors[sg.tensor].n_out, n_in, 0});
+            };
+            add_bwd(W / 2, {SegT{D + 3, FRAG_TG16, 0, 1}});                                    // g_hv   <- rgb_linear
+            add_bwd(W, {SegT{D + 2, FRAG_T16, 0, (W / 2) / 32}});                              // g_feat <- views_linears.0
+            add_bwd(W, {SegT{D + 0, FRAG_T16, 0, W / 32}, SegT{D + 1, FRAG_TG16, 0, 1}});      // g_h8   <- feature + alpha
+            for (int l = D - 1; l >= 1; --l)                                                   // g_h(l) <- pts_linears.l
+                add_bwd(W, {SegT{l, FRAG_T16, is_skip(l - 1) ? p.input_ch : 0, W / 32}});
+            p.n_frags_bwd_used = (int)p.frags_bwd.size();
+            while (p.frags_bwd.size() % STREAM_PAD_FRAGS) p.frags_bwd.push_back({0, FRAG_ZERO, 0, 0, 0, 0, 0, 0});
+        }
     }
     return 0;
 }

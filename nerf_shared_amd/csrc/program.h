@@ -30,6 +30,14 @@
 //    * FRAG_GEN16: lane quarter q = 2h + b evaluates sin (h=0) or cos (h=1) of the frequencies
 //      of parity b; see gen16_col below.
 //
+// backward stream (mlp_bwd_s16.hip): the same s16 machinery applied to g_in^T = W^T . g_out^T.
+//   Fragments are 16 rows of W^T (= 16 input features of the Linear) x 32 k (= output features):
+//    * FRAG_T16 : B operand is a gradient tile chain, k slot (q, j) of k-step ks is output
+//                 feature acc16_col(ks, q, j);  element = W[that output][col_base + row0 + (l&15)].
+//    * FRAG_TG16: B operand is built from dL/draw, k slot (q, j) is output feature 8q + j.
+//   FragDesc: row0 = first input feature of the tile (relative to col_base), seg_len = number of
+//   output features, L = number of input features of this segment.
+//
 // fp32 stream (generic kernel, mlp_fp32.hip)
 //   v_mfma_f32_32x32x2_f32: lane l holds A[row = l&31][k = l>>5].  Fragments are
 //   grouped four k-pairs at a time so a lane loads 16 bytes: group g of tile t
@@ -48,7 +56,7 @@
 
 namespace na {
 
-enum { FRAG_ACC = 0, FRAG_GEN = 1, FRAG_ZERO = 2, FRAG_ACC16 = 3, FRAG_GEN16 = 4 };
+enum { FRAG_ACC = 0, FRAG_GEN = 1, FRAG_ZERO = 2, FRAG_ACC16 = 3, FRAG_GEN16 = 4, FRAG_T16 = 5, FRAG_TG16 = 6 };
 
 struct FragDesc {        // one bf16 A fragment: 32 out rows x 16 k
     int32_t tensor;      // index into the parameter list (nerf_amd.h order)
@@ -140,6 +148,9 @@ struct Program {
     std::vector<FragDesc> frags16;
     std::vector<TileDesc> tiles16;
     int n_frags16_used = 0;
+    // backward (transposed-weight) stream for the s16 kernel; view-branch (10,4) model only
+    std::vector<FragDesc> frags_bwd;
+    int n_frags_bwd_used = 0;
     // fp32 generic program
     std::vector<LayerF32> layers;
     int64_t f32_stream_floats = 0, f32_bias_floats = 0;

@@ -89,6 +89,52 @@ def _destroy_handle(handle):
         lib.nerf_amd_model_destroy(handle)
 
 
+class _FieldTrainFn(torch.autograd.Function):
+    """The fused bf16 field with a HIP backward for the parameters:
+    forward saves every layer's activations in a workspace tensor, backward runs the dX-chain
+    kernel and the weight-gradient GEMMs (nerf_amd_field_backward).  Inputs (points, rays) get
+    no gradient yet."""
+
+    @staticmethod
+    def forward(ctx, model, pts, viewdirs, rays, z_vals, n_rays, n_samples, *params):
+        dev = params[0].device
+        handle = model._model_handle(dev)
+        P = n_rays * n_samples
+        nbytes = lib.nerf_amd_train_workspace(handle, P)
+        if nbytes < 0:
+            raise _lib.NerfAmdError("this architecture has no training kernels")
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        raw = torch.empty(P, 4, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(lib.nerf_amd_field_forward_train(handle, _lib.ptr(pts), _lib.ptr(viewdirs), _lib.ptr(rays),
+                                                        rays.shape[1] if rays is not None else 0, _lib.ptr(z_vals),
+                                                        n_rays, n_samples, raw.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                        _lib.stream_of(dev)), "nerf_amd_field_forward_train")
+        ctx.model, ctx.ws, ctx.P = model, ws, P
+        ctx.shapes = [tuple(p.shape) for p in params]
+        return raw
+
+    @staticmethod
+    def backward(ctx, g_raw):
+        model, ws, P = ctx.model, ctx.ws, ctx.P
+        dev = ws.device
+        g = g_raw.contiguous().float()
+        mods = model._linears()
+        gw = [torch.empty_like(m.weight, dtype=torch.float32) for m in mods]
+        gb = [torch.empty_like(m.bias, dtype=torch.float32) for m in mods]
+        n = len(mods)
+        wp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in gw])
+        bp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in gb])
+        with torch.cuda.device(dev):
+            _lib.check(lib.nerf_amd_field_backward(model._handle, g.data_ptr(), P, ws.data_ptr(), ws.numel(), wp, bp, n,
+                                                   _lib.stream_of(dev)), "nerf_amd_field_backward")
+        ctx.ws = None
+        grads = []
+        for w, b in zip(gw, gb):       # parameter order of _train_params(): weight, bias per linear
+            grads += [w, b]
+        return (None, None, None, None, None, None, None) + tuple(grads)
+
+
 class NeRF(nn.Module):
     """The reference's field model (nerf.py:61-143), same constructor, same
     parameters; ``forward`` runs on the MI355X kernels."""
@@ -168,6 +214,35 @@ class NeRF(nn.Module):
             self._packed_key = key
         return self._handle
 
+    def _train_params(self):
+        out = []
+        for m in self._linears():
+            out += [m.weight, m.bias]
+        return out
+
+    def _wants_grad(self, device):
+        """True when autograd should flow into the parameters and the training kernels apply.
+        Otherwise (no_grad, frozen parameters, or an architecture / precision the training
+        kernels do not cover) the forward-only kernels run and outputs carry no history."""
+        if not torch.is_grad_enabled() or not any(p.requires_grad for p in self._train_params()):
+            return False
+        ok = (self.precision or _default_precision) == "bf16" and \
+            bool(lib.nerf_amd_model_supports_training(self._model_handle(device)))
+        if not ok and not getattr(self, "_warned_no_grad", False):
+            import warnings
+            warnings.warn("nerf_shared_amd: gradients were requested but the training kernels cover only "
+                          "NeRF(D=8, W=256, skips=[4], use_viewdirs=True, multires=10, multires_views=4) in bf16 mode; "
+                          "this model runs forward-only and its outputs carry no autograd history")
+            self._warned_no_grad = True
+        return ok
+
+    def forward_rays(self, rays, z_vals):
+        """raw [R, S, 4] of rays [R, 11] at depths z_vals [R, S] (pts = o + d z formed in the kernel);
+        differentiable with respect to the parameters."""
+        R, S = z_vals.shape
+        raw = _FieldTrainFn.apply(self, None, None, rays, z_vals, R, S, *self._train_params())
+        return raw.reshape(R, S, 4)
+
     def _precision_code(self):
         name = self.precision or _default_precision
         if name not in _PRECISIONS:
@@ -201,8 +276,11 @@ class NeRF(nn.Module):
             raise _lib.NerfAmdError("this NeRF was built with use_viewdirs=True: viewdirs is required")
         handle = self._model_handle(dev)
         out_ch = 4 if self.use_viewdirs else self.output_ch
-        out = torch.empty(pts.shape[0], out_ch, device=dev, dtype=torch.float32)
         n_rays = pts.shape[0] // n_samples
+        if self._wants_grad(dev):
+            raw = _FieldTrainFn.apply(self, pts, vd, None, None, n_rays, n_samples, *self._train_params())
+            return raw.reshape(list(inputs.shape[:-1]) + [out_ch])
+        out = torch.empty(pts.shape[0], out_ch, device=dev, dtype=torch.float32)
         with torch.cuda.device(dev):
             _lib.check(lib.nerf_amd_nerf_forward(handle, pts.data_ptr(), _lib.ptr(vd), n_rays, n_samples,
                                                  out.data_ptr(), self._precision_code(), _lib.stream_of(dev)),

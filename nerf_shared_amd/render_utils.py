@@ -212,6 +212,69 @@ class Renderer(torch.nn.Module):
         # keep the draws alive until the stream has consumed them (caching allocator is stream-ordered)
         return t_rand, noise0, noise1, u
 
+    def _draws(self, R, dev, pytest):
+        """Random draws of one render_rays call in the reference's order and shapes."""
+        Nc, Ni = int(self.N_samples), int(self.N_importance)
+        t_rand = noise0 = noise1 = u = t_lin = None
+        if self.perturb > 0.:
+            t_rand = _pytest_uniform([R, Nc], dev) if pytest else torch.rand([R, Nc], device=dev)
+        if self.raw_noise_std > 0.:
+            noise0 = (_pytest_uniform([R, Nc], dev) if pytest else torch.randn([R, Nc], device=dev)) * self.raw_noise_std
+        if Ni > 0:
+            det = (self.perturb == 0.)
+            if pytest:
+                np.random.seed(0)
+                un = np.broadcast_to(np.linspace(0., 1., Ni), [R, Ni]) if det else np.random.rand(R, Ni)
+                u = torch.Tensor(np.ascontiguousarray(un)).to(dev)
+            elif det:
+                t_lin = _linspace01(Ni, dev)
+            else:
+                u = torch.rand([R, Ni], device=dev)
+            if self.raw_noise_std > 0.:
+                noise1 = (_pytest_uniform([R, Nc + Ni], dev) if pytest else torch.randn([R, Nc + Ni], device=dev)) * self.raw_noise_std
+        return t_rand, noise0, noise1, u, t_lin
+
+    def _render_rays_train(self, rays, coarse_model, fine_model, retraw, retweights, pytest):
+        """render_rays with autograd into the models' parameters (what main.py:77-104 needs):
+        the same kernels stage by stage -- z_vals, training forward of the field (activations
+        saved), compositing -- with the field and raw2outputs as autograd Functions whose
+        backward passes are HIP kernels.  z_samples are detached, as in the reference
+        (render_utils.py:145); rays get no gradient yet."""
+        R, dev = rays.shape[0], rays.device
+        Nc, Ni = int(self.N_samples), int(self.N_importance)
+        t_rand, noise0, noise1, u, t_lin = self._draws(R, dev, pytest)
+        f = dict(device=dev, dtype=torch.float32)
+        stream = _lib.stream_of(dev)
+        z = torch.empty(R, Nc, **f)
+        with torch.cuda.device(dev):
+            _lib.check(lib.nerf_amd_coarse_z(rays.data_ptr(), rays.shape[1], _linspace01(Nc, dev).data_ptr(), _lib.ptr(t_rand),
+                                             R, Nc, int(bool(self.lindisp)), int(self.perturb > 0.), z.data_ptr(), stream),
+                       "nerf_amd_coarse_z")
+        rays_d = rays[:, 3:6]
+        raw = coarse_model.forward_rays(rays, z)
+        rgb, disp, acc, weights, _ = _Raw2OutputsFn.apply(raw, z, rays_d, noise0, bool(self.white_bkgd))
+        ret = {}
+        if Ni > 0:
+            rgb0, disp0, acc0 = rgb, disp, acc
+            z_f, z_std = torch.empty(R, Nc + Ni, **f), torch.empty(R, **f)
+            w_c = weights.detach()
+            with torch.cuda.device(dev):
+                _lib.check(lib.nerf_amd_resample(z.data_ptr(), w_c.data_ptr(), _lib.ptr(u), _lib.ptr(t_lin), R, Nc, Ni,
+                                                 z_f.data_ptr(), z_std.data_ptr(), stream), "nerf_amd_resample")
+            z = z_f
+            net = coarse_model if fine_model is None else fine_model
+            raw = net.forward_rays(rays, z)
+            rgb, disp, acc, weights, _ = _Raw2OutputsFn.apply(raw, z, rays_d, noise1, bool(self.white_bkgd))
+        ret.update(rgb_map=rgb, disp_map=disp, acc_map=acc)
+        if retraw:
+            ret['raw'] = raw
+        if retweights:
+            ret['weights'] = weights
+            ret['z_vals'] = z
+        if Ni > 0:
+            ret.update(rgb0=rgb0, disp0=disp0, acc0=acc0, z_std=z_std)
+        return ret
+
     def _alloc_outputs(self, R, dev, out_ch, retraw, retweights):
         Ni = int(self.N_importance)
         S_last = int(self.N_samples) + Ni
@@ -242,6 +305,11 @@ class Renderer(torch.nn.Module):
         if rays.dim() != 2 or rays.shape[1] not in (8, 11):
             raise _lib.NerfAmdError("ray_batch must be [N, 8] or [N, 11], got %s" % (tuple(ray_batch.shape),))
         self._check_model(coarse_model, "coarse_model")
+        if fine_model is not None:
+            self._check_model(fine_model, "fine_model")
+        if rays.shape[0] > 0 and (coarse_model._wants_grad(rays.device)
+                                  or (fine_model is not None and self.N_importance > 0 and fine_model._wants_grad(rays.device))):
+            return self._render_rays_train(rays, coarse_model, fine_model, retraw, retweights, pytest)
         out_ch = 4 if coarse_model.use_viewdirs else coarse_model.output_ch
         outs = self._alloc_outputs(rays.shape[0], rays.device, out_ch, retraw, retweights)
         self._launch(rays, coarse_model, fine_model, outs, retraw, retweights, pytest)
@@ -269,6 +337,14 @@ class Renderer(torch.nn.Module):
         out_ch = 4 if coarse_model.use_viewdirs else coarse_model.output_ch
         full = self._alloc_outputs(N, dev, out_ch, retraw, False)
         starts = list(range(0, N, chunk))
+        if N > 0 and (coarse_model._wants_grad(dev) or (fine_model is not None and self.N_importance > 0
+                                                     and fine_model._wants_grad(dev))):
+            parts = {}                     # training: autograd graph per chunk, concatenated like the reference
+            for i in starts:
+                r = self.render_rays(rays[i:i + chunk], coarse_model, fine_model, retraw)
+                for k, v in r.items():
+                    parts.setdefault(k, []).append(v)
+            return {k: torch.cat(v, 0) for k, v in parts.items()}
         if not (self.overlap_chunks and len(starts) > 1):
             for i in starts:
                 part = {k: v[i:i + chunk] for k, v in full.items()}

@@ -55,3 +55,182 @@ def test_raw2outputs_backward_matches_autograd(dev, S, white, use_noise):
     assert torch.isfinite(g).all()
     assert rel_err(g, ref) < 2e-5
     np.testing.assert_allclose(g.numpy(), ref.numpy(), atol=2e-5 * float(ref.abs().max()), rtol=2e-4)
+
+
+VD = dict(D=8, W=256, output_ch=5, skips=[4], use_viewdirs=True, multires=10, multires_views=4)
+
+
+def _models(dev, seed, sharpen):
+    from nerf_shared_amd import nerf
+    sd = synth.torch_state_dict(seed, sharpen, **{**VD, "skips": (4,)})
+    m = nerf.NeRF(**VD)
+    m.load_state_dict(sd)
+    m = m.to(dev)
+    m.precision = "bf16"
+    cpu = {k: v.clone().requires_grad_(True) for k, v in O.state_dict_to_torch(sd).items()}
+    return m, cpu
+
+
+class _RoundBf16(torch.autograd.Function):
+    """Round to bf16 in the forward, identity in the backward (what the kernel's conversions do to the
+    forward values; gradients pass through the rounding untouched)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def bf16_field(sd, pts, vd):
+    """The view-branch NeRF.MLP (nerf.py:110-134) with the kernel's roundings: weights, encodings and
+    every hidden activation rounded to bf16, fp32 accumulation, fp32 bias/ReLU.  Differentiable."""
+    rb = _RoundBf16.apply
+    lin = lambda n, x: torch.nn.functional.linear(x, rb(sd[n + ".weight"]), sd[n + ".bias"])   # noqa: E731
+    e = rb(O.embed(pts.reshape(-1, 3), 10))
+    d = rb(O.embed(vd[:, None].expand(pts.shape).reshape(-1, 3), 4))
+    h = e
+    for i in range(8):
+        h = rb(torch.relu(lin("pts_linears.%d" % i, h)))
+        if i == 4:
+            h = torch.cat([e, h], -1)
+    sigma = lin("alpha_linear", h)
+    feat = rb(lin("feature_linear", h))
+    hv = rb(torch.relu(lin("views_linears.0", torch.cat([feat, d], -1))))
+    return torch.cat([lin("rgb_linear", hv), sigma], -1).reshape(list(pts.shape[:-1]) + [4])
+
+
+@pytest.mark.parametrize("seed,sharpen", [(0, 1.0), (1, 2.0)])
+def test_field_backward_matches_autograd(dev, seed, sharpen):
+    """dL/dtheta of NeRF.forward for a random linear loss on raw, HIP against torch.autograd on
+    (a) the same network with the kernel's bf16 roundings (same ReLU masks): relative L2 error
+        <= 5e-2 per parameter tensor (measured 0.05-1.4 % at default scale, up to 3.6 % with the weights
+        x2) -- the remaining difference is the bf16 rounding of the gradients themselves, which
+        accumulates with depth;
+    (b) the fp32 oracle: cosine >= 0.98 (ReLU units that flip under bf16 rounding move whole
+        gradient columns, so this is a sanity bound, not a precision claim)."""
+    rng = np.random.default_rng(11)
+    R, S = 70, 13                                   # 910 points: ragged
+    pts = torch.from_numpy(rng.uniform(-2, 2, size=(R, S, 3)).astype(np.float32))
+    vd = torch.from_numpy(rng.normal(size=(R, 3)).astype(np.float32))
+    vd = vd / vd.norm(dim=-1, keepdim=True)
+    coef = torch.from_numpy(rng.normal(size=(R, S, 4)).astype(np.float32))
+    m, cpu = _models(dev, seed, sharpen)
+    (O.nerf_forward(cpu, O.Arch(**VD), pts, vd) * coef).sum().backward()
+    cpu_b = {k: v.detach().clone().requires_grad_(True) for k, v in cpu.items()}
+    out_b = bf16_field(cpu_b, pts, vd)
+    (out_b * coef).sum().backward()
+    out = m(pts.to(dev), vd.to(dev))
+    assert out.requires_grad
+    (out * coef.to(dev)).sum().backward()
+    # forward: the kernel against its own rounding model, and training forward == inference forward
+    assert rel_err(out, out_b) < 2e-3
+    with torch.no_grad():
+        torch.testing.assert_close(m(pts.to(dev), vd.to(dev)), out.detach(), rtol=0, atol=0)
+    table = []
+    for name, p in m.named_parameters():
+        assert p.grad is not None and p.grad.shape == cpu[name].shape, name
+        g = p.grad.detach().cpu()
+        assert torch.isfinite(g).all(), name
+        cos32 = float((g.double().flatten() @ cpu[name].grad.double().flatten())
+                      / (g.double().norm() * cpu[name].grad.double().norm()).clamp_min(1e-30))
+        table.append((name, rel_err(g, cpu_b[name].grad), rel_err(g, cpu[name].grad), cos32))
+    for row in table:
+        print("%-26s err vs bf16-model %.4f   vs fp32 %.4f   cos fp32 %.5f" % row)
+    for name, eb, e32, cos32 in table:
+        assert eb < 5e-2, (name, eb)
+        assert cos32 > 0.98, (name, cos32)
+
+
+BASE = dict(perturb=0.0, N_importance=128, N_samples=64, use_viewdirs=True, white_bkgd=True,
+            raw_noise_std=0.0, ndc=False, lindisp=False, near=2.0, far=6.0)
+
+
+def _batch(n, seed):
+    rng = np.random.default_rng(seed)
+    K = synth.lego_intrinsics(400, 400)
+    idx = np.sort(rng.choice(160000, size=n, replace=False))
+    ro, rd = synth.rays_np(400, 400, K, synth.LEGO_C2W, idx)
+    target = torch.from_numpy(rng.uniform(0, 1, size=(n, 3)).astype(np.float32))
+    return torch.from_numpy(synth.ray_batch_np(ro, rd, 2.0, 6.0, True)), target
+
+
+def test_training_step_gradients(dev, monkeypatch):
+    """The reference's training loss (main.py:85-98: mse(rgb) + mse(rgb0)) through Renderer.render_rays:
+    parameter gradients of both networks against torch.autograd on the oracle -- with the kernel's
+    bf16 roundings in the field (tight) and in plain fp32 (sanity)."""
+    from nerf_shared_amd import render_utils
+    batch, target = _batch(96, 3)
+    cfg = dict(BASE, N_samples=32, N_importance=48)
+    r = render_utils.Renderer(**cfg)
+    mc, cc = _models(dev, 1, 2.0)
+    mf, cf = _models(dev, 11, 2.0)
+    out = r.render_rays(batch.to(dev), mc, mf)
+    assert out["rgb_map"].requires_grad and out["rgb0"].requires_grad and not out["z_std"].requires_grad
+    t = target.to(dev)
+    loss = ((out["rgb_map"] - t) ** 2).mean() + ((out["rgb0"] - t) ** 2).mean()
+    loss.backward()
+
+    def oracle_grads(field):
+        if field is not None:
+            monkeypatch.setattr(O, "nerf_forward", lambda sd, arch, pts, vd, netchunk=0: field(sd, pts, vd))
+        c = {k: v.detach().clone().requires_grad_(True) for k, v in cc.items()}
+        f = {k: v.detach().clone().requires_grad_(True) for k, v in cf.items()}
+        o = O.render_rays(O.RenderCfg(**cfg), batch, (c, O.Arch(**VD)), (f, O.Arch(**VD)))
+        l = ((o["rgb_map"] - target) ** 2).mean() + ((o["rgb0"] - target) ** 2).mean()
+        l.backward()
+        monkeypatch.undo()
+        return float(l), c, f
+
+    l32, c32, f32 = oracle_grads(None)
+    lb, cb, fb = oracle_grads(bf16_field)
+    assert abs(float(loss) - lb) < 2e-3 * max(1.0, abs(lb))
+    for tag, m, gb, g32 in (("coarse", mc, cb, c32), ("fine", mf, fb, f32)):
+        for name, p in m.named_parameters():
+            g = p.grad.detach().cpu()
+            eb, cos = rel_err(g, gb[name].grad), float((g.double().flatten() @ g32[name].grad.double().flatten())
+                                                         / (g.double().norm() * g32[name].grad.double().norm()).clamp_min(1e-30))
+            assert eb < 8e-2 and cos > 0.97, (tag, name, eb, cos)
+
+
+def test_adam_steps_reduce_the_loss(dev):
+    """A few optimizer steps on a fixed batch (the loop of main.py:67-112 without the data loader)."""
+    from nerf_shared_amd import render_utils
+    batch, _ = _batch(256, 4)
+    target = torch.full((256, 3), 0.25)
+    r = render_utils.Renderer(**dict(BASE, N_samples=32, N_importance=32))
+    mc, _ = _models(dev, 0, 1.0)
+    mf, _ = _models(dev, 10, 1.0)
+    opt = torch.optim.Adam(list(mc.parameters()) + list(mf.parameters()), lr=5e-4, betas=(0.9, 0.999))
+    losses = []
+    b, t = batch.to(dev), target.to(dev)
+    for _ in range(12):
+        opt.zero_grad()
+        rgb, disp, acc, extras = r.render(400, 400, None, mc, mf, chunk=128, rays=(b[:, 0:3], b[:, 3:6]), retraw=True)
+        loss = ((rgb - t) ** 2).mean() + ((extras["rgb0"] - t) ** 2).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    print("losses", ["%.4f" % v for v in losses])
+    assert all(b < a for a, b in zip(losses, losses[1:])) and losses[-1] < losses[0] - 0.03
+    # the same loop on the fp32 CPU oracle follows the same trajectory
+    _, cc = _models(dev, 0, 1.0)
+    _, cf = _models(dev, 10, 1.0)
+    opt2 = torch.optim.Adam(list(cc.values()) + list(cf.values()), lr=5e-4, betas=(0.9, 0.999))
+    ocfg = O.RenderCfg(**dict(BASE, N_samples=32, N_importance=32))
+    ref = []
+    for _ in range(12):
+        opt2.zero_grad()
+        o = O.render_rays(ocfg, batch, (cc, O.Arch(**VD)), (cf, O.Arch(**VD)))
+        l = ((o["rgb_map"] - target) ** 2).mean() + ((o["rgb0"] - target) ** 2).mean()
+        l.backward()
+        opt2.step()
+        ref.append(float(l))
+    print("oracle", ["%.4f" % v for v in ref])
+    np.testing.assert_allclose(losses, ref, rtol=2e-2)
+    # the packed weights followed the optimizer: inference agrees with the last training forward's parameters
+    with torch.no_grad():
+        rgb2 = r.render(400, 400, None, mc, mf, chunk=128, rays=(b[:, 0:3], b[:, 3:6]), retraw=False)[0]
+    assert float(((rgb2 - t) ** 2).mean()) < losses[0]

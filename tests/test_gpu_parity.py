@@ -48,7 +48,7 @@ def gpu_model(dev, seed, sharpen, precision, **arch):
     m = nerf.NeRF(**arch)
     m.load_state_dict(synth.torch_state_dict(seed, sharpen, **{**arch, "skips": tuple(arch["skips"])}))
     m.precision = precision
-    return m.to(dev)
+    return m.to(dev).requires_grad_(False)       # parity tests exercise the forward-only kernels
 
 
 def cpu_model(seed, sharpen, **arch):
