@@ -149,7 +149,8 @@ int nerf_amd_raw2outputs_backward(const float *raw, int32_t raw_ch, const float 
  *   forward_train : the fused bf16 forward (explicit pts + viewdirs, or rays + z_vals with pts = o + d z) that also saves every
  *                   layer's activations in `workspace` (nerf_amd_train_workspace bytes, 256-B aligned)
  *   backward      : dL/draw [P,4] -> gradients of every nn.Linear weight [out,in] and bias [out]
- *                   (fp32 device tensors in nerf_amd_model_update order, overwritten)
+ *                   (fp32 device tensors in nerf_amd_model_update order; the kernels ACCUMULATE into
+ *                   them with float atomics, so pass zeroed tensors for plain gradients)
  * ------------------------------------------------------------------------ */
 int     nerf_amd_model_supports_training(const nerf_amd_model *m);
 int64_t nerf_amd_train_workspace(const nerf_amd_model *m, int64_t n_points);

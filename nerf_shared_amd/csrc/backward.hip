@@ -1,14 +1,15 @@
 // backward.hip -- training support for the fused view-branch (10,4) field: workspace layout,
-// training forward (activations saved), and the backward pass
+// training forward (activations saved), and the parameter gradients
 //   dL/draw -> mlp_bwd_s16_kernel (pre-activation gradients of every layer, in registers)
-//           -> weight gradients  dW_l = g_pre(l)^T h_(l-1)   (plain GEMMs with K = #points: rocBLAS)
-//           -> bias gradients    db_l = column sums of g_pre(l)
-// Saved activations and gradients are slot-major bf16 rows (kernels.h), so dW comes out with
-// permuted rows/columns; unpermute_kernel scatters it into the nn.Linear layout.
+//           -> weight gradients  dW_l = g_pre(l)^T h_(l-1)   and bias gradients (column sums)
+// Saved activations X and gradients G are slot-major bf16 rows [P, n] (kernels.h).  dW is a GEMM
+// whose contraction runs over the points (K = hundreds of thousands) with M, N <= 256: HBM-bound
+// streaming of G and X.  dw_kernel splits the points over the workgroups; each stages 32-point
+// chunks of G and X into LDS, reads both MFMA operands with the transposing LDS read
+// (ds_read_b64_tr_b16: 8 consecutive points of one feature per lane), accumulates a full
+// [n_out x n_in] fp32 tile in registers and adds it to the nn.Linear-layout gradient with
+// float atomics (un-permuting the slot order on the way).
 #include <hip/hip_runtime.h>
-#include <rocblas/rocblas.h>
-
-#include <mutex>
 
 #include "kernels.h"
 #include "program.h"
@@ -23,41 +24,200 @@ __device__ __forceinline__ int slot_to_feature(int kind, int s, int L) {
     return kind == PERM_ACC ? acc16_col(ks, q, j) : gen16_col(ks, q, j, L);
 }
 
-// dst[out_feature][col_off + in_feature] = src[o_slot][i_slot]   (src is n x m row-major, ld = m)
-__global__ __launch_bounds__(256) void unpermute_kernel(const float *src, int n, int m, int out_kind, int in_kind,
-                                                        int in_L, int n_valid, int m_valid, float *dst, int dst_ld,
-                                                        int col_off) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n * m) return;
-    const int o_slot = idx / m, i_slot = idx - o_slot * m;
-    const int o = slot_to_feature(out_kind, o_slot, 0), i = slot_to_feature(in_kind, i_slot, in_L);
-    if (o < 0 || i < 0 || o >= n_valid || i >= m_valid) return;
-    dst[(int64_t)o * dst_ld + col_off + i] = src[idx];
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+struct DwArgs {
+    const uint16_t *G; int ldg;          // [P, ldg] bf16 gradient rows, columns [0, 16*OT) used
+    const uint16_t *X; int ldx;          // [P, ldx] bf16 activation rows, columns [0, 16*IT) used
+    int64_t P;
+    float *slab;                         // per-workgroup partial results: [grid][OT*IT*256 + OT*16] fp32
+};
+
+struct DwReduceArgs {
+    const float *slab; int n_slabs, OT, IT;
+    float *dW; int ld_dw, col_off;       // nn.Linear weight gradient [n_out][ld_dw], written at column col_off + feature
+    float *db;                           // bias gradient [n_out] or NULL
+    int out_kind, in_kind, in_L, n_valid, m_valid;
+};
+
+__device__ __forceinline__ bf16x8 tr_frag(const char *img, int row_stride, int col0, int lane) {
+    // 8 consecutive image rows (points 8g..8g+7) of column col0 + (lane & 15), as an MFMA 16x16x32 operand.
+    const int i = lane & 15, g = lane >> 4;
+    const char *p = img + (8 * g + (i >> 2)) * row_stride + (col0 + 4 * (i & 3)) * 2;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p + 4 * row_stride));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
 }
 
-// out[feature(slot)] = sum over rows of G[row][col0 + slot]  (G bf16, ld elements per row)
-__global__ __launch_bounds__(256) void colsum_kernel(const uint16_t *G, int64_t P, int ld, int col0, int n, int kind,
-                                                     int n_valid, float *out) {
-    const int t = threadIdx.x;
-    if (t >= n) return;
-    const int64_t r0 = (int64_t)blockIdx.x * 2048, r1 = r0 + 2048 < P ? r0 + 2048 : P;
-    float acc = 0.f;
-    for (int64_t r = r0; r < r1; ++r) {
-        const unsigned u = (unsigned)G[r * ld + col0 + t] << 16;
-        acc += __builtin_bit_cast(float, u);
+// OT / IT: 16-wide tiles of the output / input feature axis; the 8 waves form a WO x WI grid.
+template <int OT, int IT, int WO, int WI>
+__global__ __launch_bounds__(512) void dw_kernel(DwArgs a) {
+    static_assert(WO * WI == 8 && OT % WO == 0 && IT % WI == 0, "bad wave grid");
+    constexpr int TO = OT / WO, TI = IT / WI;
+    constexpr int RSG = OT * 32 + 32, RSX = IT * 32 + 32;          // padded LDS row strides (bytes)
+    constexpr int PG = OT * 2, PX = IT * 2;                         // 16-byte pieces per row
+    constexpr int NPG = (32 * PG + 511) / 512, NPX = (32 * PX + 511) / 512;
+    constexpr int BUF = 32 * (RSG + RSX);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wo = wave / WI, wi = wave % WI;
+
+    f32x4 acc[TO][TI];
+#pragma unroll
+    for (int x = 0; x < TO; ++x)
+#pragma unroll
+        for (int y = 0; y < TI; ++y) acc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float csum[NPG][8];
+#pragma unroll
+    for (int k = 0; k < NPG; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) csum[k][j] = 0.f;
+
+    const int64_t n_chunks = (a.P + 31) / 32;
+    u32x4 rg[NPG], rx[NPX];
+    auto load_chunk = [&](int64_t c) {
+#pragma unroll
+        for (int k = 0; k < NPG; ++k) {
+            const int pc = tid + 512 * k, row = pc / PG, col = pc % PG;
+            const int64_t p = c * 32 + row;
+            rg[k] = (u32x4){0u, 0u, 0u, 0u};
+            if (pc < 32 * PG && p < a.P) rg[k] = *reinterpret_cast<const u32x4 *>(a.G + p * a.ldg + col * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < NPX; ++k) {
+            const int pc = tid + 512 * k, row = pc / PX, col = pc % PX;
+            const int64_t p = c * 32 + row;
+            rx[k] = (u32x4){0u, 0u, 0u, 0u};
+            if (pc < 32 * PX && p < a.P) rx[k] = *reinterpret_cast<const u32x4 *>(a.X + p * a.ldx + col * 8);
+        }
+    };
+    int buf = 0;
+    int64_t c = blockIdx.x;
+    if (c < n_chunks) load_chunk(c);
+    for (; c < n_chunks; c += gridDim.x) {
+        char *gimg = smem + buf * BUF, *ximg = gimg + 32 * RSG;
+#pragma unroll
+        for (int k = 0; k < NPG; ++k) {
+            const int pc = tid + 512 * k, row = pc / PG, col = pc % PG;
+            if (pc < 32 * PG) {
+                *reinterpret_cast<u32x4 *>(gimg + row * RSG + col * 16) = rg[k];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {       // bias gradient: this thread always holds the same 8 columns
+                    csum[k][2 * j] += __builtin_bit_cast(float, rg[k][j] << 16);
+                    csum[k][2 * j + 1] += __builtin_bit_cast(float, rg[k][j] & 0xffff0000u);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NPX; ++k) {
+            const int pc = tid + 512 * k, row = pc / PX, col = pc % PX;
+            if (pc < 32 * PX) *reinterpret_cast<u32x4 *>(ximg + row * RSX + col * 16) = rx[k];
+        }
+        __syncthreads();
+        if (c + gridDim.x < n_chunks) load_chunk(c + gridDim.x);     // next chunk's loads fly under the MFMAs
+        bf16x8 A[TO], B[TI];
+#pragma unroll
+        for (int x = 0; x < TO; ++x) A[x] = tr_frag(gimg, RSG, (wo * TO + x) * 16, lane);
+#pragma unroll
+        for (int y = 0; y < TI; ++y) B[y] = tr_frag(ximg, RSX, (wi * TI + y) * 16, lane);
+#pragma unroll
+        for (int x = 0; x < TO; ++x)
+#pragma unroll
+            for (int y = 0; y < TI; ++y)
+                acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[x], B[y], acc[x][y], 0, 0, 0);
+        buf ^= 1;
     }
-    const int o = slot_to_feature(kind, t, 0);
-    if (o >= 0 && o < n_valid) atomicAdd(out + o, acc);
+    // ---- this workgroup's partial tile, as a register dump (1 KiB per 16x16 tile, fully coalesced);
+    //      dw_reduce_kernel sums the dumps of all workgroups and un-permutes the slot order
+    float *slab = a.slab + (int64_t)blockIdx.x * (OT * IT * 256 + OT * 16);
+#pragma unroll
+    for (int x = 0; x < TO; ++x)
+#pragma unroll
+        for (int y = 0; y < TI; ++y)
+            *reinterpret_cast<f32x4 *>(slab + (((wo * TO + x) * IT + (wi * TI + y)) * 64 + lane) * 4) = acc[x][y];
+    // bias partials: threads that staged the same columns (different rows) reduce through LDS
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(smem);
+    for (int i = tid; i < OT * 16; i += 512) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NPG; ++k) {
+        const int pc = tid + 512 * k, col = pc % PG;
+        if (pc < 32 * PG)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) atomicAdd(red + col * 8 + j, csum[k][j]);
+    }
+    __syncthreads();
+    for (int i = tid; i < OT * 16; i += 512) slab[OT * IT * 256 + i] = red[i];
+}
+
+// dW[feature(o_slot)][col_off + feature(i_slot)] = sum over workgroups of their register dumps.
+// 64 elements per block; the slabs are split four ways over the block's waves (more loads in flight).
+__global__ __launch_bounds__(256) void dw_reduce_kernel(DwReduceArgs a) {
+    __shared__ float part[4][64];
+    const int per = a.OT * a.IT * 256 + a.OT * 16;
+    const int t = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + t;
+    float acc = 0.f;
+    if (e < per)
+        for (int b = grp; b < a.n_slabs; b += 4) acc += a.slab[(int64_t)b * per + e];
+    part[grp][t] = acc;
+    __syncthreads();
+    if (grp != 0 || e >= per) return;
+    acc = part[0][t] + part[1][t] + part[2][t] + part[3][t];
+    if (e < a.OT * a.IT * 256) {
+        const int r = e & 3, lane = (e >> 2) & 63, tile = e >> 8;
+        const int to = tile / a.IT, ti = tile - to * a.IT;
+        const int o = slot_to_feature(a.out_kind, to * 16 + 4 * (lane >> 4) + r, 0);
+        const int i = slot_to_feature(a.in_kind, ti * 16 + (lane & 15), a.in_L);
+        if (i >= 0 && o >= 0 && i < a.m_valid && o < a.n_valid) a.dW[(int64_t)o * a.ld_dw + a.col_off + i] = acc;
+    } else if (a.db) {
+        const int o = slot_to_feature(a.out_kind, e - a.OT * a.IT * 256, 0);
+        if (o >= 0 && o < a.n_valid) a.db[o] = acc;
+    }
+}
+
+// Heads (alpha_linear, rgb_linear): G = NO <= 4 natural-order columns of g_rawb [P, 4].
+template <int NO>
+__global__ __launch_bounds__(256) void dw_small_kernel(const uint16_t *G, int g_col0, const uint16_t *X, int ldx, int n_in,
+                                                       int64_t P, int in_kind, float *dW, int ld_dw, float *db) {
+    const int t = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * 128, r1 = r0 + 128 < P ? r0 + 128 : P;
+    float acc[NO], bs[NO];
+#pragma unroll
+    for (int k = 0; k < NO; ++k) { acc[k] = 0.f; bs[k] = 0.f; }
+    for (int64_t p = r0; p < r1; ++p) {
+        const float x = t < n_in ? __builtin_bit_cast(float, (unsigned)X[p * ldx + t] << 16) : 0.f;
+#pragma unroll
+        for (int k = 0; k < NO; ++k) {
+            const float g = __builtin_bit_cast(float, (unsigned)G[p * 4 + g_col0 + k] << 16);
+            acc[k] += g * x;
+            bs[k] += g;
+        }
+    }
+    if (t < n_in) {
+        const int i = slot_to_feature(in_kind, t, 0);
+#pragma unroll
+        for (int k = 0; k < NO; ++k) atomicAdd(dW + (int64_t)k * ld_dw + i, acc[k]);
+    }
+    if (t == 0)
+#pragma unroll
+        for (int k = 0; k < NO; ++k) atomicAdd(db + k, bs[k]);
 }
 
 namespace {
-std::mutex g_blas_mu;
-rocblas_handle g_blas = nullptr;
-
 struct TrainWs {
     uint16_t *sv_e, *sv_d, *sv_h, *sv_feat, *sv_hv, *g_rawb, *g_hv, *g_feat, *g_h;
-    float *scratch;     // 256 x 320 fp32 GEMM output in slot order
+    float *slab;        // DW_GRID partial [256 x 256 + 256] fp32 results of one weight-gradient product
 };
+constexpr int DW_GRID = 128;
 size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 
 int64_t carve(const Program &p, int64_t P, char *base, TrainWs *w) {
@@ -74,7 +234,7 @@ int64_t carve(const Program &p, int64_t P, char *base, TrainWs *w) {
     t.g_hv = (uint16_t *)take(P * 128 * 2);
     t.g_feat = (uint16_t *)take(P * 256 * 2);
     t.g_h = (uint16_t *)take((size_t)8 * P * 256 * 2);
-    t.scratch = (float *)take(256 * 320 * sizeof(float));
+    t.slab = (float *)take((size_t)DW_GRID * (256 * 256 + 256) * sizeof(float));
     if (w) *w = t;
     return (int64_t)off;
 }
@@ -94,38 +254,56 @@ void train_fill_args(const Program &p, int64_t P, void *workspace, MlpArgs *a) {
     a->g_rawb = w.g_rawb; a->g_hv = w.g_hv; a->g_feat = w.g_feat; a->g_h = w.g_h;
 }
 
-// dW (n_out x n_in slice) = G^T X over P rows, then scatter to the nn.Linear layout.
-static int weight_grad(rocblas_handle h, hipStream_t s, int64_t P, const uint16_t *X, int ldx, int m, int in_kind,
-                       int in_L, int m_valid, const uint16_t *G, int ldg, int n, int out_kind, int n_valid,
-                       float *scratch, float *dst, int dst_ld, int col_off) {
-    const float one = 1.0f, zero = 0.0f;
-    // column-major view: C[m x n] = X'[m x P] * (G'[n x P])^T, i.e. row-major C[n][m]
-    rocblas_status st = rocblas_gemm_ex(h, rocblas_operation_none, rocblas_operation_transpose, m, n, (rocblas_int)P, &one,
-                                        X, rocblas_datatype_bf16_r, ldx, G, rocblas_datatype_bf16_r, ldg, &zero,
-                                        scratch, rocblas_datatype_f32_r, m, scratch, rocblas_datatype_f32_r, m,
-                                        rocblas_datatype_f32_r, rocblas_gemm_algo_standard, 0, 0);
-    if (st != rocblas_status_success) return NERF_AMD_EHIP;
-    hipLaunchKernelGGL(unpermute_kernel, dim3((n * m + 255) / 256), dim3(256), 0, s, scratch, n, m, out_kind, in_kind,
-                       in_L, n_valid, m_valid, dst, dst_ld, col_off);
+template <int OT, int IT, int WO, int WI>
+static int launch_dw(const DwArgs &a, const DwReduceArgs &ra, hipStream_t s) {
+    constexpr int RSG = OT * 32 + 32, RSX = IT * 32 + 32;
+    const size_t lds = 2 * 32 * (RSG + RSX);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(dw_kernel<OT, IT, WO, WI>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return NERF_AMD_EHIP;
+        attr_set = true;
+    }
+    // at least ~16 chunks (512 points) per workgroup so the partial tiles are worth their reduction
+    const int64_t n_chunks = (a.P + 31) / 32;
+    int64_t g = n_chunks / 16;
+    if (g < 1) g = 1;
+    if (g > DW_GRID) g = DW_GRID;
+    const unsigned grid = (unsigned)g;
+    hipLaunchKernelGGL((dw_kernel<OT, IT, WO, WI>), dim3(grid), dim3(512), lds, s, a);
+    DwReduceArgs r = ra;
+    r.n_slabs = (int)grid; r.OT = OT; r.IT = IT;
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3((OT * IT * 256 + OT * 16 + 63) / 64), dim3(256), 0, s, r);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
 
-static int bias_grad(hipStream_t s, int64_t P, const uint16_t *G, int ldg, int col0, int n, int kind, int n_valid, float *dst) {
-    if (hipMemsetAsync(dst, 0, n_valid * sizeof(float), s) != hipSuccess) return NERF_AMD_EHIP;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((P + 2047) / 2048)), dim3(256), 0, s, G, P, ldg, col0, n, kind, n_valid, dst);
-    return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
+// dW[:, col_off : col_off + m_valid] (+ db) of one Linear from G [P, 16*OT] and X [P, 16*IT].
+static int weight_grad(hipStream_t s, int64_t P, float *slab, const uint16_t *X, int n_in_slots, int in_kind, int in_L,
+                       int m_valid, const uint16_t *G, int n_out_slots, int n_valid, float *dW, int ld_dw, int col_off,
+                       float *db) {
+    DwArgs a;
+    a.G = G; a.ldg = n_out_slots; a.X = X; a.ldx = n_in_slots; a.P = P; a.slab = slab;
+    DwReduceArgs r;
+    r.slab = slab; r.n_slabs = 0; r.OT = 0; r.IT = 0;
+    r.dW = dW; r.ld_dw = ld_dw; r.col_off = col_off; r.db = db;
+    r.out_kind = PERM_ACC; r.in_kind = in_kind; r.in_L = in_L; r.n_valid = n_valid; r.m_valid = m_valid;
+    if (n_out_slots == 256 && n_in_slots == 256) return launch_dw<16, 16, 4, 2>(a, r, s);
+    if (n_out_slots == 256 && n_in_slots == 64) return launch_dw<16, 4, 8, 1>(a, r, s);
+    if (n_out_slots == 128 && n_in_slots == 256) return launch_dw<8, 16, 4, 2>(a, r, s);
+    if (n_out_slots == 128 && n_in_slots == 32) return launch_dw<8, 2, 8, 1>(a, r, s);
+    return NERF_AMD_EUNSUPPORTED;
 }
 
 // Parameter gradients of the view-branch (10,4) model from the saved activations and the
-// pre-activation gradients the dX-chain kernel left in the workspace.
+// pre-activation gradients the dX-chain kernel left in the workspace.  The 256-wide products
+// overwrite their destination; the two heads (alpha, rgb) accumulate with atomics, so gw / gb of
+// those must come in zeroed (the Python shim hands in one zeroed buffer for everything).
 int train_param_grads(const Program &p, int64_t P, void *workspace, float *const *gw, float *const *gb, hipStream_t s) {
     TrainWs w;
     carve(p, P, static_cast<char *>(workspace), &w);
-    std::lock_guard<std::mutex> lk(g_blas_mu);
-    if (!g_blas && rocblas_create_handle(&g_blas) != rocblas_status_success) return NERF_AMD_EHIP;
-    if (rocblas_set_stream(g_blas, s) != rocblas_status_success) return NERF_AMD_EHIP;
-    rocblas_set_pointer_mode(g_blas, rocblas_pointer_mode_host);
     const int D = p.arch.D, W = p.arch.W, E = 32 * p.KE16, Dd = 32 * p.KD16, ic = p.input_ch, icv = p.input_ch_views;
+    if (W != 256 || E != 64 || Dd != 32) return NERF_AMD_EUNSUPPORTED;
     const int64_t HS = P * 256;
     const int Lx = p.arch.multires, Ld = p.arch.multires_views;
     int rc = 0;
@@ -133,30 +311,26 @@ int train_param_grads(const Program &p, int64_t P, void *workspace, float *const
         const uint16_t *G = w.g_h + l * HS;
         const int n_in = p.tensors[l].n_in;
         if (l == 0) {
-            rc = weight_grad(g_blas, s, P, w.sv_e, E, E, PERM_GEN, Lx, ic, G, W, W, PERM_ACC, W, w.scratch, gw[l], n_in, 0);
+            rc = weight_grad(s, P, w.slab, w.sv_e, E, PERM_GEN, Lx, ic, G, W, W, gw[l], n_in, 0, gb[l]);
         } else if (n_in == W + ic) {      // the layer after the skip: [input_pts | h]
-            rc = weight_grad(g_blas, s, P, w.sv_e, E, E, PERM_GEN, Lx, ic, G, W, W, PERM_ACC, W, w.scratch, gw[l], n_in, 0);
-            if (!rc) rc = weight_grad(g_blas, s, P, w.sv_h + (l - 1) * HS, W, W, PERM_ACC, 0, W, G, W, W, PERM_ACC, W, w.scratch, gw[l], n_in, ic);
+            rc = weight_grad(s, P, w.slab, w.sv_e, E, PERM_GEN, Lx, ic, G, W, W, gw[l], n_in, 0, nullptr);
+            if (!rc) rc = weight_grad(s, P, w.slab, w.sv_h + (l - 1) * HS, W, PERM_ACC, 0, W, G, W, W, gw[l], n_in, ic, gb[l]);
         } else {
-            rc = weight_grad(g_blas, s, P, w.sv_h + (l - 1) * HS, W, W, PERM_ACC, 0, W, G, W, W, PERM_ACC, W, w.scratch, gw[l], n_in, 0);
+            rc = weight_grad(s, P, w.slab, w.sv_h + (l - 1) * HS, W, PERM_ACC, 0, W, G, W, W, gw[l], n_in, 0, gb[l]);
         }
-        if (!rc) rc = bias_grad(s, P, G, W, 0, W, PERM_ACC, W, gb[l]);
     }
     const uint16_t *h8 = w.sv_h + (D - 1) * HS;
+    const unsigned small_grid = (unsigned)((P + 127) / 128);
     // feature_linear
-    if (!rc) rc = weight_grad(g_blas, s, P, h8, W, W, PERM_ACC, 0, W, w.g_feat, W, W, PERM_ACC, W, w.scratch, gw[D], W, 0);
-    if (!rc) rc = bias_grad(s, P, w.g_feat, W, 0, W, PERM_ACC, W, gb[D]);
-    // alpha_linear: G = column 3 of g_rawb
-    if (!rc) rc = weight_grad(g_blas, s, P, h8, W, W, PERM_ACC, 0, W, w.g_rawb + 3, 4, 1, PERM_NAT, 1, w.scratch, gw[D + 1], W, 0);
-    if (!rc) rc = bias_grad(s, P, w.g_rawb, 4, 3, 1, PERM_NAT, 1, gb[D + 1]);
+    if (!rc) rc = weight_grad(s, P, w.slab, h8, W, PERM_ACC, 0, W, w.g_feat, W, W, gw[D], W, 0, gb[D]);
     // views_linears.0: [feature | dirs]
-    if (!rc) rc = weight_grad(g_blas, s, P, w.sv_feat, W, W, PERM_ACC, 0, W, w.g_hv, W / 2, W / 2, PERM_ACC, W / 2, w.scratch, gw[D + 2], W + icv, 0);
-    if (!rc) rc = weight_grad(g_blas, s, P, w.sv_d, Dd, Dd, PERM_GEN, Ld, icv, w.g_hv, W / 2, W / 2, PERM_ACC, W / 2, w.scratch, gw[D + 2], W + icv, W);
-    if (!rc) rc = bias_grad(s, P, w.g_hv, W / 2, 0, W / 2, PERM_ACC, W / 2, gb[D + 2]);
-    // rgb_linear: G = columns 0..2 of g_rawb
-    if (!rc) rc = weight_grad(g_blas, s, P, w.sv_hv, W / 2, W / 2, PERM_ACC, 0, W / 2, w.g_rawb, 4, 3, PERM_NAT, 3, w.scratch, gw[D + 3], W / 2, 0);
-    if (!rc) rc = bias_grad(s, P, w.g_rawb, 4, 0, 3, PERM_NAT, 3, gb[D + 3]);
-    return rc;
+    if (!rc) rc = weight_grad(s, P, w.slab, w.sv_feat, W, PERM_ACC, 0, W, w.g_hv, W / 2, W / 2, gw[D + 2], W + icv, 0, gb[D + 2]);
+    if (!rc) rc = weight_grad(s, P, w.slab, w.sv_d, Dd, PERM_GEN, Ld, icv, w.g_hv, W / 2, W / 2, gw[D + 2], W + icv, W, nullptr);
+    if (rc) return rc;
+    // alpha_linear (column 3 of g_rawb) and rgb_linear (columns 0..2)
+    hipLaunchKernelGGL(dw_small_kernel<1>, dim3(small_grid), dim3(256), 0, s, w.g_rawb, 3, h8, W, W, P, PERM_ACC, gw[D + 1], W, gb[D + 1]);
+    hipLaunchKernelGGL(dw_small_kernel<3>, dim3(small_grid), dim3(256), 0, s, w.g_rawb, 0, w.sv_hv, W / 2, W / 2, P, PERM_ACC, gw[D + 3], W / 2, gb[D + 3]);
+    return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
 
 }  // namespace na

@@ -121,11 +121,12 @@ int nerf_amd_model_update(nerf_amd_model *m, const float *const *weights, const 
     for (int i = 0; i < n_tensors; ++i)
         if (!weights[i] || !biases[i]) return fail(NERF_AMD_EINVAL, "null parameter pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    m->h_wptrs.assign(weights, weights + n_tensors);
-    m->h_bptrs.assign(biases, biases + n_tensors);
-    HIP_TRY(hipMemcpyAsync(m->d_wptrs, m->h_wptrs.data(), n_tensors * sizeof(float *), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(m->d_bptrs, m->h_bptrs.data(), n_tensors * sizeof(float *), hipMemcpyHostToDevice, s));
-    int rc = launch_pack(p, m->d_frags, m->d_tiles, m->d_layers, m->d_tensors, m->d_wptrs, m->d_bptrs,
+    if (n_tensors > MAX_TENSORS) return fail(NERF_AMD_EINVAL, "too many parameter tensors");
+    PtrTable wt, bt;
+    std::memset(&wt, 0, sizeof(wt));
+    std::memset(&bt, 0, sizeof(bt));
+    for (int i = 0; i < n_tensors; ++i) { wt.p[i] = weights[i]; bt.p[i] = biases[i]; }
+    int rc = launch_pack(p, m->d_frags, m->d_tiles, m->d_layers, m->d_tensors, wt, bt,
                          m->stream_bf16, m->bias_bf16, m->stream_f32, m->bias_f32,
                          m->d_frags16, m->d_tiles16, m->stream_s16, m->bias_s16, m->d_frags_bwd, m->stream_bwd, s);
     if (rc) return fail(rc, "pack launch failed");

@@ -56,9 +56,13 @@ int launch_mlp_bf16(const MlpArgs &a, int multires, int multires_views, int use_
 int launch_mlp_f32(const MlpArgs &a, hipStream_t s);
 int launch_embed(const float *x, int64_t n, int multires, float *out, hipStream_t s);
 
+// Parameter pointers of one model, passed to the pack kernels by value (no host->device copy).
+constexpr int MAX_TENSORS = 72;     // D <= 64 pts_linears + 4 heads
+struct PtrTable { const float *p[MAX_TENSORS]; };
+
 // pack.hip
 int launch_pack(const Program &p, const FragDesc *d_frags, const TileDesc *d_tiles, const LayerF32 *d_layers,
-                const TensorDesc *d_tensors, const float *const *d_weight_ptrs, const float *const *d_bias_ptrs,
+                const TensorDesc *d_tensors, const PtrTable &d_weight_ptrs, const PtrTable &d_bias_ptrs,
                 uint16_t *stream_bf16, float *bias_bf16, float *stream_f32, float *bias_f32,
                 const FragDesc *d_frags16, const TileDesc *d_tiles16, uint16_t *stream_s16, float *bias_s16,
                 const FragDesc *d_frags_bwd, uint16_t *stream_bwd, hipStream_t s);

@@ -38,7 +38,8 @@ NA_HD inline int frag_source(const FragDesc &d, int lane, int j, int n_out, int 
 }
 
 __global__ __launch_bounds__(512) void pack_bf16_kernel(const FragDesc *frags, const TensorDesc *tensors,
-                                                        const float *const *weights, uint16_t *stream) {
+                                                        PtrTable weights_tab, uint16_t *stream) {
+    const float *const *weights = weights_tab.p;
     const FragDesc d = frags[blockIdx.x];
     const int lane = threadIdx.x >> 3, j = threadIdx.x & 7;
     int row;
@@ -49,7 +50,8 @@ __global__ __launch_bounds__(512) void pack_bf16_kernel(const FragDesc *frags, c
 }
 
 __global__ __launch_bounds__(32) void pack_bias_bf16_kernel(const TileDesc *tiles, const TensorDesc *tensors,
-                                                            const float *const *biases, float *table) {
+                                                            PtrTable biases_tab, float *table) {
+    const float *const *biases = biases_tab.p;
     const TileDesc t = tiles[blockIdx.x];
     const int h = threadIdx.x >> 4, r = threadIdx.x & 15;
     const int row = t.row0 + acc_row(r, h);
@@ -57,7 +59,8 @@ __global__ __launch_bounds__(32) void pack_bias_bf16_kernel(const TileDesc *tile
 }
 
 __global__ __launch_bounds__(16) void pack_bias_s16_kernel(const TileDesc *tiles, const TensorDesc *tensors,
-                                                           const float *const *biases, float *table) {
+                                                           PtrTable biases_tab, float *table) {
+    const float *const *biases = biases_tab.p;
     const TileDesc t = tiles[blockIdx.x];
     const int row = t.row0 + threadIdx.x;           // [q][r] with row = 4q + r is just the natural order
     table[blockIdx.x * 16 + threadIdx.x] = row < tensors[t.tensor].n_out ? biases[t.tensor][row] : 0.0f;
@@ -65,8 +68,10 @@ __global__ __launch_bounds__(16) void pack_bias_s16_kernel(const TileDesc *tiles
 
 // fp32 stream: one block per (layer, tile, group); 256 threads = 64 lanes x 4 k-pairs.
 __global__ __launch_bounds__(256) void pack_f32_kernel(const LayerF32 *layers, int n_layers,
-                                                       const float *const *weights, const float *const *biases,
+                                                       PtrTable weights_tab, PtrTable biases_tab,
                                                        float *stream, float *bias_out) {
+    const float *const *weights = weights_tab.p;
+    const float *const *biases = biases_tab.p;
     const LayerF32 L = layers[blockIdx.y];
     const int tiles = (L.n_out + 31) >> 5, groups = (L.n_in + 7) >> 3;
     for (int blk = blockIdx.x; blk < tiles * groups; blk += gridDim.x) {
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(256) void pack_f32_kernel(const LayerF32 *layers, i
 }
 
 int launch_pack(const Program &p, const FragDesc *d_frags, const TileDesc *d_tiles, const LayerF32 *d_layers,
-                const TensorDesc *d_tensors, const float *const *d_w, const float *const *d_b,
+                const TensorDesc *d_tensors, const PtrTable &d_w, const PtrTable &d_b,
                 uint16_t *stream_bf16, float *bias_bf16, float *stream_f32, float *bias_f32,
                 const FragDesc *d_frags16, const TileDesc *d_tiles16, uint16_t *stream_s16, float *bias_s16,
                 const FragDesc *d_frags_bwd, uint16_t *stream_bwd, hipStream_t s) {

@@ -120,9 +120,13 @@ class _FieldTrainFn(torch.autograd.Function):
         dev = ws.device
         g = g_raw.contiguous().float()
         mods = model._linears()
-        gw = [torch.empty_like(m.weight, dtype=torch.float32) for m in mods]
-        gb = [torch.empty_like(m.bias, dtype=torch.float32) for m in mods]
+        # one zeroed buffer for every gradient (the kernels accumulate with atomics), views per tensor
+        sizes = [m.weight.numel() for m in mods] + [m.bias.numel() for m in mods]
+        flat = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
+        views = torch.split(flat, sizes)
         n = len(mods)
+        gw = [v.view_as(m.weight) for v, m in zip(views[:n], mods)]
+        gb = list(views[n:])
         wp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in gw])
         bp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in gb])
         with torch.cuda.device(dev):

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Time one training step of the reference's loop (main.py:67-112 without the data loader):
+N_rand rays -> render (64+128, two 8x256 view-branch models) -> mse(rgb)+mse(rgb0) -> backward -> Adam.
+
+    python tools/train_bench.py [--rays 1024] [--steps 20]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("NERF_AMD_QUIET", "1")
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from nerf_shared_amd import nerf, render_utils, synth  # noqa: E402
+
+ARCH = dict(D=8, W=256, output_ch=5, skips=[4], use_viewdirs=True, multires=10, multires_views=4)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rays", type=int, default=1024)      # N_rand of configs/lego.txt:15
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    models = []
+    for seed in (0, 10):
+        m = nerf.NeRF(**ARCH)
+        m.load_state_dict(synth.torch_state_dict(seed, 1.0, **{**ARCH, "skips": (4,)}))
+        models.append(m.to(dev))
+    r = render_utils.Renderer(perturb=1.0, N_importance=128, N_samples=64, use_viewdirs=True, white_bkgd=True,
+                              raw_noise_std=0.0, near=2.0, far=6.0)
+    opt = torch.optim.Adam(list(models[0].parameters()) + list(models[1].parameters()), lr=5e-4)
+    rng = np.random.default_rng(0)
+    K = synth.lego_intrinsics(400, 400)
+    idx = rng.choice(160000, size=args.rays, replace=False)
+    ro, rd = synth.rays_np(400, 400, K, synth.LEGO_C2W, idx)
+    rays = (torch.from_numpy(ro).to(dev), torch.from_numpy(rd).to(dev))
+    target = torch.rand(args.rays, 3, device=dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        rgb, disp, acc, extras = r.render(400, 400, K, models[0], models[1], chunk=32768, rays=rays, retraw=True)
+        loss = ((rgb - target) ** 2).mean() + ((extras["rgb0"] - target) ** 2).mean()
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    pts = args.rays * 256
+    print(json.dumps({"rays_per_step": args.rays, "ms_per_step": dt * 1e3, "steps_per_s": 1 / dt,
+                      "rays_per_s": args.rays / dt, "loss": float(loss),
+                      "model_tflops": pts * 1186816 * 3 / dt / 1e12}))
+
+
+if __name__ == "__main__":
+    main()
