@@ -6,8 +6,9 @@ Signatures, attribute names and state_dict keys follow the reference
 (`coarse_model_state_dict` / `fine_model_state_dict`, utils.py:450-455) loads
 with ``load_state_dict`` unchanged.
 
-Forward only: outputs never carry autograd history (SURVEY.md section 8f ranks the
-backward pass as the next row).
+Inference runs the forward-only kernels.  With gradients enabled, the standard model
+(D=8, W=256, skips=[4], viewdirs, multires 10/4, bf16) runs the training kernels and
+loss.backward() reaches its parameters (no ray gradients yet).
 """
 import ctypes
 import weakref

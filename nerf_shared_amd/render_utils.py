@@ -12,7 +12,7 @@ edges of the hot path:
     reference's seeded numpy draws bit for bit;
   * the NaN/Inf scan of every output (render_utils.py:170-172) only runs when
     DEBUG is set -- it never changes outputs and costs a device sync per key;
-  * forward only (no autograd history on the outputs).
+  * autograd reaches the models' parameters (standard model, bf16), not the rays.
 """
 import os
 
