@@ -172,7 +172,8 @@ class WaveEmu16:
         return out
 
 
-def emulate16(arch, sd, pts, dirs):
+def emulate16(arch, sd, pts, dirs, keep=None):
+    """`keep` (dict) receives the fragment lists of every layer output (the training forward's saves)."""
     LX, LD, VD = arch["multires"], arch["multires_views"], arch["use_viewdirs"]
     KE, KD = gen16_ksteps(LX), (gen16_ksteps(LD) if VD else 0)
     stream, bias = host_pack(arch, sd, 16)
@@ -182,14 +183,17 @@ def emulate16(arch, sd, pts, dirs):
     F_HEAD = F_L6 + 256
     w = WaveEmu16(stream, bias)
     E = w.encode(O.embed(torch.from_numpy(pts), LX).numpy(), LX, KE)
-    A = w.layer(0, 0, 8, E, KE)
-    B = w.layer(F_L1, 16, 8, A, 8)
-    A = w.layer(F_L1 + 128, 32, 8, B, 8)
-    B = w.layer(F_L1 + 256, 48, 8, A, 8)
-    A = w.layer(F_L1 + 384, 64, 8, B, 8)
-    B = w.layer(F_L5, 80, 8, E, KE, A, 8)
-    A = w.layer(F_L6, 96, 8, B, 8)
-    B = w.layer(F_L6 + 128, 112, 8, A, 8)
+    hs = []
+    A = w.layer(0, 0, 8, E, KE); hs.append(A)
+    B = w.layer(F_L1, 16, 8, A, 8); hs.append(B)
+    A = w.layer(F_L1 + 128, 32, 8, B, 8); hs.append(A)
+    B = w.layer(F_L1 + 256, 48, 8, A, 8); hs.append(B)
+    A = w.layer(F_L1 + 384, 64, 8, B, 8); hs.append(A)
+    B = w.layer(F_L5, 80, 8, E, KE, A, 8); hs.append(B)
+    A = w.layer(F_L6, 96, 8, B, 8); hs.append(A)
+    B = w.layer(F_L6 + 128, 112, 8, A, 8); hs.append(B)
+    if keep is not None:
+        keep["h"] = hs
     out = np.zeros((32, 4 if VD else arch["output_ch"]), np.float32)
     if VD:
         Dv = w.encode(O.embed(torch.from_numpy(dirs), LD).numpy(), LD, KD)
@@ -200,6 +204,8 @@ def emulate16(arch, sd, pts, dirs):
         A = w.layer(F_HEAD, 128, 8, B, 8, relu=False)
         alpha = w.tile_single(F_ALPHA, 144, B, 8)
         B2 = w.layer(F_VIEWS, 145, 4, A, 8, Dv, KD)
+        if keep is not None:
+            keep["feat"], keep["hv"] = A, B2
         rgb = w.tile_single(F_RGB, 153, B2, 4)
         for cc in range(2):
             out[16 * cc:16 * cc + 16, 0:3] = rgb[cc][:16, 0:3]
@@ -345,6 +351,83 @@ def test_s16_stream_matches_kernel_dataflow(arch):
     dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
     sd = synth.make_state_dict(3, 3.0, **{**arch, "skips": tuple(arch["skips"])})
     np.testing.assert_allclose(emulate16(arch, sd, pts, dirs), plain_bf16(arch, sd, pts, dirs), atol=2e-3, rtol=2e-3)
+
+
+def frags_to_rows(frags, n_ks):
+    """[2*n_ks] fragments [64, 8] -> natural-order rows [32 points, 32*n_ks features] (acc16 slot order undone)."""
+    rows = np.zeros((32, 32 * n_ks), np.float32)
+    for ks in range(n_ks):
+        for cc in range(2):
+            f = frags[2 * ks + cc]
+            for l in range(64):
+                q = l >> 4
+                for j in range(8):
+                    rows[16 * cc + (l & 15), 32 * ks + 16 * (j >> 2) + 4 * q + (j & 3)] = f[l, j]
+    return rows
+
+
+def test_backward_stream_matches_kernel_dataflow():
+    """mlp_bwd_s16.hip's dX chain replayed on the host-packed transposed stream (shape 17): the
+    pre-activation gradients of every layer against a plain numpy backward with the same roundings."""
+    arch = CASES[0]
+    rng = np.random.default_rng(9)
+    pts = rng.uniform(-3, 3, size=(32, 3)).astype(np.float32)
+    dirs = rng.normal(size=(32, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    sd = synth.make_state_dict(3, 2.0, **{**arch, "skips": tuple(arch["skips"])})
+    keep = {}
+    emulate16(arch, sd, pts, dirs, keep)
+    g_raw = rng.normal(size=(32, 4)).astype(np.float32)
+    stream, _ = host_pack(arch, sd, 17)
+    assert stream.shape[0] % 192 == 0 and stream.shape[0] >= 1112
+    w = WaveEmu16(stream, np.zeros((400, 16), np.float32))
+
+    def gen_frag(cols):                      # FRAG_TG16 operand: k slot (q=0, j) = column j of g_raw
+        out = []
+        for cc in range(2):
+            f = np.zeros((64, 8), np.float32)
+            for l in range(16):
+                for j, c in enumerate(cols):
+                    f[l, j] = g_raw[16 * cc + l, c]
+            out.append(bf16_round(f))
+        return out
+
+    def tlayer(f0, npair, x1, k1, x2=None, k2=0, mask=None):
+        g = w.layer(f0, 0, npair, x1, k1, x2, k2, relu=False)       # bias table is zero here
+        if mask is not None:
+            g = [np.where(m != 0, v, 0).astype(np.float32) for v, m in zip(g, mask)]
+        return g
+
+    Grgb, Gsig = gen_frag([0, 1, 2]), gen_frag([3])
+    G = {}
+    G["hv"] = tlayer(0, 4, Grgb, 1, mask=keep["hv"])
+    G["feat"] = tlayer(8, 8, G["hv"], 4)
+    g = tlayer(72, 8, G["feat"], 8, Gsig, 1, mask=keep["h"][7])
+    G[7] = g
+    for n, l in enumerate(range(6, -1, -1)):
+        g = tlayer(216 + 128 * n, 8, g, 8, mask=keep["h"][l])
+        G[l] = g
+
+    # plain numpy backward on natural-order rows with the same bf16 roundings
+    Wb = {k: bf16_round(v).astype(np.float64) for k, v in sd.items() if k.endswith("weight")}
+    rb = lambda v: bf16_round(v.astype(np.float32)).astype(np.float64)   # noqa: E731
+    h = [frags_to_rows(f, 8).astype(np.float64) for f in keep["h"]]
+    hv = frags_to_rows(keep["hv"], 4).astype(np.float64)
+    gr = rb(g_raw)
+    g_hv = rb((gr[:, 0:3] @ Wb["rgb_linear.weight"]) * (hv != 0))
+    g_feat = rb(g_hv @ Wb["views_linears.0.weight"][:, :256])
+    g8 = rb((g_feat @ Wb["feature_linear.weight"] + gr[:, 3:4] @ Wb["alpha_linear.weight"]) * (h[7] != 0))
+    ref = {"hv": g_hv, "feat": g_feat, 7: g8}
+    g_prev = g8
+    for l in range(7, 0, -1):
+        Wl = Wb["pts_linears.%d.weight" % l]
+        if Wl.shape[1] == 319:
+            Wl = Wl[:, 63:]
+        g_prev = rb((g_prev @ Wl) * (h[l - 1] != 0))
+        ref[l - 1] = g_prev
+    for key, n_ks in (("hv", 4), ("feat", 8), (7, 8), (4, 8), (0, 8)):
+        got = frags_to_rows(G[key], n_ks)
+        np.testing.assert_allclose(got, ref[key], atol=2e-2 * float(np.abs(ref[key]).max()), rtol=0, err_msg=str(key))
 
 
 def test_gen16_layout_is_a_bijection():
