@@ -2,11 +2,14 @@
 warp, hierarchical sampling, metrics and the two factories that build models
 and renderers from an argparse namespace.
 
-Reference: /root/reference/nerf_shared/utils.py:24-161.  Dataset loaders,
-checkpoint I/O and the training-batch plumbing (utils.py:174-494) are outside
-the hot path and are not reproduced.
+Reference: /root/reference/nerf_shared/utils.py:24-161 for the hot path.  From the
+callers either side of it this module also carries the optimizer
+factory and checkpoint format (utils.py:163-214, :444-456) and a device-resident version
+of the training ray batching (utils.py:360-442).  Dataset loaders are not reproduced
+(no datasets offline).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -157,3 +160,109 @@ def get_renderer(args, bds_dict):
         render_kwargs['ndc'] = False
     render_kwargs.update(bds_dict)
     return render_utils.Renderer(**render_kwargs)
+
+
+# ---------------------------------------------------------------- optimizer + checkpoints (utils.py:163-214, 444-456)
+def get_optimizer(coarse_model, fine_model, args):
+    """Adam over both models' parameters, lr = args.lrate (utils.py:163-172)."""
+    params = list(coarse_model.parameters())
+    if fine_model is not None:
+        params += list(fine_model.parameters())
+    return torch.optim.Adam(params=params, lr=args.lrate, betas=(0.9, 0.999))
+
+
+def save_checkpoints(args, coarse_model, fine_model, optimizer, global_step, i):
+    """<basedir>/<expname>/<i:06d>.tar with the reference's four keys (utils.py:444-456), so
+    checkpoints move freely between this package and the reference."""
+    path = os.path.join(args.basedir, args.expname, '{:06d}.tar'.format(i))
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    torch.save({
+        'global_step': global_step,
+        'coarse_model_state_dict': coarse_model.state_dict(),
+        'fine_model_state_dict': fine_model.state_dict() if fine_model is not None else None,
+        'optimizer_state_dict': optimizer.state_dict(),
+    }, path)
+    print('Saved checkpoints at', path)
+    return path
+
+
+def load_checkpoint(coarse_model, fine_model, optimizer, args, b_load_ckpnt_as_trainable=False, checkpoint_index=None):
+    """Reload the newest (or the indexed) *.tar of the experiment, or args.ft_path (utils.py:174-214).
+    Returns the stored global_step (0 when nothing was loaded)."""
+    if getattr(args, 'ft_path', None) is not None and args.ft_path != 'None':
+        ckpts = [args.ft_path]
+    else:
+        folder = os.path.join(args.basedir, args.expname)
+        ckpts = [os.path.join(folder, f) for f in sorted(os.listdir(folder)) if 'tar' in f] if os.path.isdir(folder) else []
+    print('Found ckpts', ckpts)
+    if not ckpts or getattr(args, 'no_reload', False):
+        return 0
+    path = ckpts[checkpoint_index] if checkpoint_index is not None else ckpts[-1]
+    print('Reloading from', path)
+    device = next(coarse_model.parameters()).device
+    ckpt = torch.load(path, map_location=device)
+    if optimizer is not None:
+        optimizer.load_state_dict(ckpt['optimizer_state_dict'])
+    coarse_model.load_state_dict(ckpt['coarse_model_state_dict'], strict=False)
+    coarse_model.requires_grad_(b_load_ckpnt_as_trainable)
+    if fine_model is not None:
+        fine_model.load_state_dict(ckpt['fine_model_state_dict'])
+        fine_model.requires_grad_(b_load_ckpnt_as_trainable)
+    return ckpt['global_step']
+
+
+# ---------------------------------------------------------------- training ray batches (utils.py:360-442)
+def batch_training_data(args, poses, hwf, K, images, i_train):
+    """Device-resident version of utils.py:360-392: with ray batching (not args.no_batching) the
+    rays of every training image are generated on the GPU (make_rays kernel, no host meshgrid),
+    joined with their pixels into rays_rgb [N_train*H*W, 3, 3] = (origin, direction, colour) and
+    shuffled there.  Returns the reference's tuple."""
+    H, W = int(hwf[0]), int(hwf[1])
+    device = _default_device()
+    images = torch.as_tensor(np.asarray(images), dtype=torch.float32, device=device) if not isinstance(images, torch.Tensor) \
+        else images.to(device).float()
+    poses = torch.as_tensor(np.asarray(poses), dtype=torch.float32, device=device) if not isinstance(poses, torch.Tensor) \
+        else poses.to(device).float()
+    use_batching = not args.no_batching
+    if not use_batching:
+        return images, poses, torch.empty(0, device=device), use_batching, args.N_rand, None
+    blocks = []
+    for i in i_train:
+        b = make_ray_batch(H, W, K, poses[i, :3, :4], 0.0, 1.0, False, False, device=device)     # [H*W, 8]
+        blocks.append(torch.stack([b[:, 0:3], b[:, 3:6], images[i].reshape(-1, 3)[:, :3]], 1))  # [H*W, 3, 3]
+    rays_rgb = torch.cat(blocks, 0)
+    rays_rgb = rays_rgb[torch.randperm(rays_rgb.shape[0], device=device)]
+    return images, poses, rays_rgb, use_batching, args.N_rand, 0
+
+
+def sample_random_ray_batch(args, images, poses, rays_rgb, N_rand, use_batching, i_batch, i_train, hwf, K, start, i):
+    """One training batch (utils.py:394-442): the next N_rand rows of the shuffled ray bank
+    (reshuffled on the device after an epoch), or N_rand random pixels of one random training
+    image, centre-cropped during the first args.precrop_iters iterations.
+    Returns batch_rays [2, N_rand, 3], target_s [N_rand, 3], rays_rgb, i_batch."""
+    H, W = int(hwf[0]), int(hwf[1])
+    if use_batching:
+        batch = rays_rgb[i_batch:i_batch + N_rand].transpose(0, 1)
+        batch_rays, target_s = batch[:2], batch[2]
+        i_batch += N_rand
+        if i_batch >= rays_rgb.shape[0]:
+            print("Shuffle data after an epoch!")
+            rays_rgb = rays_rgb[torch.randperm(rays_rgb.shape[0], device=rays_rgb.device)]
+            i_batch = 0
+        return batch_rays, target_s, rays_rgb, i_batch
+    img_i = int(np.random.choice(i_train))
+    target = images[img_i]
+    rays_o, rays_d = get_rays(H, W, K, poses[img_i, :3, :4])
+    if i < getattr(args, 'precrop_iters', 0):
+        dH, dW = int(H // 2 * args.precrop_frac), int(W // 2 * args.precrop_frac)
+        ys = torch.arange(H // 2 - dH, H // 2 + dH, device=target.device)
+        xs = torch.arange(W // 2 - dW, W // 2 + dW, device=target.device)
+        if i == start:
+            print(f"[Config] Center cropping of size {2*dH} x {2*dW} is enabled until iter {args.precrop_iters}")
+    else:
+        ys, xs = torch.arange(H, device=target.device), torch.arange(W, device=target.device)
+    n = ys.numel() * xs.numel()
+    sel = torch.randperm(n, device=target.device)[:N_rand]            # without replacement, as np.random.choice(replace=False)
+    yy, xx = ys[sel // xs.numel()], xs[sel % xs.numel()]
+    batch_rays = torch.stack([rays_o[yy, xx], rays_d[yy, xx]], 0)
+    return batch_rays, target[yy, xx][:, :3], rays_rgb, i_batch

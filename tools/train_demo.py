@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""End-to-end training demo on a synthetic scene (no datasets offline): a shaded sphere on a
+white background, rendered analytically from poses on a camera circle, is learned by a fresh
+coarse+fine NeRF pair with the reference's loop (main.py:67-112: random ray batches -> render ->
+mse(rgb) + mse(rgb0) -> Adam with exponential lr decay).  Prints PSNR on a held-out view.
+
+    python tools/train_demo.py [--steps 600] [--res 64] [--views 12]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("NERF_AMD_QUIET", "1")
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from nerf_shared_amd import nerf, render_utils, synth, utils  # noqa: E402
+
+
+def sphere_image(H, W, K, c2w, dev, radius=1.0):
+    """Analytic target: Lambert-shaded unit sphere at the origin, white background."""
+    ro, rd = utils.get_rays(H, W, K, torch.from_numpy(c2w))
+    rd_n = rd / rd.norm(dim=-1, keepdim=True)
+    b = (ro * rd_n).sum(-1)
+    disc = b * b - ((ro * ro).sum(-1) - radius * radius)
+    hit = disc > 0
+    t = -b - torch.sqrt(disc.clamp_min(0))
+    n = (ro + rd_n * t[..., None]) / radius
+    light = torch.tensor([0.5, 0.4, 0.77], device=dev)
+    shade = (n * light).sum(-1).clamp(0.1, 1.0)
+    base = 0.5 + 0.5 * n                                    # normal-coloured albedo
+    img = torch.where(hit[..., None], base * shade[..., None], torch.ones_like(base))
+    return img
+
+
+def run(steps=600, res=64, views=12, n_rand=1024, seed=0, verbose=True):
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    dev = torch.device("cuda:0")
+    H = W = res
+    K = synth.lego_intrinsics(H, W)
+    poses = np.stack([np.concatenate([synth.pose_spherical(th, -30.0 + 20.0 * np.sin(i)), [[0, 0, 0, 1]]], 0)
+                      for i, th in enumerate(np.linspace(-180, 180, views + 1)[:-1])], 0).astype(np.float32)
+    images = torch.stack([sphere_image(H, W, K, p[:3, :4], dev) for p in poses], 0)
+    i_train, i_test = list(range(1, views)), 0
+    args = SimpleNamespace(N_rand=n_rand, no_batching=False, lrate=5e-4, lrate_decay=250, netdepth=8, netwidth=256,
+                           netdepth_fine=8, netwidth_fine=256, N_importance=128, use_viewdirs=True, multires=10,
+                           multires_views=4, i_embed=0)
+    coarse, fine = utils.create_nerf_models(args, dev)
+    renderer = render_utils.Renderer(perturb=1.0, N_importance=128, N_samples=64, use_viewdirs=True, white_bkgd=True,
+                                     raw_noise_std=0.0, near=2.0, far=6.0)
+    opt = utils.get_optimizer(coarse, fine, args)
+    images, poses_t, rays_rgb, use_batching, N_rand, i_batch = utils.batch_training_data(args, poses, (H, W, K[0][0]), K, images, i_train)
+
+    def test_psnr():
+        with torch.no_grad():
+            rgb = renderer.render(H, W, K, coarse, fine, chunk=32768, c2w=poses_t[i_test, :3, :4], retraw=False)[0]
+            return float(utils.mse2psnr(utils.img2mse(rgb, images[i_test])))
+
+    psnr0 = test_psnr()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        batch_rays, target, rays_rgb, i_batch = utils.sample_random_ray_batch(args, images, poses_t, rays_rgb, N_rand, use_batching,
+                                                                              i_batch, i_train, (H, W, K[0][0]), K, 0, i)
+        opt.zero_grad(set_to_none=True)
+        rgb, disp, acc, extras = renderer.render_from_rays(H, W, K, 32768, batch_rays, coarse, fine, retraw=True)
+        loss = utils.img2mse(rgb, target) + utils.img2mse(extras['rgb0'], target)
+        loss.backward()
+        opt.step()
+        new_lr = args.lrate * (0.1 ** (i / (args.lrate_decay * 1000)))          # main.py:108-112
+        for g in opt.param_groups:
+            g['lr'] = new_lr
+        if verbose and (i + 1) % 100 == 0:
+            print("step %d loss %.5f" % (i + 1, float(loss.detach())))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"steps": steps, "rays_per_step": n_rand, "train_s": dt, "steps_per_s": steps / dt,
+           "psnr_before": psnr0, "psnr_after": test_psnr(), "final_loss": float(loss.detach())}
+    return out, (coarse, fine, opt, args)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=600)
+    ap.add_argument("--res", type=int, default=64)
+    ap.add_argument("--views", type=int, default=12)
+    a = ap.parse_args()
+    print(json.dumps(run(a.steps, a.res, a.views)[0]))
