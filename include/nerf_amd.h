@@ -135,17 +135,20 @@ int nerf_amd_raw2outputs(const float *raw, int32_t raw_ch, const float *z_vals,
                          float *rgb_map, float *disp_map, float *acc_map, float *weights,
                          float *depth_map, void *stream);
 
-/* Backward of raw2outputs with respect to raw (what autograd derives from render_utils.py:241-290):
- * upstream gradients of the five outputs (any may be NULL) -> g_raw [R,S,raw_ch].  SURVEY.md section 8f-1. */
+/* Backward of raw2outputs (what autograd derives from render_utils.py:241-290): upstream gradients of
+ * the five outputs (any may be NULL) -> g_raw [R,S,raw_ch] and, if asked, g_rays_d [R,3] (the
+ * dependence of dists on |rays_d|, :259).  z_vals are constants.  SURVEY.md section 8f-1. */
 int nerf_amd_raw2outputs_backward(const float *raw, int32_t raw_ch, const float *z_vals, const float *rays_d,
                                   int32_t rays_d_stride, const float *noise, int64_t R, int32_t S, int white_bkgd,
                                   const float *g_rgb_map, const float *g_disp_map, const float *g_acc_map,
-                                  const float *g_depth_map, const float *g_weights, float *g_raw, void *stream);
+                                  const float *g_depth_map, const float *g_weights, float *g_raw,
+                                  float *g_rays_d /* [R,3] or NULL */, void *stream);
 
 /* ------------------------------------------------------------------------
  * Training (what loss.backward() does through NeRF.forward, main.py:85-104).
- * Covered: the D=8, W=256, skips=[4], multires 10/4 view-branch model, parameter gradients
- * (the encodings are constants: no ray gradients yet), bf16 operands / fp32 accumulation.
+ * Covered: the D=8, W=256, skips=[4], multires 10/4 view-branch model; gradients of the parameters,
+ * of the points / rays (through the positional encoding) and of the view directions; bf16 operands /
+ * fp32 accumulation.
  *   forward_train : the fused bf16 forward (explicit pts + viewdirs, or rays + z_vals with pts = o + d z) that also saves every
  *                   layer's activations in `workspace` (nerf_amd_train_workspace bytes, 256-B aligned)
  *   backward      : dL/draw [P,4] -> gradients of every nn.Linear weight [out,in] and bias [out]
@@ -158,9 +161,14 @@ int     nerf_amd_field_forward_train(const nerf_amd_model *m, const float *pts /
                                      const float *viewdirs /* [R,3], with pts */, const float *rays /* [R,11], without pts */,
                                      int32_t ray_ch, const float *z_vals, int64_t R, int32_t S, float *raw,
                                      void *workspace, int64_t workspace_bytes, void *stream);
-int     nerf_amd_field_backward(const nerf_amd_model *m, const float *g_raw, int64_t n_points, void *workspace,
-                                int64_t workspace_bytes, float *const *grad_weights, float *const *grad_biases,
-                                int n_tensors, void *stream);
+int     nerf_amd_field_backward(const nerf_amd_model *m, const float *g_raw /* [R*S,4] */,
+                                const float *pts, const float *viewdirs, const float *rays, int32_t ray_ch,
+                                const float *z_vals, int64_t R, int32_t S /* the forward_train inputs */,
+                                void *workspace, int64_t workspace_bytes, float *const *grad_weights,
+                                float *const *grad_biases, int n_tensors,
+                                float *g_pts /* [R*S,3] overwritten, pts mode, or NULL */,
+                                float *g_rays /* [R,6] dL/d(o,d), accumulated (pass zeros), rays mode, or NULL */,
+                                float *g_viewdirs /* [R,3] accumulated (pass zeros), or NULL */, void *stream);
 
 /* ------------------------------------------------------------------------
  * a11  utils.sample_pdf                       utils.py:74-117

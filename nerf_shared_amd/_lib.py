@@ -76,7 +76,7 @@ def _load():
                                          c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
         "nerf_amd_raw2outputs_backward": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32,
                                                   c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                                  c_void_p]),
+                                                  c_void_p, c_void_p]),
         "nerf_amd_sample_pdf": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
                                         c_void_p, c_void_p]),
         "nerf_amd_render_rays_workspace": (c_int64, [POINTER(RenderCfg), c_int64, c_int32]),
@@ -91,7 +91,8 @@ def _load():
         "nerf_amd_train_workspace": (c_int64, [c_void_p, c_int64]),
         "nerf_amd_field_forward_train": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32,
                                                  c_void_p, c_void_p, c_int64, c_void_p]),
-        "nerf_amd_field_backward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, pp_f, pp_f, c_int, c_void_p]),
+        "nerf_amd_field_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32,
+                                            c_void_p, c_int64, pp_f, pp_f, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
         "nerf_amd_profile_enable": (c_int, [c_int]),
         "nerf_amd_profile_collect": (c_int, [POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),
     }

@@ -301,10 +301,14 @@ int nerf_amd_field_forward_train(const nerf_amd_model *m, const float *pts, cons
     return rc ? fail(rc, "training forward launch failed") : NERF_AMD_OK;
 }
 
-int nerf_amd_field_backward(const nerf_amd_model *m, const float *g_raw, int64_t n_points, void *workspace,
-                            int64_t workspace_bytes, float *const *grad_weights, float *const *grad_biases,
-                            int n_tensors, void *stream) {
-    if (!m || n_points < 0 || !grad_weights || !grad_biases) return fail(NERF_AMD_EINVAL, "bad backward arguments");
+int nerf_amd_field_backward(const nerf_amd_model *m, const float *g_raw, const float *pts, const float *viewdirs,
+                            const float *rays, int32_t ray_ch, const float *z_vals, int64_t R, int32_t S,
+                            void *workspace, int64_t workspace_bytes, float *const *grad_weights,
+                            float *const *grad_biases, int n_tensors, float *g_pts, float *g_rays, float *g_viewdirs,
+                            void *stream) {
+    const int64_t n_points = R * S;
+    if (!m || R < 0 || S < 1 || !grad_weights || !grad_biases) return fail(NERF_AMD_EINVAL, "bad backward arguments");
+    if ((!pts && (ray_ch != 11 || !rays || !z_vals)) || (pts && !viewdirs)) return fail(NERF_AMD_EINVAL, "backward needs the forward's inputs (pts + viewdirs, or rays [R,11] + z_vals)");
     if (!train_supported(m->prog)) return fail(NERF_AMD_EUNSUPPORTED, "training kernels cover the D=8, W=256, skips=[4], multires 10/4 view-branch model");
     if (n_tensors != (int)m->prog.tensors.size()) return fail(NERF_AMD_EINVAL, "wrong number of gradient tensors");
     if (n_points == 0) return NERF_AMD_OK;
@@ -313,7 +317,10 @@ int nerf_amd_field_backward(const nerf_amd_model *m, const float *g_raw, int64_t
     hipStream_t s = static_cast<hipStream_t>(stream);
     MlpArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.stream_bwd = m->stream_bwd; a.g_raw = g_raw; a.P = n_points;
+    a.stream_bwd = m->stream_bwd; a.g_raw = g_raw; a.P = n_points; a.S = S;
+    if (pts) { a.pts = pts; a.viewdirs = viewdirs; a.vd_stride = 3; }
+    else { a.rays = rays; a.ray_stride = ray_ch; a.z_vals = z_vals; a.viewdirs = rays + 8; a.vd_stride = ray_ch; }
+    a.g_pts = g_pts; a.g_rays = g_rays; a.g_vd = g_viewdirs;
     train_fill_args(m->prog, n_points, workspace, &a);
     int rc = launch_mlp_bwd_s16(a, m->prog.n_frags_bwd_used, s);
     if (rc) return fail(rc, "backward kernel launch failed");
@@ -334,11 +341,13 @@ int nerf_amd_raw2outputs(const float *raw, int32_t raw_ch, const float *z_vals, 
 int nerf_amd_raw2outputs_backward(const float *raw, int32_t raw_ch, const float *z_vals, const float *rays_d,
                                   int32_t rays_d_stride, const float *noise, int64_t R, int32_t S, int white_bkgd,
                                   const float *g_rgb_map, const float *g_disp_map, const float *g_acc_map,
-                                  const float *g_depth_map, const float *g_weights, float *g_raw, void *stream) {
+                                  const float *g_depth_map, const float *g_weights, float *g_raw, float *g_rays_d,
+                                  void *stream) {
     if (R < 0 || S < 1 || raw_ch < 4 || (R > 0 && (!raw || !z_vals || !rays_d || !g_raw)))
         return fail(NERF_AMD_EINVAL, "bad raw2outputs_backward arguments");
     int rc = launch_composite_bwd(raw, raw_ch, z_vals, rays_d, rays_d_stride, noise, R, S, white_bkgd, g_rgb_map,
-                                  g_disp_map, g_acc_map, g_depth_map, g_weights, g_raw, static_cast<hipStream_t>(stream));
+                                  g_disp_map, g_acc_map, g_depth_map, g_weights, g_raw, g_rays_d,
+                                  static_cast<hipStream_t>(stream));
     return rc ? fail(rc, "composite backward launch failed (S must be <= 2048)") : NERF_AMD_OK;
 }
 

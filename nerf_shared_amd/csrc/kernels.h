@@ -47,6 +47,9 @@ struct MlpArgs {
     uint16_t *g_feat;              // [P, 256]
     uint16_t *g_h;                 // [8][P, 256]  dL/d(pre-activation) of pts_linears.0..7
     const uint16_t *stream_bwd;    // transposed-weight fragment stream
+    float *g_pts;                  // [P, 3]  dL/dpts (explicit-points mode), overwritten; or NULL
+    float *g_rays;                 // [R, 6]  dL/d(origin, direction) accumulated with atomics (rays mode); or NULL
+    float *g_vd;                   // [R, 3]  dL/d(view direction) accumulated with atomics; or NULL
 };
 
 extern int g_variant;
@@ -89,7 +92,8 @@ int launch_composite(const float *raw, int raw_ch, const float *z, const float *
                      float *weights, float *depth, hipStream_t s);
 int launch_composite_bwd(const float *raw, int raw_ch, const float *z, const float *rays_d, int rays_d_stride,
                          const float *noise, int64_t R, int S, int white_bkgd, const float *g_rgb, const float *g_disp,
-                         const float *g_acc, const float *g_depth, const float *g_weights, float *g_raw, hipStream_t s);
+                         const float *g_acc, const float *g_depth, const float *g_weights, float *g_raw, float *g_rays_d,
+                         hipStream_t s);
 int launch_sample_pdf(const float *bins, const float *weights, const float *u, const float *t_lin,
                       int64_t R, int n_bins, int n_samples, float *samples, hipStream_t s);
 int launch_resample(const float *z_coarse, const float *weights, const float *u, const float *t_lin,

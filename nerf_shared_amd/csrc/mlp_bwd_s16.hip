@@ -10,7 +10,9 @@
 // ReLU masks come from the activations the training forward saved; every g_pre(l) is
 // written to HBM (slot-major bf16 rows, same layout as the saved activations) for the
 // weight-gradient GEMMs  dW_l = g_pre(l)^T h_{l-1}  that follow (backward.hip).
-// Encodings are treated as constants (no ray gradients yet).
+// Ray gradients: the gradient with respect to the encodings (three more transposed products whose
+// rows are encoding slots, FRAG_TE16) is pushed through d/dx sin(2^f x) = 2^f cos(2^f x) in
+// registers and summed per point (pts mode) or per ray (rays mode: dL/do += g, dL/dd += z g).
 #include <hip/hip_runtime.h>
 #include <utility>
 
@@ -95,12 +97,78 @@ __device__ __forceinline__ void tlayer(C &c, const bf16x8 *x1, const bf16x8 *x2,
     });
 }
 
+// Gradient of a generated encoding (encode16 of mlp_bf16_s16.hip) with respect to its 3 inputs:
+// g[i] is dL/d(slot i) of this lane's slots (same order as encode16's vals[]).
+template <int L, int K>
+__device__ __forceinline__ void encode16_bwd(float x0, float x1, float x2, int h, int b, const float *g, float (&gx)[3]) {
+    constexpr float INV2PI_HI = 0.15915494f;
+    constexpr float INV2PI_LO = (float)(0.15915494309189535 - (double)INV2PI_HI);
+    constexpr int NSTEP = (L + 1) / 2, CAP = 8 * K;
+    constexpr int N_EVEN = gen16_ntrig(L, 0), N_ODD = gen16_ntrig(L, 1);
+    const float x[3] = {x0, x1, x2};
+    const float phase = (h ? 0.25f : 0.0f) + 0.25f;          // cos(u) = sin(u + 1/4 turn): derivative of the forward value
+    const float s0 = b ? 2.0f : 1.0f;
+    const int n_mine = b ? N_ODD : N_EVEN;
+    float ra[3], tl[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float th = x[c] * INV2PI_HI;
+        tl[c] = (__builtin_fmaf(x[c], INV2PI_HI, -th) + x[c] * INV2PI_LO) * s0;
+        ra[c] = __builtin_amdgcn_fractf(th * s0);
+    }
+    float scale = s0;                                         // 2^f of the current step
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (3 * s + c < CAP) {
+                const float dv = __builtin_amdgcn_sinf(ra[c] + (tl[c] + phase)) * scale;
+                gx[c] += (3 * s + c < n_mine) ? g[3 * s + c] * dv : 0.0f;
+            }
+            ra[c] = __builtin_amdgcn_fractf(ra[c] * 4.0f);
+            tl[c] *= 4.0f;
+        }
+        scale *= 4.0f;
+    }
+    // raw-coordinate slots: derivative 1
+#pragma unroll
+    for (int i = (N_ODD < N_EVEN ? N_ODD : N_EVEN); i < CAP; ++i) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const bool even_hit = i >= N_EVEN && (h ? gen16_misc(L, 1, 0, i - N_EVEN) : gen16_misc(L, 0, 0, i - N_EVEN)) == c;
+            const bool odd_hit = i >= N_ODD && (h ? gen16_misc(L, 1, 1, i - N_ODD) : gen16_misc(L, 0, 1, i - N_ODD)) == c;
+            gx[c] += (b ? odd_hit : even_hit) ? g[i] : 0.0f;
+        }
+    }
+}
+
+// Transposed products whose rows are the slots of a generated encoding (FRAG_TE16): NPAIR pairs,
+// K1 k-steps of x1 each; g[cc][8*pair + 4*u + r] receives this lane's slot gradients.
+template <int F0, int NPAIR, int K1, int NB, int NFRAGS, class C>
+__device__ __forceinline__ void tenc(C &c, const bf16x8 *x1, float (&g)[2][8 * NPAIR]) {
+    static_for<NPAIR>([&](auto p_) {
+        constexpr int p = p_;
+        f32x4 acc[2][2];
+        tpair<F0 + p * 2 * K1, K1, 0, NB, NFRAGS>(c, x1, x1, acc);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g[cc][8 * p + 4 * u + r] = acc[u][cc][r];
+    });
+}
+
 struct LayoutB {
     static constexpr int F_HV = 0;                 // 4 pairs x 1 k-step
     static constexpr int F_FEAT = F_HV + 8;        // 8 pairs x 4 k-steps
-    static constexpr int F_H8 = F_FEAT + 64;       // 8 pairs x (8 + 1) k-steps
-    static constexpr int F_H7 = F_H8 + 144;        // then 7 layers of 8 pairs x 8 k-steps
-    static constexpr int F_END = F_H7 + 7 * 128;
+    static constexpr int F_DIRS = F_FEAT + 64;     // view-direction encoding slots: 1 pair x 4 k-steps
+    static constexpr int F_H8 = F_DIRS + 8;        // 8 pairs x (8 + 1) k-steps
+    static constexpr int F_L7 = F_H8 + 144;        // pts_linears.7, .6, .5: 8 pairs x 8 k-steps each
+    static constexpr int F_E5 = F_L7 + 3 * 128;    // xyz encoding slots through pts_linears.5: 2 pairs x 8 k-steps
+    static constexpr int F_L4 = F_E5 + 32;         // pts_linears.4 .. .1
+    static constexpr int F_E0 = F_L4 + 4 * 128;    // xyz encoding slots through pts_linears.0
+    static constexpr int F_END = F_E0 + 32;
 };
 
 template <class C>
@@ -120,14 +188,32 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bwd_s16_kernel(MlpArgs a
 
     pipeline_prologue<NB>(c);
 
-    int64_t pidx[2];
+    int64_t pidx[2], rayi[2];
     bool valid[2];
     bf16x8 Grgb[2], Gsig[2];
+    float xp[2][3], dv[2][3], zp[2];
     static_for<2>([&](auto cc_) {
         constexpr int cc = cc_;
         const int64_t p = (int64_t)blockIdx.x * WG_POINTS + c.wave * 32 + cc * 16 + (lane & 15);
         pidx[cc] = p;
         valid[cc] = p < a.P;
+        {
+            const int64_t pc = valid[cc] ? p : a.P - 1;
+            const int64_t ray = (int64_t)((uint32_t)pc / (uint32_t)a.S);
+            rayi[cc] = ray;
+            zp[cc] = 0.f;
+            if (a.pts) {
+                xp[cc][0] = a.pts[3 * pc]; xp[cc][1] = a.pts[3 * pc + 1]; xp[cc][2] = a.pts[3 * pc + 2];
+            } else {
+                const float *r = a.rays + ray * a.ray_stride;
+                zp[cc] = a.z_vals[pc];
+                xp[cc][0] = __fadd_rn(r[0], __fmul_rn(r[3], zp[cc]));
+                xp[cc][1] = __fadd_rn(r[1], __fmul_rn(r[4], zp[cc]));
+                xp[cc][2] = __fadd_rn(r[2], __fmul_rn(r[5], zp[cc]));
+            }
+            const float *d = a.viewdirs + ray * a.vd_stride;
+            dv[cc][0] = d[0]; dv[cc][1] = d[1]; dv[cc][2] = d[2];
+        }
         f32x4 g = {0.f, 0.f, 0.f, 0.f};
         if (valid[cc] && q == 0) g = *reinterpret_cast<const f32x4 *>(a.g_raw + 4 * p);
         bf16x8 r = {}, s = {};
@@ -146,21 +232,60 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bwd_s16_kernel(MlpArgs a
         static_for<C::LA>([&](auto i_) { constexpr int i = i_; c.q[i] = ring_frag<i>(c); });
     }
     const int64_t HS = a.P * 256;
+    const int hh = q >> 1, bb = q & 1;
     bf16x8 A[16], B[16];
+    float gx[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, gd[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     // g_hv = relu'(hv) * (W_rgb^T g_rgb)
     tlayer<LayoutB::F_HV, 4, 1, 0, true, 128, NB, NF>(c, Grgb, Grgb, B, a.sv_hv, a.g_hv, pidx, valid, q);
     // g_feat = W_views[:, :256]^T g_hv          (feature_linear has no activation)
     tlayer<LayoutB::F_FEAT, 8, 4, 0, false, 256, NB, NF>(c, B, B, A, nullptr, a.g_feat, pidx, valid, q);
+    {   // view-direction encoding: g_dirs = W_views[:, 256:]^T g_hv, then through the encoding
+        float g[2][8];
+        tenc<LayoutB::F_DIRS, 1, 4, NB, NF>(c, B, g);
+        static_for<2>([&](auto cc_) { constexpr int cc = cc_; encode16_bwd<4, 1>(dv[cc][0], dv[cc][1], dv[cc][2], hh, bb, g[cc], gd[cc]); });
+    }
     // g_h8 = relu'(h8) * (W_feature^T g_feat + W_alpha^T g_sigma)
     tlayer<LayoutB::F_H8, 8, 8, 1, true, 256, NB, NF>(c, A, Gsig, B, a.sv_h + 7 * HS, a.g_h + 7 * HS, pidx, valid, q);
     // g_h(l-1) = relu'(h(l-1)) * (W_l^T g_h(l)),  l = 7 .. 1   (layer 5 uses the h-columns of its [e | h] input)
-    tlayer<LayoutB::F_H7 + 0 * 128, 8, 8, 0, true, 256, NB, NF>(c, B, B, A, a.sv_h + 6 * HS, a.g_h + 6 * HS, pidx, valid, q);
-    tlayer<LayoutB::F_H7 + 1 * 128, 8, 8, 0, true, 256, NB, NF>(c, A, A, B, a.sv_h + 5 * HS, a.g_h + 5 * HS, pidx, valid, q);
-    tlayer<LayoutB::F_H7 + 2 * 128, 8, 8, 0, true, 256, NB, NF>(c, B, B, A, a.sv_h + 4 * HS, a.g_h + 4 * HS, pidx, valid, q);
-    tlayer<LayoutB::F_H7 + 3 * 128, 8, 8, 0, true, 256, NB, NF>(c, A, A, B, a.sv_h + 3 * HS, a.g_h + 3 * HS, pidx, valid, q);
-    tlayer<LayoutB::F_H7 + 4 * 128, 8, 8, 0, true, 256, NB, NF>(c, B, B, A, a.sv_h + 2 * HS, a.g_h + 2 * HS, pidx, valid, q);
-    tlayer<LayoutB::F_H7 + 5 * 128, 8, 8, 0, true, 256, NB, NF>(c, A, A, B, a.sv_h + 1 * HS, a.g_h + 1 * HS, pidx, valid, q);
-    tlayer<LayoutB::F_H7 + 6 * 128, 8, 8, 0, true, 256, NB, NF>(c, B, B, A, a.sv_h + 0 * HS, a.g_h + 0 * HS, pidx, valid, q);
+    tlayer<LayoutB::F_L7 + 0 * 128, 8, 8, 0, true, 256, NB, NF>(c, B, B, A, a.sv_h + 6 * HS, a.g_h + 6 * HS, pidx, valid, q);
+    tlayer<LayoutB::F_L7 + 1 * 128, 8, 8, 0, true, 256, NB, NF>(c, A, A, B, a.sv_h + 5 * HS, a.g_h + 5 * HS, pidx, valid, q);
+    tlayer<LayoutB::F_L7 + 2 * 128, 8, 8, 0, true, 256, NB, NF>(c, B, B, A, a.sv_h + 4 * HS, a.g_h + 4 * HS, pidx, valid, q);
+    {   // xyz encoding through the skip layer's [input_pts] columns (its pre-activation gradient is still in B)
+        float g[2][16];
+        tenc<LayoutB::F_E5, 2, 8, NB, NF>(c, B, g);
+        static_for<2>([&](auto cc_) { constexpr int cc = cc_; encode16_bwd<10, 2>(xp[cc][0], xp[cc][1], xp[cc][2], hh, bb, g[cc], gx[cc]); });
+    }
+    tlayer<LayoutB::F_L4 + 0 * 128, 8, 8, 0, true, 256, NB, NF>(c, A, A, B, a.sv_h + 3 * HS, a.g_h + 3 * HS, pidx, valid, q);
+    tlayer<LayoutB::F_L4 + 1 * 128, 8, 8, 0, true, 256, NB, NF>(c, B, B, A, a.sv_h + 2 * HS, a.g_h + 2 * HS, pidx, valid, q);
+    tlayer<LayoutB::F_L4 + 2 * 128, 8, 8, 0, true, 256, NB, NF>(c, A, A, B, a.sv_h + 1 * HS, a.g_h + 1 * HS, pidx, valid, q);
+    tlayer<LayoutB::F_L4 + 3 * 128, 8, 8, 0, true, 256, NB, NF>(c, B, B, A, a.sv_h + 0 * HS, a.g_h + 0 * HS, pidx, valid, q);
+    {   // xyz encoding through pts_linears.0
+        float g[2][16];
+        tenc<LayoutB::F_E0, 2, 8, NB, NF>(c, A, g);
+        static_for<2>([&](auto cc_) { constexpr int cc = cc_; encode16_bwd<10, 2>(xp[cc][0], xp[cc][1], xp[cc][2], hh, bb, g[cc], gx[cc]); });
+    }
+    // ---- point / ray gradients: sum the four lane quarters of each point, then one lane per point writes
+    static_for<2>([&](auto cc_) {
+        constexpr int cc = cc_;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            gx[cc][k] += __shfl_xor(gx[cc][k], 16); gx[cc][k] += __shfl_xor(gx[cc][k], 32);
+            gd[cc][k] += __shfl_xor(gd[cc][k], 16); gd[cc][k] += __shfl_xor(gd[cc][k], 32);
+        }
+        if (valid[cc] && q == 0) {
+            if (a.g_pts) { a.g_pts[3 * pidx[cc]] = gx[cc][0]; a.g_pts[3 * pidx[cc] + 1] = gx[cc][1]; a.g_pts[3 * pidx[cc] + 2] = gx[cc][2]; }
+            if (a.g_rays) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    atomicAdd(a.g_rays + rayi[cc] * 6 + k, gx[cc][k]);
+                    atomicAdd(a.g_rays + rayi[cc] * 6 + 3 + k, gx[cc][k] * zp[cc]);
+                }
+            }
+            if (a.g_vd)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) atomicAdd(a.g_vd + rayi[cc] * 3 + k, gd[cc][k]);
+        }
+    });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // no LDS-DMA may outlive the workgroup
 }
 

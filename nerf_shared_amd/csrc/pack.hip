@@ -19,11 +19,17 @@ NA_HD inline uint16_t f32_to_bf16_rne(float f) {
 
 // Weight column (inside the tensor) held by element j of lane `lane` of fragment d, or -1.
 NA_HD inline int frag_source(const FragDesc &d, int lane, int j, int n_out, int *row) {
-    if (d.kind == FRAG_T16 || d.kind == FRAG_TG16) {      // transposed: *row = output feature, column = input feature
+    if (d.kind == FRAG_T16 || d.kind == FRAG_TG16 || d.kind == FRAG_TE16) {   // transposed: *row = output feature, column = input feature
         const int i = lane & 15, q = lane >> 4;
-        const int o = d.kind == FRAG_T16 ? acc16_col(d.ks, q, j) : 32 * d.ks + 8 * q + j;
+        const int o = d.kind == FRAG_TG16 ? 32 * d.ks + 8 * q + j : acc16_col(d.ks, q, j);
         *row = o;
-        if (o >= d.seg_len || d.row0 + i >= d.L) return -1;
+        if (o >= d.seg_len) return -1;
+        if (d.kind == FRAG_TE16) {       // tile row i = encoding slot (ks' = t>>1, q' = i>>2, j' = 4(t&1) + (i&3))
+            const int t = d.row0 >> 4;
+            const int c = gen16_col(t >> 1, i >> 2, 4 * (t & 1) + (i & 3), d.L);
+            return c < 0 ? -1 : d.col_base + c;
+        }
+        if (d.row0 + i >= d.L) return -1;
         return d.col_base + d.row0 + i;
     }
     const bool s16 = d.kind == FRAG_ACC16 || d.kind == FRAG_GEN16;

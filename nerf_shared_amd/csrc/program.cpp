@@ -148,11 +148,22 @@ int build_program(const nerf_amd_arch &a, Program &p, const char **err) {
                                 p.frags_bwd.push_back({sg.tensor, sg.kind, 16 * (t + u), sg.col_base, ks,
                                                        p.tensors[sg.tensor].n_out, n_in, 0});
             };
+            // encoding-slot rows (ray gradients): n_in = 32 * k-steps of the encoding, L = its multires
+            auto add_bwd_enc = [&](int tensor, int col_base, int n_slots, int L, int nk) {
+                for (int t = 0; t < n_slots / 16; t += 2)
+                    for (int ks = 0; ks < nk; ++ks)
+                        for (int u = 0; u < 2; ++u)
+                            p.frags_bwd.push_back({tensor, FRAG_TE16, 16 * (t + u), col_base, ks, p.tensors[tensor].n_out, L, 0});
+            };
             add_bwd(W / 2, {SegT{D + 3, FRAG_TG16, 0, 1}});                                    // g_hv   <- rgb_linear
             add_bwd(W, {SegT{D + 2, FRAG_T16, 0, (W / 2) / 32}});                              // g_feat <- views_linears.0
+            add_bwd_enc(D + 2, W, 32 * p.KD16, Ld, (W / 2) / 32);                              // g_dirs <- views_linears.0[:, W:]
             add_bwd(W, {SegT{D + 0, FRAG_T16, 0, W / 32}, SegT{D + 1, FRAG_TG16, 0, 1}});      // g_h8   <- feature + alpha
-            for (int l = D - 1; l >= 1; --l)                                                   // g_h(l) <- pts_linears.l
+            for (int l = D - 1; l >= 1; --l) {                                                 // g_h(l) <- pts_linears.l
                 add_bwd(W, {SegT{l, FRAG_T16, is_skip(l - 1) ? p.input_ch : 0, W / 32}});
+                if (is_skip(l - 1)) add_bwd_enc(l, 0, 32 * p.KE16, Lx, W / 32);                // g_e    <- its [input_pts] columns
+            }
+            add_bwd_enc(0, 0, 32 * p.KE16, Lx, W / 32);                                        // g_e    <- pts_linears.0
             p.n_frags_bwd_used = (int)p.frags_bwd.size();
             while (p.frags_bwd.size() % STREAM_PAD_FRAGS) p.frags_bwd.push_back({0, FRAG_ZERO, 0, 0, 0, 0, 0, 0});
         }

@@ -35,8 +35,12 @@
 //    * FRAG_T16 : B operand is a gradient tile chain, k slot (q, j) of k-step ks is output
 //                 feature acc16_col(ks, q, j);  element = W[that output][col_base + row0 + (l&15)].
 //    * FRAG_TG16: B operand is built from dL/draw, k slot (q, j) is output feature 8q + j.
-//   FragDesc: row0 = first input feature of the tile (relative to col_base), seg_len = number of
-//   output features, L = number of input features of this segment.
+//    * FRAG_TE16: like FRAG_T16, but the 16 rows of the tile are slots of a generated encoding
+//                 (row 16t + 4q + r = slot (ks = t>>1, q, j = 4(t&1) + r) of gen16_col), so every lane
+//                 receives the gradients of exactly the encoding values it generated in the forward.
+//   FragDesc: row0 = first input feature (or encoding slot) of the tile (relative to col_base),
+//   seg_len = number of output features, L = number of input features of this segment
+//   (FRAG_TE16: the multires of the encoding).
 //
 // fp32 stream (generic kernel, mlp_fp32.hip)
 //   v_mfma_f32_32x32x2_f32: lane l holds A[row = l&31][k = l>>5].  Fragments are
@@ -56,7 +60,7 @@
 
 namespace na {
 
-enum { FRAG_ACC = 0, FRAG_GEN = 1, FRAG_ZERO = 2, FRAG_ACC16 = 3, FRAG_GEN16 = 4, FRAG_T16 = 5, FRAG_TG16 = 6 };
+enum { FRAG_ACC = 0, FRAG_GEN = 1, FRAG_ZERO = 2, FRAG_ACC16 = 3, FRAG_GEN16 = 4, FRAG_T16 = 5, FRAG_TG16 = 6, FRAG_TE16 = 7 };
 
 struct FragDesc {        // one bf16 A fragment: 32 out rows x 16 k
     int32_t tensor;      // index into the parameter list (nerf_amd.h order)

@@ -183,7 +183,7 @@ __device__ __forceinline__ double wave_suffix_excl_sum(double v, int lane) {
 __global__ __launch_bounds__(64 * RAYS_PER_WG) void composite_bwd_kernel(
     const float *raw, int raw_ch, const float *z, const float *rays_d, int rays_d_stride, const float *noise,
     int64_t R, int S, int white_bkgd, const float *g_rgb, const float *g_disp, const float *g_acc,
-    const float *g_depth, const float *g_weights, float *g_raw) {
+    const float *g_depth, const float *g_weights, float *g_raw, float *g_rays_d) {
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t r = (int64_t)blockIdx.x * RAYS_PER_WG + wv;
@@ -236,6 +236,7 @@ __global__ __launch_bounds__(64 * RAYS_PER_WG) void composite_bwd_kernel(
     if (white_bkgd) gacc -= gr + gg + gb;
     // ---- sweep 2, last chunk first: suffix sums of u = v w
     double tail = 0.0;                     // sum of u over all later chunks
+    float gdn = 0.f;                       // dL/d|rays_d| (dists = dz * |d|, render_utils.py:259)
     for (int s0 = ((S - 1) / 64) * 64; s0 >= 0; s0 -= 64) {
         const int s = s0 + lane;
         const bool in = s < S;
@@ -262,21 +263,33 @@ __global__ __launch_bounds__(64 * RAYS_PER_WG) void composite_bwd_kernel(
             o[1] = gg * w * cg * (1.0f - cg);
             o[2] = gb * w * cb * (1.0f - cb);
             const float oma = 1.0f - a;
-            o[3] = sig > 0.0f ? dist * oma * (v * T - (float)later / (oma + 1e-10f)) : 0.0f;
+            const float core = sig > 0.0f ? oma * (v * T - (float)later / (oma + 1e-10f)) : 0.0f;   // dL/dalpha * (1 - alpha)
+            o[3] = dist * core;
             for (int c = 4; c < raw_ch; ++c) o[c] = 0.0f;
+            gdn += core * sig * (dist / dnorm);                  // dL/ddist * dz
+        }
+    }
+    if (g_rays_d) {
+        gdn = wave_sum(gdn);
+        if (lane == 0) {
+            g_rays_d[3 * r] = gdn * d[0] / dnorm;
+            g_rays_d[3 * r + 1] = gdn * d[1] / dnorm;
+            g_rays_d[3 * r + 2] = gdn * d[2] / dnorm;
         }
     }
 }
 
 int launch_composite_bwd(const float *raw, int raw_ch, const float *z, const float *rays_d, int rays_d_stride,
                          const float *noise, int64_t R, int S, int white_bkgd, const float *g_rgb, const float *g_disp,
-                         const float *g_acc, const float *g_depth, const float *g_weights, float *g_raw, hipStream_t s) {
+                         const float *g_acc, const float *g_depth, const float *g_weights, float *g_raw, float *g_rays_d,
+                         hipStream_t s) {
     if (R <= 0) return NERF_AMD_OK;
     if (S < 1 || S > 2048 || raw_ch < 4) return NERF_AMD_EINVAL;
     const int64_t blocks = (R + RAYS_PER_WG - 1) / RAYS_PER_WG;
     const size_t lds = (size_t)RAYS_PER_WG * 3 * S * sizeof(float);
     hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)blocks), dim3(64 * RAYS_PER_WG), lds, s, raw, raw_ch, z,
-                       rays_d, rays_d_stride, noise, R, S, white_bkgd, g_rgb, g_disp, g_acc, g_depth, g_weights, g_raw);
+                       rays_d, rays_d_stride, noise, R, S, white_bkgd, g_rgb, g_disp, g_acc, g_depth, g_weights, g_raw,
+                       g_rays_d);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
 

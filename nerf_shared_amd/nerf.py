@@ -8,7 +8,8 @@ with ``load_state_dict`` unchanged.
 
 Inference runs the forward-only kernels.  With gradients enabled, the standard model
 (D=8, W=256, skips=[4], viewdirs, multires 10/4, bf16) runs the training kernels and
-loss.backward() reaches its parameters (no ray gradients yet).
+loss.backward() reaches its parameters, the points / view directions and the rays
+(SURVEY.md section 8f rank 1).
 """
 import ctypes
 import weakref
@@ -91,10 +92,11 @@ def _destroy_handle(handle):
 
 
 class _FieldTrainFn(torch.autograd.Function):
-    """The fused bf16 field with a HIP backward for the parameters:
-    forward saves every layer's activations in a workspace tensor, backward runs the dX-chain
-    kernel and the weight-gradient GEMMs (nerf_amd_field_backward).  Inputs (points, rays) get
-    no gradient yet."""
+    """The fused bf16 field with HIP backward kernels: forward saves
+    every layer's activations in a workspace tensor; backward runs the dX-chain kernel and the
+    weight-gradient kernels (nerf_amd_field_backward) and returns gradients for the parameters and,
+    when asked, for the points / view directions (explicit-points mode) or the ray batch (rays mode;
+    z_vals are constants: the coarse depths depend on near/far only and the fine ones are detached)."""
 
     @staticmethod
     def forward(ctx, model, pts, viewdirs, rays, z_vals, n_rays, n_samples, *params):
@@ -111,17 +113,18 @@ class _FieldTrainFn(torch.autograd.Function):
                                                         rays.shape[1] if rays is not None else 0, _lib.ptr(z_vals),
                                                         n_rays, n_samples, raw.data_ptr(), ws.data_ptr(), ws.numel(),
                                                         _lib.stream_of(dev)), "nerf_amd_field_forward_train")
-        ctx.model, ctx.ws, ctx.P = model, ws, P
-        ctx.shapes = [tuple(p.shape) for p in params]
+        ctx.model, ctx.ws, ctx.R, ctx.S = model, ws, n_rays, n_samples
+        ctx.inputs = (pts, viewdirs, rays, z_vals)
         return raw
 
     @staticmethod
     def backward(ctx, g_raw):
-        model, ws, P = ctx.model, ctx.ws, ctx.P
+        model, ws, R, S = ctx.model, ctx.ws, ctx.R, ctx.S
+        pts, viewdirs, rays, z_vals = ctx.inputs
         dev = ws.device
         g = g_raw.contiguous().float()
         mods = model._linears()
-        # one zeroed buffer for every gradient (the kernels accumulate with atomics), views per tensor
+        # one zeroed buffer for every gradient (head and ray gradients accumulate with atomics), views per tensor
         sizes = [m.weight.numel() for m in mods] + [m.bias.numel() for m in mods]
         flat = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
         views = torch.split(flat, sizes)
@@ -130,14 +133,23 @@ class _FieldTrainFn(torch.autograd.Function):
         gb = list(views[n:])
         wp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in gw])
         bp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in gb])
+        need_pts, need_vd, need_rays = ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        g_pts = torch.empty(R * S, 3, device=dev, dtype=torch.float32) if (pts is not None and need_pts) else None
+        g_rays6 = torch.zeros(R, 6, device=dev, dtype=torch.float32) if (rays is not None and need_rays) else None
+        g_vd = torch.zeros(R, 3, device=dev, dtype=torch.float32) if ((pts is not None and need_vd) or g_rays6 is not None) else None
         with torch.cuda.device(dev):
-            _lib.check(lib.nerf_amd_field_backward(model._handle, g.data_ptr(), P, ws.data_ptr(), ws.numel(), wp, bp, n,
-                                                   _lib.stream_of(dev)), "nerf_amd_field_backward")
+            _lib.check(lib.nerf_amd_field_backward(model._handle, g.data_ptr(), _lib.ptr(pts), _lib.ptr(viewdirs), _lib.ptr(rays),
+                                                   rays.shape[1] if rays is not None else 0, _lib.ptr(z_vals), R, S,
+                                                   ws.data_ptr(), ws.numel(), wp, bp, n, _lib.ptr(g_pts), _lib.ptr(g_rays6),
+                                                   _lib.ptr(g_vd), _lib.stream_of(dev)), "nerf_amd_field_backward")
         ctx.ws = None
+        g_rays = None
+        if g_rays6 is not None:           # [R, 11] = d/d(o, d, near, far, viewdir)
+            g_rays = torch.cat([g_rays6, torch.zeros(R, 2, device=dev), g_vd], -1)
         grads = []
-        for w, b in zip(gw, gb):       # parameter order of _train_params(): weight, bias per linear
+        for w, b in zip(gw, gb):          # parameter order of _train_params(): weight, bias per linear
             grads += [w, b]
-        return (None, None, None, None, None, None, None) + tuple(grads)
+        return (None, g_pts, g_vd if (pts is not None and need_vd) else None, g_rays, None, None, None) + tuple(grads)
 
 
 class NeRF(nn.Module):
@@ -225,11 +237,12 @@ class NeRF(nn.Module):
             out += [m.weight, m.bias]
         return out
 
-    def _wants_grad(self, device):
-        """True when autograd should flow into the parameters and the training kernels apply.
-        Otherwise (no_grad, frozen parameters, or an architecture / precision the training
-        kernels do not cover) the forward-only kernels run and outputs carry no history."""
-        if not torch.is_grad_enabled() or not any(p.requires_grad for p in self._train_params()):
+    def _wants_grad(self, device, *inputs):
+        """True when autograd should flow into the parameters (or the given inputs) and the training
+        kernels apply.  Otherwise (no_grad, nothing requires grad, or an architecture / precision
+        the training kernels do not cover) the forward-only kernels run and outputs carry no history."""
+        if not torch.is_grad_enabled() or not (any(p.requires_grad for p in self._train_params())
+                                               or any(t is not None and t.requires_grad for t in inputs)):
             return False
         ok = (self.precision or _default_precision) == "bf16" and \
             bool(lib.nerf_amd_model_supports_training(self._model_handle(device)))
@@ -243,7 +256,7 @@ class NeRF(nn.Module):
 
     def forward_rays(self, rays, z_vals):
         """raw [R, S, 4] of rays [R, 11] at depths z_vals [R, S] (pts = o + d z formed in the kernel);
-        differentiable with respect to the parameters."""
+        differentiable with respect to the parameters and the ray batch."""
         R, S = z_vals.shape
         raw = _FieldTrainFn.apply(self, None, None, rays, z_vals, R, S, *self._train_params())
         return raw.reshape(R, S, 4)
@@ -268,7 +281,8 @@ class NeRF(nn.Module):
         tiles points itself, so chunking cannot change the result."""
         _lib.require_device(inputs, "inputs")
         dev = inputs.device
-        pts = inputs.detach().reshape(-1, 3).contiguous().float()
+        want = self._wants_grad(dev, inputs, viewdirs)
+        pts = (inputs if want else inputs.detach()).reshape(-1, 3).contiguous().float()
         n_samples = inputs.shape[-2] if inputs.dim() >= 2 else 1
         vd = None
         if viewdirs is not None:
@@ -276,13 +290,13 @@ class NeRF(nn.Module):
                 raise _lib.NerfAmdError("viewdirs given to a NeRF built with use_viewdirs=False")
             if inputs.dim() != 3 or viewdirs.shape[0] != inputs.shape[0]:
                 raise _lib.NerfAmdError("with viewdirs, inputs must be [R, S, 3] and viewdirs [R, 3]")
-            vd = viewdirs.detach().reshape(-1, 3).contiguous().float()
+            vd = (viewdirs if want else viewdirs.detach()).reshape(-1, 3).contiguous().float()
         elif self.use_viewdirs:
             raise _lib.NerfAmdError("this NeRF was built with use_viewdirs=True: viewdirs is required")
         handle = self._model_handle(dev)
         out_ch = 4 if self.use_viewdirs else self.output_ch
         n_rays = pts.shape[0] // n_samples
-        if self._wants_grad(dev):
+        if want:
             raw = _FieldTrainFn.apply(self, pts, vd, None, None, n_rays, n_samples, *self._train_params())
             return raw.reshape(list(inputs.shape[:-1]) + [out_ch])
         out = torch.empty(pts.shape[0], out_ch, device=dev, dtype=torch.float32)

@@ -12,7 +12,7 @@ edges of the hot path:
     reference's seeded numpy draws bit for bit;
   * the NaN/Inf scan of every output (render_utils.py:170-172) only runs when
     DEBUG is set -- it never changes outputs and costs a device sync per key;
-  * autograd reaches the models' parameters (standard model, bf16), not the rays.
+  * autograd reaches the models' parameters and the rays (standard model, bf16 mode).
 """
 import os
 
@@ -70,8 +70,8 @@ def _pytest_uniform(shape, device):
 
 
 class _Raw2OutputsFn(torch.autograd.Function):
-    """raw2outputs with a HIP backward with respect to ``raw`` (nerf_amd_raw2outputs_backward).
-    z_vals and rays_d are treated as constants (ray gradients come later)."""
+    """raw2outputs with a HIP backward (nerf_amd_raw2outputs_backward) with respect to ``raw`` and to
+    ``rays_d`` (dists scale with |rays_d|, render_utils.py:259).  z_vals are constants."""
 
     @staticmethod
     def forward(ctx, raw, z, d, noise, white):
@@ -97,13 +97,14 @@ class _Raw2OutputsFn(torch.autograd.Function):
         R, S, ch = raw.shape
         g = [None if t is None else t.contiguous().float() for t in (g_rgb, g_disp, g_acc, g_depth, g_w)]
         g_raw = torch.empty_like(raw)
+        g_d = torch.empty(R, 3, device=raw.device, dtype=torch.float32) if ctx.needs_input_grad[2] else None
         with torch.cuda.device(raw.device):
             _lib.check(lib.nerf_amd_raw2outputs_backward(raw.data_ptr(), ch, z.data_ptr(), d.data_ptr(), d.stride(0),
                                                          _lib.ptr(noise), R, S, int(ctx.white), _lib.ptr(g[0]),
                                                          _lib.ptr(g[1]), _lib.ptr(g[2]), _lib.ptr(g[3]), _lib.ptr(g[4]),
-                                                         g_raw.data_ptr(), _lib.stream_of(raw.device)),
+                                                         g_raw.data_ptr(), _lib.ptr(g_d), _lib.stream_of(raw.device)),
                        "nerf_amd_raw2outputs_backward")
-        return g_raw, None, None, None, None
+        return g_raw, None, g_d, None, None
 
 
 class Renderer(torch.nn.Module):
@@ -239,7 +240,7 @@ class Renderer(torch.nn.Module):
         the same kernels stage by stage -- z_vals, training forward of the field (activations
         saved), compositing -- with the field and raw2outputs as autograd Functions whose
         backward passes are HIP kernels.  z_samples are detached, as in the reference
-        (render_utils.py:145); rays get no gradient yet."""
+        (render_utils.py:145); `rays` may require grad (pose estimation)."""
         R, dev = rays.shape[0], rays.device
         Nc, Ni = int(self.N_samples), int(self.N_importance)
         t_rand, noise0, noise1, u, t_lin = self._draws(R, dev, pytest)
@@ -250,7 +251,7 @@ class Renderer(torch.nn.Module):
             _lib.check(lib.nerf_amd_coarse_z(rays.data_ptr(), rays.shape[1], _linspace01(Nc, dev).data_ptr(), _lib.ptr(t_rand),
                                              R, Nc, int(bool(self.lindisp)), int(self.perturb > 0.), z.data_ptr(), stream),
                        "nerf_amd_coarse_z")
-        rays_d = rays[:, 3:6]
+        rays_d = rays[:, 3:6]            # a view: composite gradients with respect to |d| flow back into `rays`
         raw = coarse_model.forward_rays(rays, z)
         rgb, disp, acc, weights, _ = _Raw2OutputsFn.apply(raw, z, rays_d, noise0, bool(self.white_bkgd))
         ret = {}
@@ -307,9 +308,11 @@ class Renderer(torch.nn.Module):
         self._check_model(coarse_model, "coarse_model")
         if fine_model is not None:
             self._check_model(fine_model, "fine_model")
-        if rays.shape[0] > 0 and (coarse_model._wants_grad(rays.device)
-                                  or (fine_model is not None and self.N_importance > 0 and fine_model._wants_grad(rays.device))):
-            return self._render_rays_train(rays, coarse_model, fine_model, retraw, retweights, pytest)
+        if rays.shape[0] > 0 and (coarse_model._wants_grad(rays.device, ray_batch)
+                                  or (fine_model is not None and self.N_importance > 0
+                                      and fine_model._wants_grad(rays.device, ray_batch))):
+            live = ray_batch.contiguous().float() if (torch.is_grad_enabled() and ray_batch.requires_grad) else rays
+            return self._render_rays_train(live, coarse_model, fine_model, retraw, retweights, pytest)
         out_ch = 4 if coarse_model.use_viewdirs else coarse_model.output_ch
         outs = self._alloc_outputs(rays.shape[0], rays.device, out_ch, retraw, retweights)
         self._launch(rays, coarse_model, fine_model, outs, retraw, retweights, pytest)
@@ -337,11 +340,12 @@ class Renderer(torch.nn.Module):
         out_ch = 4 if coarse_model.use_viewdirs else coarse_model.output_ch
         full = self._alloc_outputs(N, dev, out_ch, retraw, False)
         starts = list(range(0, N, chunk))
-        if N > 0 and (coarse_model._wants_grad(dev) or (fine_model is not None and self.N_importance > 0
-                                                     and fine_model._wants_grad(dev))):
+        if N > 0 and (coarse_model._wants_grad(dev, rays_flat) or (fine_model is not None and self.N_importance > 0
+                                                                 and fine_model._wants_grad(dev, rays_flat))):
+            live = rays_flat if (torch.is_grad_enabled() and rays_flat.requires_grad) else rays
             parts = {}                     # training: autograd graph per chunk, concatenated like the reference
             for i in starts:
-                r = self.render_rays(rays[i:i + chunk], coarse_model, fine_model, retraw)
+                r = self.render_rays(live[i:i + chunk], coarse_model, fine_model, retraw)
                 for k, v in r.items():
                     parts.setdefault(k, []).append(v)
             return {k: torch.cat(v, 0) for k, v in parts.items()}
@@ -427,8 +431,8 @@ class Renderer(torch.nn.Module):
         noise = None
         if self.raw_noise_std > 0.:
             noise = (_pytest_uniform([R, S], dev) if pytest else torch.randn([R, S], device=dev)) * self.raw_noise_std
-        if torch.is_grad_enabled() and raw.requires_grad:
-            return _Raw2OutputsFn.apply(raw.contiguous().float(), z, d, noise, bool(self.white_bkgd))
+        if torch.is_grad_enabled() and (raw.requires_grad or rays_d.requires_grad):
+            return _Raw2OutputsFn.apply(raw.contiguous().float(), z, rays_d.contiguous().float(), noise, bool(self.white_bkgd))
         with torch.no_grad():
             return _Raw2OutputsFn.apply(raw_c, z, d, noise, bool(self.white_bkgd))
 

@@ -260,3 +260,63 @@ def test_train_demo_learns_a_scene_and_checkpoints_roundtrip(dev, tmp_path):
         a = r.render(32, 32, K, coarse, fine, c2w=torch.from_numpy(synth.LEGO_C2W), retraw=False)[0]
         b = r.render(32, 32, K, c2, f2, c2w=torch.from_numpy(synth.LEGO_C2W), retraw=False)[0]
     assert torch.equal(a, b)
+
+
+def test_ray_gradients_for_pose_estimation(dev, monkeypatch):
+    """dL/d(rays_o, rays_d) through Renderer.render(rays=...) -- what the pose-estimation demo
+    differentiates (demo_est_rel_pose.py:87-98): through the view-direction normalisation, the
+    positional encodings of o + d z and of the view direction, the field and the compositing
+    (dists scale with |d|).  Against torch.autograd on the oracle with the kernel's bf16 roundings
+    (relative L2 <= 8e-2; measured 3.6 %) and in fp32 (cosine >= 0.85: derivatives with respect to
+    position carry the 2^f factors of the encoding, so they amplify the bf16-vs-fp32 difference of
+    the network itself; measured 0.92)."""
+    from nerf_shared_amd import render_utils
+    batch, target = _batch(80, 7)
+    cfg = dict(BASE, N_samples=32, N_importance=48)
+    r = render_utils.Renderer(**cfg)
+    mc, cc = _models(dev, 1, 2.0)
+    mf, cf = _models(dev, 11, 2.0)
+    mc.requires_grad_(False)
+    mf.requires_grad_(False)                       # frozen networks, free rays: the pose-estimation setting
+    ro = batch[:, 0:3].clone().to(dev).requires_grad_(True)
+    rd = (batch[:, 3:6] * 1.3).clone().to(dev).requires_grad_(True)     # not unit length: the |d| path matters
+    rgb, disp, acc, extras = r.render(400, 400, None, mc, mf, chunk=64, rays=(ro, rd), retraw=False)
+    assert rgb.requires_grad
+    t = target.to(dev)
+    (((rgb - t) ** 2).mean() + ((extras["rgb0"] - t) ** 2).mean()).backward()
+    assert ro.grad is not None and rd.grad is not None and all(p.grad is None for p in mc.parameters())
+
+    def oracle(field):
+        if field is not None:
+            monkeypatch.setattr(O, "nerf_forward", lambda sd, arch, pts, vd, netchunk=0: field(sd, pts, vd))
+        o = batch[:, 0:3].clone().requires_grad_(True)
+        d = (batch[:, 3:6] * 1.3).clone().requires_grad_(True)
+        out = O.render(O.RenderCfg(**cfg), 400, 400, None, ({k: v.detach() for k, v in cc.items()}, O.Arch(**VD)),
+                       ({k: v.detach() for k, v in cf.items()}, O.Arch(**VD)), chunk=64, rays=(o, d), retraw=False)
+        (((out[0] - target) ** 2).mean() + ((out[3]["rgb0"] - target) ** 2).mean()).backward()
+        monkeypatch.undo()
+        return o.grad, d.grad
+
+    o32, d32 = oracle(None)
+    ob, db = oracle(bf16_field)
+    for name, g, gb, g32 in (("rays_o", ro.grad.cpu(), ob, o32), ("rays_d", rd.grad.cpu(), db, d32)):
+        cos = float((g.double().flatten() @ g32.double().flatten()) / (g.double().norm() * g32.double().norm()).clamp_min(1e-30))
+        print(name, "err vs bf16-model %.4f  cos fp32 %.4f" % (rel_err(g, gb), cos))
+        assert torch.isfinite(g).all()
+        assert rel_err(g, gb) < 8e-2 and cos > 0.85, (name, rel_err(g, gb), cos)
+
+
+def test_point_gradients_of_the_field(dev):
+    """NeRF.forward(inputs, viewdirs) with inputs/viewdirs requiring grad (frozen parameters)."""
+    rng = np.random.default_rng(21)
+    pts = torch.from_numpy(rng.uniform(-2, 2, size=(40, 9, 3)).astype(np.float32))
+    vd = torch.from_numpy(rng.normal(size=(40, 3)).astype(np.float32))
+    coef = torch.from_numpy(rng.normal(size=(40, 9, 4)).astype(np.float32))
+    m, cpu = _models(dev, 1, 2.0)
+    m.requires_grad_(False)
+    p_gpu, v_gpu = pts.to(dev).requires_grad_(True), vd.to(dev).requires_grad_(True)
+    (m(p_gpu, v_gpu) * coef.to(dev)).sum().backward()
+    p_cpu, v_cpu = pts.clone().requires_grad_(True), vd.clone().requires_grad_(True)
+    (bf16_field({k: v.detach() for k, v in cpu.items()}, p_cpu, v_cpu) * coef).sum().backward()
+    print("pts", rel_err(p_gpu.grad, p_cpu.grad), "viewdirs", rel_err(v_gpu.grad, v_cpu.grad))
+    assert rel_err(p_gpu.grad, p_cpu.grad) < 6e-2 and rel_err(v_gpu.grad, v_cpu.grad) < 6e-2

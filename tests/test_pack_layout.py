@@ -400,13 +400,37 @@ def test_backward_stream_matches_kernel_dataflow():
 
     Grgb, Gsig = gen_frag([0, 1, 2]), gen_frag([3])
     G = {}
-    G["hv"] = tlayer(0, 4, Grgb, 1, mask=keep["hv"])
-    G["feat"] = tlayer(8, 8, G["hv"], 4)
-    g = tlayer(72, 8, G["feat"], 8, Gsig, 1, mask=keep["h"][7])
+    # fragment offsets of mlp_bwd_s16.hip's LayoutB
+    F_HV, F_FEAT, F_DIRS, F_H8, F_L7, F_E5, F_L4, F_E0 = 0, 8, 72, 80, 224, 608, 640, 1152
+    assert stream.shape[0] >= F_E0 + 32
+
+    def enc_slots(f0, npair, x, L, n_cols):
+        """FRAG_TE16 products: per point, gradient of every encoding column (from the lane that owns its slot)."""
+        out = np.zeros((32, n_cols), np.float64)
+        for pr in range(npair):
+            acc = w.tile_pair(f0 + pr * 2 * (len(x) // 2), 0, x, len(x) // 2)
+            for u in range(2):
+                for cc in range(2):
+                    for l in range(64):
+                        for r in range(4):
+                            col = gen16_col(pr, l >> 4, 4 * u + r, L)
+                            if col >= 0:
+                                out[16 * cc + (l & 15), col] = acc[u][cc][l, r]
+        return out
+
+    G["hv"] = tlayer(F_HV, 4, Grgb, 1, mask=keep["hv"])
+    G["feat"] = tlayer(F_FEAT, 8, G["hv"], 4)
+    g_dirs = enc_slots(F_DIRS, 1, G["hv"], 4, 27)
+    g = tlayer(F_H8, 8, G["feat"], 8, Gsig, 1, mask=keep["h"][7])
     G[7] = g
+    g_e = None
     for n, l in enumerate(range(6, -1, -1)):
-        g = tlayer(216 + 128 * n, 8, g, 8, mask=keep["h"][l])
+        f0 = F_L7 + 128 * n if l >= 4 else F_L4 + 128 * (3 - l)
+        if l == 4:
+            g_e = enc_slots(F_E5, 2, g, 10, 63)              # g here is the gradient of pts_linears.5's pre-activation
+        g = tlayer(f0, 8, g, 8, mask=keep["h"][l])
         G[l] = g
+    g_e = g_e + enc_slots(F_E0, 2, g, 10, 63)
 
     # plain numpy backward on natural-order rows with the same bf16 roundings
     Wb = {k: bf16_round(v).astype(np.float64) for k, v in sd.items() if k.endswith("weight")}
@@ -428,6 +452,11 @@ def test_backward_stream_matches_kernel_dataflow():
     for key, n_ks in (("hv", 4), ("feat", 8), (7, 8), (4, 8), (0, 8)):
         got = frags_to_rows(G[key], n_ks)
         np.testing.assert_allclose(got, ref[key], atol=2e-2 * float(np.abs(ref[key]).max()), rtol=0, err_msg=str(key))
+    # gradients of the encodings (inputs of the ray gradients)
+    ref_dirs = ref["hv"] @ Wb["views_linears.0.weight"][:, 256:283]
+    ref_e = ref[5] @ Wb["pts_linears.5.weight"][:, :63] + ref[0] @ Wb["pts_linears.0.weight"]
+    np.testing.assert_allclose(g_dirs, ref_dirs, atol=2e-2 * float(np.abs(ref_dirs).max()), rtol=0)
+    np.testing.assert_allclose(g_e, ref_e, atol=2e-2 * float(np.abs(ref_e).max()), rtol=0)
 
 
 def test_gen16_layout_is_a_bijection():
