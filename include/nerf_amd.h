@@ -244,6 +244,12 @@ int nerf_amd_make_rays(int32_t H, int32_t W, const double *K4, const float *c2w,
                        int64_t pix0, int64_t n, float near, float far, int use_viewdirs, int ndc,
                        float *rays_out, void *stream);
 
+/* Backward of get_rays with respect to the pose (utils.py:33-42; what the pose-estimation demo
+ * differentiates, demo_est_rel_pose.py:87): gradients of rays_o / rays_d [n,3] (either may be NULL) for
+ * flat pixels [pix0, pix0+n) -> g_c2w (12 floats, 3x4 row-major, DEVICE, overwritten). */
+int nerf_amd_get_rays_backward(int32_t H, int32_t W, const double *K4, int64_t pix0, int64_t n, const float *g_rays_o,
+                               const float *g_rays_d, float *g_c2w, void *stream);
+
 /* ------------------------------------------------------------------------
  * Measurement hook (bench.py): while enabled, every field-MLP launch is
  * bracketed by hipEvents on its own stream.  nerf_amd_profile_collect waits for

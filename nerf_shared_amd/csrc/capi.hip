@@ -485,6 +485,14 @@ int nerf_amd_profile_collect(int64_t launches[2], double total_ms[2], double tot
     return NERF_AMD_OK;
 }
 
+int nerf_amd_get_rays_backward(int32_t H, int32_t W, const double *K4, int64_t pix0, int64_t n, const float *g_rays_o,
+                               const float *g_rays_d, float *g_c2w, void *stream) {
+    if (H < 1 || W < 1 || !K4 || pix0 < 0 || n < 0 || pix0 + n > (int64_t)H * W || !g_c2w)
+        return fail(NERF_AMD_EINVAL, "bad get_rays_backward arguments");
+    int rc = launch_get_rays_bwd(H, W, K4, pix0, n, g_rays_o, g_rays_d, g_c2w, static_cast<hipStream_t>(stream));
+    return rc ? fail(rc, "get_rays backward launch failed") : NERF_AMD_OK;
+}
+
 int nerf_amd_make_rays(int32_t H, int32_t W, const double *K4, const float *c2w, const float *c2w_static,
                        int64_t pix0, int64_t n, float near, float far, int use_viewdirs, int ndc,
                        float *rays_out, void *stream) {

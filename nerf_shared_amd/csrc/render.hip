@@ -516,6 +516,45 @@ int launch_ndc_rays(int H, int W, double focal, float near, const float *rays_o,
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
 
+// Backward of get_rays with respect to c2w (utils.py:33-42): rays_d = R dirs, rays_o = t, so
+// dL/dR[k][m] = sum_pix g_d[pix][k] dirs[pix][m] and dL/dt[k] = sum_pix g_o[pix][k].
+__global__ __launch_bounds__(256) void get_rays_bwd_kernel(RayGen g, int64_t pix0, int64_t n, const float *g_o,
+                                                           const float *g_d, float *g_c2w) {
+    float acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = 0.f;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = pix0 + idx;
+        const float i = (float)(pix % g.W), j = (float)(pix / g.W);
+        const float dir[3] = {(i - g.cx) / g.fx, -(j - g.cy) / g.fy, -1.0f};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float gd = g_d ? g_d[3 * idx + k] : 0.f;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) acc[4 * k + m] += gd * dir[m];
+            if (g_o) acc[4 * k + 3] += g_o[3 * idx + k];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const float v = wave_sum(acc[i]);
+        if ((threadIdx.x & 63) == 0) atomicAdd(g_c2w + i, v);
+    }
+}
+
+int launch_get_rays_bwd(int H, int W, const double *K4, int64_t pix0, int64_t n, const float *g_o, const float *g_d,
+                        float *g_c2w, hipStream_t s) {
+    if (hipMemsetAsync(g_c2w, 0, 12 * sizeof(float), s) != hipSuccess) return NERF_AMD_EHIP;
+    if (n <= 0) return NERF_AMD_OK;
+    RayGen g;
+    g.fx = (float)K4[0]; g.fy = (float)K4[1]; g.cx = (float)K4[2]; g.cy = (float)K4[3];
+    g.H = H; g.W = W;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(get_rays_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, pix0, n, g_o, g_d, g_c2w);
+    return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
+}
+
 int launch_make_rays(int H, int W, const double *K4, const float *c2w, const float *c2w_static,
                      int64_t pix0, int64_t n, float near, float far, int use_viewdirs, int ndc,
                      float *rays_out, hipStream_t s) {

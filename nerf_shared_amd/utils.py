@@ -61,9 +61,36 @@ def make_ray_batch(H, W, K, c2w, near, far, use_viewdirs, ndc, c2w_staticcam=Non
     return out
 
 
+class _GetRaysFn(torch.autograd.Function):
+    """get_rays with a HIP backward with respect to the pose (nerf_amd_get_rays_backward)."""
+
+    @staticmethod
+    def forward(ctx, c2w, H, W, K4):
+        b = make_ray_batch(H, W, [[K4[0], 0, K4[2]], [0, K4[1], K4[3]]], c2w, 0.0, 1.0, False, False, device=c2w.device)
+        ctx.meta = (H, W, K4, tuple(c2w.shape))
+        return b[:, 0:3].reshape(H, W, 3), b[:, 3:6].reshape(H, W, 3)
+
+    @staticmethod
+    def backward(ctx, g_o, g_d):
+        H, W, K4, shape = ctx.meta
+        g_o = None if g_o is None else g_o.reshape(-1, 3).contiguous().float()
+        g_d = None if g_d is None else g_d.reshape(-1, 3).contiguous().float()
+        dev = (g_o if g_o is not None else g_d).device
+        out = torch.empty(12, device=dev, dtype=torch.float32)
+        k4 = (ctypes.c_double * 4)(*K4)
+        with torch.cuda.device(dev):
+            _lib.check(lib.nerf_amd_get_rays_backward(int(H), int(W), k4, 0, H * W, _lib.ptr(g_o), _lib.ptr(g_d),
+                                                      out.data_ptr(), _lib.stream_of(dev)), "nerf_amd_get_rays_backward")
+        g = torch.zeros(shape, device=dev, dtype=torch.float32)
+        g[:3, :4] = out.reshape(3, 4)
+        return g, None, None, None
+
+
 def get_rays(H, W, K, c2w):
-    """rays_o, rays_d [H, W, 3] (utils.py:33-42); pixel centres at integer
-    coordinates, camera looks down -z."""
+    """rays_o, rays_d [H, W, 3] (utils.py:33-42); pixel centres at integer coordinates, camera looks
+    down -z.  Differentiable with respect to a device-resident ``c2w`` that requires grad."""
+    if isinstance(c2w, torch.Tensor) and c2w.is_cuda and c2w.requires_grad and torch.is_grad_enabled():
+        return _GetRaysFn.apply(c2w.float(), int(H), int(W), (float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2])))
     dev = c2w.device if isinstance(c2w, torch.Tensor) and c2w.is_cuda else _default_device()
     b = make_ray_batch(H, W, K, c2w, 0.0, 1.0, False, False, device=dev)
     return b[:, 0:3].reshape(H, W, 3), b[:, 3:6].reshape(H, W, 3)

@@ -236,15 +236,20 @@ def test_adam_steps_reduce_the_loss(dev):
     assert float(((rgb2 - t) ** 2).mean()) < losses[0]
 
 
-def test_train_demo_learns_a_scene_and_checkpoints_roundtrip(dev, tmp_path):
-    """tools/train_demo.py: 300 steps of the reference's loop on an analytic sphere scene lift the
-    held-out-view PSNR by > 10 dB; the checkpoint (reference .tar layout, utils.py:444-456) reloads
-    into fresh models bit-identically."""
+@pytest.fixture(scope="module")
+def sphere_run(dev):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from tools import train_demo
+    return train_demo.run(steps=300, res=48, views=8, verbose=False)
+
+
+def test_train_demo_learns_a_scene_and_checkpoints_roundtrip(dev, tmp_path, sphere_run):
+    """tools/train_demo.py: 300 steps of the reference's loop on an analytic sphere scene lift the
+    held-out-view PSNR by > 10 dB; the checkpoint (reference .tar layout, utils.py:444-456) reloads
+    into fresh models bit-identically."""
     from nerf_shared_amd import nerf, render_utils, utils
-    out, (coarse, fine, opt, args) = train_demo.run(steps=300, res=48, views=8, verbose=False)
+    out, (coarse, fine, opt, args) = sphere_run
     print(out)
     assert out["psnr_after"] > out["psnr_before"] + 10.0 and out["psnr_after"] > 18.0
     args.basedir, args.expname, args.ft_path, args.no_reload = str(tmp_path), "demo", None, False
@@ -320,3 +325,51 @@ def test_point_gradients_of_the_field(dev):
     (bf16_field({k: v.detach() for k, v in cpu.items()}, p_cpu, v_cpu) * coef).sum().backward()
     print("pts", rel_err(p_gpu.grad, p_cpu.grad), "viewdirs", rel_err(v_gpu.grad, v_cpu.grad))
     assert rel_err(p_gpu.grad, p_cpu.grad) < 6e-2 and rel_err(v_gpu.grad, v_cpu.grad) < 6e-2
+
+
+def test_pose_optimisation_recovers_a_translation(dev, sphere_run):
+    """The loop of the pose-estimation demo (demo_est_rel_pose.py:74-98) in miniature: the frozen
+    networks trained on the sphere scene, a pose with a learnable translation offset, get_rays -> a
+    fixed subset of rays -> render_from_rays -> mse against the image rendered from the true pose ->
+    Adam on the offset.  get_rays' backward is checked against autograd of the oracle's get_rays first."""
+    from nerf_shared_amd import render_utils, utils
+    H = W = 40
+    K = synth.lego_intrinsics(H, W)
+    true = torch.from_numpy(synth.LEGO_C2W).to(dev)
+    # (a) get_rays backward
+    c2w = true.clone().requires_grad_(True)
+    ro, rd = utils.get_rays(H, W, K, c2w)
+    wo, wd = torch.randn(H, W, 3, device=dev), torch.randn(H, W, 3, device=dev)
+    ((ro * wo).sum() + (rd * wd).sum()).backward()
+    c_cpu = true.cpu().clone().requires_grad_(True)
+    ro2, rd2 = O.get_rays(H, W, K, c_cpu)
+    ((ro2 * wo.cpu()).sum() + (rd2 * wd.cpu()).sum()).backward()
+    assert rel_err(c2w.grad, c_cpu.grad) < 1e-5
+    # (b) recover a translation offset
+    _, (mc, mf, _, _) = sphere_run
+    was = [p.requires_grad for p in mc.parameters()]
+    mc.requires_grad_(False)
+    mf.requires_grad_(False)
+    r = render_utils.Renderer(**dict(BASE, N_samples=32, N_importance=32))
+    sel = torch.arange(0, H * W, 3, device=dev)
+    with torch.no_grad():
+        ro, rd = utils.get_rays(H, W, K, true)
+        target = r.render_from_rays(H, W, K, 4096, torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0), mc, mf, retraw=False)[0]
+    offset = torch.tensor([0.15, -0.12, 0.10], device=dev, requires_grad=True)
+    opt = torch.optim.Adam([offset], lr=1e-2)
+    losses, dists = [], []
+    for _ in range(80):
+        opt.zero_grad()
+        pose = torch.cat([true[:, :3], (true[:, 3] + offset)[:, None]], 1)
+        ro, rd = utils.get_rays(H, W, K, pose)
+        rays = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0)
+        rgb = r.render_from_rays(H, W, K, 4096, rays, mc, mf, retraw=False)[0]
+        loss = ((rgb - target) ** 2).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+        dists.append(float(offset.detach().norm()))
+    print("pose losses %.5f -> %.5f, |offset| %.4f -> %.4f" % (losses[0], losses[-1], dists[0], dists[-1]))
+    mc.requires_grad_(was[0])
+    mf.requires_grad_(was[0])
+    assert losses[-1] < 0.3 * losses[0] and dists[-1] < 0.5 * dists[0]
