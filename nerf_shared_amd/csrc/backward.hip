@@ -166,8 +166,10 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(DwReduceArgs a) {
     const int t = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + t;
     float acc = 0.f;
-    if (e < per)
+    if (e < per) {
+#pragma unroll 8
         for (int b = grp; b < a.n_slabs; b += 4) acc += a.slab[(int64_t)b * per + e];
+    }
     part[grp][t] = acc;
     __syncthreads();
     if (grp != 0 || e >= per) return;
@@ -184,32 +186,93 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(DwReduceArgs a) {
     }
 }
 
-// Heads (alpha_linear, rgb_linear): G = NO <= 4 natural-order columns of g_rawb [P, 4].
+// Heads (alpha_linear, rgb_linear): G = NO <= 4 natural-order columns of g_rawb [P, 4], X = [P, n_in]
+// slot-major.  A block walks 256-row tiles; a thread owns 8 consecutive X columns (one 16-byte load
+// per row) of every (256 / groups)-th row.  Partial sums meet in LDS and leave as one slab row per
+// block ([NO][n_in] weights, then NO biases); dw_small_reduce_kernel sums the rows.
 template <int NO>
 __global__ __launch_bounds__(256) void dw_small_kernel(const uint16_t *G, int g_col0, const uint16_t *X, int ldx, int n_in,
-                                                       int64_t P, int in_kind, float *dW, int ld_dw, float *db) {
-    const int t = threadIdx.x;
-    const int64_t r0 = (int64_t)blockIdx.x * 128, r1 = r0 + 128 < P ? r0 + 128 : P;
-    float acc[NO], bs[NO];
+                                                       int64_t P, float *slab) {
+    __shared__ float red[NO][256 + 1];
+    const int groups = n_in / 8;                       // column groups per row (32 for 256 columns, 16 for 128)
+    const int rows_par = 256 / groups;                 // rows in flight per block
+    const int cg = threadIdx.x % groups, ty = threadIdx.x / groups;
+    float acc[NO][8], bs[NO];
 #pragma unroll
-    for (int k = 0; k < NO; ++k) { acc[k] = 0.f; bs[k] = 0.f; }
-    for (int64_t p = r0; p < r1; ++p) {
-        const float x = t < n_in ? __builtin_bit_cast(float, (unsigned)X[p * ldx + t] << 16) : 0.f;
+    for (int k = 0; k < NO; ++k) {
+        bs[k] = 0.f;
 #pragma unroll
-        for (int k = 0; k < NO; ++k) {
-            const float g = __builtin_bit_cast(float, (unsigned)G[p * 4 + g_col0 + k] << 16);
-            acc[k] += g * x;
-            bs[k] += g;
+        for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
+    }
+    for (int64_t r0 = (int64_t)blockIdx.x * 256; r0 < P; r0 += (int64_t)gridDim.x * 256) {
+        const int64_t r1 = r0 + 256 < P ? r0 + 256 : P;
+        for (int64_t p = r0 + ty; p < r1; p += rows_par) {
+            const u32x4 xv = *reinterpret_cast<const u32x4 *>(X + p * ldx + cg * 8);
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                x[2 * j] = __builtin_bit_cast(float, xv[j] << 16);
+                x[2 * j + 1] = __builtin_bit_cast(float, xv[j] & 0xffff0000u);
+            }
+#pragma unroll
+            for (int k = 0; k < NO; ++k) {
+                const float g = __builtin_bit_cast(float, (unsigned)G[p * 4 + g_col0 + k] << 16);
+                if (cg == 0) bs[k] += g;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[k][j] += g * x[j];
+            }
         }
     }
-    if (t < n_in) {
-        const int i = slot_to_feature(in_kind, t, 0);
 #pragma unroll
-        for (int k = 0; k < NO; ++k) atomicAdd(dW + (int64_t)k * ld_dw + i, acc[k]);
+    for (int k = 0; k < NO; ++k) red[k][threadIdx.x] = 0.f;
+    if (threadIdx.x < NO) red[threadIdx.x][256] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NO; ++k) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(&red[k][cg * 8 + j], acc[k][j]);
+        if (cg == 0) atomicAdd(&red[k][256], bs[k]);
     }
-    if (t == 0)
+    __syncthreads();
+    float *row = slab + (int64_t)blockIdx.x * (NO * n_in + NO);
+    if ((int)threadIdx.x < n_in)
 #pragma unroll
-        for (int k = 0; k < NO; ++k) atomicAdd(db + k, bs[k]);
+        for (int k = 0; k < NO; ++k) row[k * n_in + threadIdx.x] = red[k][threadIdx.x];
+    if (threadIdx.x < NO) row[NO * n_in + threadIdx.x] = red[threadIdx.x][256];
+}
+
+// dW[k][feature(slot)] / db[k] = sum of the slab rows dw_small_kernel left; 64 elements per block.
+__global__ __launch_bounds__(256) void dw_small_reduce_kernel(const float *slab, int n_rows, int NO, int n_in, int in_kind,
+                                                              float *dW, int ld_dw, float *db) {
+    __shared__ float part[4][64];
+    const int per = NO * n_in + NO;
+    const int t = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + t;
+    float acc = 0.f;
+    if (e < per) {
+#pragma unroll 8
+        for (int b = grp; b < n_rows; b += 4) acc += slab[(int64_t)b * per + e];
+    }
+    part[grp][t] = acc;
+    __syncthreads();
+    if (grp != 0 || e >= per) return;
+    acc = part[0][t] + part[1][t] + part[2][t] + part[3][t];
+    if (e < NO * n_in) {
+        const int k = e / n_in, i = slot_to_feature(in_kind, e - k * n_in, 0);
+        if (i >= 0) dW[(int64_t)k * ld_dw + i] = acc;
+    } else {
+        db[e - NO * n_in] = acc;
+    }
+}
+
+template <int NO>
+static void launch_dw_small(hipStream_t s, int64_t P, float *slab, const uint16_t *G, int g_col0, const uint16_t *X, int n_in,
+                            float *dW, float *db) {
+    int64_t g = (P + 255) / 256;
+    if (g > 256) g = 256;                              // one block per CU; 256 * (3 * 256 + 3) floats fit the slab
+    hipLaunchKernelGGL(dw_small_kernel<NO>, dim3((unsigned)g), dim3(256), 0, s, G, g_col0, X, n_in, n_in, P, slab);
+    hipLaunchKernelGGL(dw_small_reduce_kernel, dim3((NO * n_in + NO + 63) / 64), dim3(256), 0, s, slab, (int)g, NO, n_in,
+                       (int)PERM_ACC, dW, n_in, db);
 }
 
 namespace {
@@ -296,9 +359,8 @@ static int weight_grad(hipStream_t s, int64_t P, float *slab, const uint16_t *X,
 }
 
 // Parameter gradients of the view-branch (10,4) model from the saved activations and the
-// pre-activation gradients the dX-chain kernel left in the workspace.  The 256-wide products
-// overwrite their destination; the two heads (alpha, rgb) accumulate with atomics, so gw / gb of
-// those must come in zeroed (the Python shim hands in one zeroed buffer for everything).
+// pre-activation gradients the dX-chain kernel left in the workspace.  Every product overwrites
+// its destination (no accumulation into gw / gb).
 int train_param_grads(const Program &p, int64_t P, void *workspace, float *const *gw, float *const *gb, hipStream_t s) {
     TrainWs w;
     carve(p, P, static_cast<char *>(workspace), &w);
@@ -320,7 +382,6 @@ int train_param_grads(const Program &p, int64_t P, void *workspace, float *const
         }
     }
     const uint16_t *h8 = w.sv_h + (D - 1) * HS;
-    const unsigned small_grid = (unsigned)((P + 127) / 128);
     // feature_linear
     if (!rc) rc = weight_grad(s, P, w.slab, h8, W, PERM_ACC, 0, W, w.g_feat, W, W, gw[D], W, 0, gb[D]);
     // views_linears.0: [feature | dirs]
@@ -328,8 +389,8 @@ int train_param_grads(const Program &p, int64_t P, void *workspace, float *const
     if (!rc) rc = weight_grad(s, P, w.slab, w.sv_d, Dd, PERM_GEN, Ld, icv, w.g_hv, W / 2, W / 2, gw[D + 2], W + icv, W, nullptr);
     if (rc) return rc;
     // alpha_linear (column 3 of g_rawb) and rgb_linear (columns 0..2)
-    hipLaunchKernelGGL(dw_small_kernel<1>, dim3(small_grid), dim3(256), 0, s, w.g_rawb, 3, h8, W, W, P, PERM_ACC, gw[D + 1], W, gb[D + 1]);
-    hipLaunchKernelGGL(dw_small_kernel<3>, dim3(small_grid), dim3(256), 0, s, w.g_rawb, 0, w.sv_hv, W / 2, W / 2, P, PERM_ACC, gw[D + 3], W / 2, gb[D + 3]);
+    launch_dw_small<1>(s, P, w.slab, w.g_rawb, 3, h8, W, gw[D + 1], gb[D + 1]);
+    launch_dw_small<3>(s, P, w.slab, w.g_rawb, 0, w.sv_hv, W / 2, gw[D + 3], gb[D + 3]);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
 
