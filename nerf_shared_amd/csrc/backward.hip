@@ -278,12 +278,14 @@ static void launch_dw_small(hipStream_t s, int64_t P, float *slab, const uint16_
 namespace {
 struct TrainWs {
     uint16_t *sv_e, *sv_d, *sv_h, *sv_feat, *sv_hv, *g_rawb, *g_hv, *g_feat, *g_h;
+    uint8_t *sv_bits;
     float *slab;        // DW_GRID partial [256 x 256 + 256] fp32 results of one weight-gradient product
 };
-constexpr int DW_GRID = 128;
+constexpr int DW_GRID = 256;
 size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 
-int64_t carve(const Program &p, int64_t P, char *base, TrainWs *w) {
+int64_t carve(const Program &p, int64_t P_points, char *base, TrainWs *w) {
+    const size_t P = (size_t)pad_points(P_points);     // rows for the last workgroup's padding points too
     size_t off = 0;
     auto take = [&](size_t bytes) { char *q = base ? base + off : nullptr; off += al(bytes); return q; };
     const size_t e = 32 * p.KE16, d = 32 * p.KD16;
@@ -293,6 +295,7 @@ int64_t carve(const Program &p, int64_t P, char *base, TrainWs *w) {
     t.sv_h = (uint16_t *)take((size_t)8 * P * 256 * 2);
     t.sv_feat = (uint16_t *)take(P * 256 * 2);
     t.sv_hv = (uint16_t *)take(P * 128 * 2);
+    t.sv_bits = (uint8_t *)take(P * (8 * 32 + 16));
     t.g_rawb = (uint16_t *)take(P * 4 * 2);
     t.g_hv = (uint16_t *)take(P * 128 * 2);
     t.g_feat = (uint16_t *)take(P * 256 * 2);
@@ -314,6 +317,7 @@ void train_fill_args(const Program &p, int64_t P, void *workspace, MlpArgs *a) {
     TrainWs w;
     carve(p, P, static_cast<char *>(workspace), &w);
     a->sv_e = w.sv_e; a->sv_d = w.sv_d; a->sv_h = w.sv_h; a->sv_feat = w.sv_feat; a->sv_hv = w.sv_hv;
+    a->sv_bits = w.sv_bits;
     a->g_rawb = w.g_rawb; a->g_hv = w.g_hv; a->g_feat = w.g_feat; a->g_h = w.g_h;
 }
 
@@ -366,7 +370,7 @@ int train_param_grads(const Program &p, int64_t P, void *workspace, float *const
     carve(p, P, static_cast<char *>(workspace), &w);
     const int D = p.arch.D, W = p.arch.W, E = 32 * p.KE16, Dd = 32 * p.KD16, ic = p.input_ch, icv = p.input_ch_views;
     if (W != 256 || E != 64 || Dd != 32) return NERF_AMD_EUNSUPPORTED;
-    const int64_t HS = P * 256;
+    const int64_t HS = pad_points(P) * 256;
     const int Lx = p.arch.multires, Ld = p.arch.multires_views;
     int rc = 0;
     for (int l = 0; l < D && !rc; ++l) {

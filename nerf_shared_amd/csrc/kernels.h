@@ -32,7 +32,9 @@ struct MlpArgs {
     int32_t S;                     // samples per ray (ray index = p / S)
     int32_t out_ch;
     float *out;                    // [P, out_ch]
-    // training: activations saved by the forward for the backward pass, bf16, one row per point in
+    // training: every saved / gradient array below has pad_points(P) rows (the kernels store the rows of a
+    // workgroup's padding points unconditionally, which keeps their store counts compile-time constants).
+    // Activations saved by the forward for the backward pass, bf16, one row per point in
     // the k-slot order of the fragments ("slot-major": position 32*ks + 8*q + j of a row holds the
     // feature that slot (ks, q, j) of the B fragment holds; program.h acc16_col / gen16_col)
     uint16_t *sv_e;                // [P, 32*KE16]  encoded xyz
@@ -40,6 +42,8 @@ struct MlpArgs {
     uint16_t *sv_h;                // [8][P, 256]   outputs of pts_linears.0..7 (post-ReLU)
     uint16_t *sv_feat;             // [P, 256]      feature_linear output
     uint16_t *sv_hv;               // [P, 128]      views_linears.0 output (post-ReLU)
+    uint8_t *sv_bits;              // [8][P, 32 B] + [P, 16 B]: "activation > 0" bit rows of pts_linears.0..7 and
+                                   // views_linears.0 (lane quarter q owns bytes q*NK .. of a row; bit layout: mlp_bf16_s16.hip save_bits)
     // backward inputs / outputs
     const float *g_raw;            // [P, 4] dL/draw
     uint16_t *g_rawb;              // [P, 4] bf16 copy of g_raw (GEMM operand)
@@ -51,6 +55,9 @@ struct MlpArgs {
     float *g_rays;                 // [R, 6]  dL/d(origin, direction) accumulated with atomics (rays mode); or NULL
     float *g_vd;                   // [R, 3]  dL/d(view direction) accumulated with atomics; or NULL
 };
+
+// Rows of the training arrays: P rounded up to whole 256-point workgroups.
+constexpr int64_t pad_points(int64_t P) { return (P + 255) & ~(int64_t)255; }
 
 extern int g_variant;
 bool mlp_bf16_supported(int multires, int multires_views, int use_viewdirs);

@@ -150,16 +150,51 @@ __device__ __forceinline__ void encode16(float x0, float x1, float x2, int h, in
         for (int j = 0; j < 8; ++j) out[k * STRIDE][j] = (__bf16)vals[8 * k + j];
 }
 
-// Save NK k-steps of fragments (y[2*ks + cc]) as slot-major bf16 rows of ROW elements.
+// Save NK k-steps of fragments (y[2*ks + cc]) as slot-major bf16 rows of ROW elements.  Unconditional:
+// the training arrays have rows for a workgroup's padding points (kernels.h pad_points).
 template <int NK, int ROW>
-__device__ __forceinline__ void save_frags(uint16_t *base, const bf16x8 *y, const int64_t (&pidx)[2],
-                                           const bool (&valid)[2], int q) {
+__device__ __forceinline__ void save_frags(uint16_t *base, const bf16x8 *y, const int64_t (&pidx)[2], int q) {
     static_for<NK>([&](auto k_) {
         constexpr int k = k_;
         static_for<2>([&](auto cc_) {
             constexpr int cc = cc_;
-            if (valid[cc]) *reinterpret_cast<bf16x8 *>(base + pidx[cc] * ROW + k * 32 + q * 8) = y[2 * k + cc];
+            *reinterpret_cast<bf16x8 *>(base + pidx[cc] * ROW + k * 32 + q * 8) = y[2 * k + cc];
         });
+    });
+}
+
+// "activation > 0" bits of a post-ReLU layer for the backward's ReLU masks, 8 bits per fragment and
+// lane: dword k/4 of the lane's NK/4 dwords holds, for k-step k, bit 4*(k%4) + i = element 2i and bit
+// 16 + 4*(k%4) + i = element 2i + 1 (i = 0..3).  A lane quarter's dwords are contiguous at
+// row*4*NK + q*NK, so the backward fetches a whole layer's masks with one load per point.
+template <int NK>
+__device__ __forceinline__ void save_bits(uint8_t *base, const bf16x8 *y, const int64_t (&pidx)[2], int q) {
+    static_assert(NK == 4 || NK == 8, "one or two dwords of mask bits");
+    static_for<2>([&](auto cc_) {
+        constexpr int cc = cc_;
+        unsigned w[NK / 4];
+#pragma unroll
+        for (int i = 0; i < NK / 4; ++i) w[i] = 0;
+        static_for<NK>([&](auto k_) {
+            constexpr int k = k_;
+            const u32x4 v = __builtin_bit_cast(u32x4, y[2 * k + cc]);
+            unsigned t = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                unsigned m;
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(v[i]), "v"(0x00010001u));   // 1 per non-zero half
+                t |= m << i;
+            }
+            w[k / 4] |= t << (4 * (k % 4));
+        });
+        uint8_t *dst = base + pidx[cc] * (4 * NK) + q * NK;
+        if constexpr (NK == 8) {
+            typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+            u32x2 o = {w[0], w[1]};
+            *reinterpret_cast<u32x2 *>(dst) = o;
+        } else {
+            *reinterpret_cast<unsigned *>(dst) = w[0];
+        }
     });
 }
 
@@ -237,37 +272,40 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16_kernel(MlpArgs 
         static_for<C::LA>([&](auto i_) { constexpr int i = i_; c.q[i] = ring_frag<i>(c); });
     }
     // training forward: every layer's output also goes to HBM for the backward pass.  (These stores
-    // sit in the same vmcnt queue as the ring DMA, so the counted waits become conservative.)
-    const int64_t HS = a.P * 256;                               // one saved hidden layer
+    // sit in the same vmcnt queue as the ring DMA, so the counted waits are conservative right after a
+    // layer's burst; measured, a store ledger like the backward kernel's gains nothing here -- the
+    // kernel is bound by its 5.3 KB of writes per point.)
+    const int64_t HS = pad_points(a.P) * 256;                   // one saved hidden layer
+    const int64_t BS = pad_points(a.P) * 32;                    // one layer of mask-bit rows
     if constexpr (SAVE) {
-        save_frags<KE, 32 * KE>(a.sv_e, E, pidx, valid, q);
-        if constexpr (VD) save_frags<KD, 32 * KD>(a.sv_d, Dv, pidx, valid, q);
+        save_frags<KE, 32 * KE>(a.sv_e, E, pidx, q);
+        if constexpr (VD) save_frags<KD, 32 * KD>(a.sv_d, Dv, pidx, q);
     }
     bf16x8 A[16], B[16];
     layer16<Lay::F_L0, 0, 8, KE, 0, true, NB, NF>(c, E, E, A);
-    if constexpr (SAVE) save_frags<8, 256>(a.sv_h + 0 * HS, A, pidx, valid, q);
+    if constexpr (SAVE) { save_frags<8, 256>(a.sv_h + 0 * HS, A, pidx, q); save_bits<8>(a.sv_bits + 0 * BS, A, pidx, q); }
     layer16<Lay::F_L1 + 0 * 128, 16, 8, 8, 0, true, NB, NF>(c, A, A, B);
-    if constexpr (SAVE) save_frags<8, 256>(a.sv_h + 1 * HS, B, pidx, valid, q);
+    if constexpr (SAVE) { save_frags<8, 256>(a.sv_h + 1 * HS, B, pidx, q); save_bits<8>(a.sv_bits + 1 * BS, B, pidx, q); }
     layer16<Lay::F_L1 + 1 * 128, 32, 8, 8, 0, true, NB, NF>(c, B, B, A);
-    if constexpr (SAVE) save_frags<8, 256>(a.sv_h + 2 * HS, A, pidx, valid, q);
+    if constexpr (SAVE) { save_frags<8, 256>(a.sv_h + 2 * HS, A, pidx, q); save_bits<8>(a.sv_bits + 2 * BS, A, pidx, q); }
     layer16<Lay::F_L1 + 2 * 128, 48, 8, 8, 0, true, NB, NF>(c, A, A, B);
-    if constexpr (SAVE) save_frags<8, 256>(a.sv_h + 3 * HS, B, pidx, valid, q);
+    if constexpr (SAVE) { save_frags<8, 256>(a.sv_h + 3 * HS, B, pidx, q); save_bits<8>(a.sv_bits + 3 * BS, B, pidx, q); }
     layer16<Lay::F_L1 + 3 * 128, 64, 8, 8, 0, true, NB, NF>(c, B, B, A);
-    if constexpr (SAVE) save_frags<8, 256>(a.sv_h + 4 * HS, A, pidx, valid, q);
+    if constexpr (SAVE) { save_frags<8, 256>(a.sv_h + 4 * HS, A, pidx, q); save_bits<8>(a.sv_bits + 4 * BS, A, pidx, q); }
     layer16<Lay::F_L5, 80, 8, KE, 8, true, NB, NF>(c, E, A, B);            // skip: [input_pts | h]
-    if constexpr (SAVE) save_frags<8, 256>(a.sv_h + 5 * HS, B, pidx, valid, q);
+    if constexpr (SAVE) { save_frags<8, 256>(a.sv_h + 5 * HS, B, pidx, q); save_bits<8>(a.sv_bits + 5 * BS, B, pidx, q); }
     layer16<Lay::F_L6, 96, 8, 8, 0, true, NB, NF>(c, B, B, A);
-    if constexpr (SAVE) save_frags<8, 256>(a.sv_h + 6 * HS, A, pidx, valid, q);
+    if constexpr (SAVE) { save_frags<8, 256>(a.sv_h + 6 * HS, A, pidx, q); save_bits<8>(a.sv_bits + 6 * BS, A, pidx, q); }
     layer16<Lay::F_L6 + 128, 112, 8, 8, 0, true, NB, NF>(c, A, A, B);      // h7 in B
-    if constexpr (SAVE) save_frags<8, 256>(a.sv_h + 7 * HS, B, pidx, valid, q);
+    if constexpr (SAVE) { save_frags<8, 256>(a.sv_h + 7 * HS, B, pidx, q); save_bits<8>(a.sv_bits + 7 * BS, B, pidx, q); }
 
     if constexpr (VD) {
         layer16<Lay::F_FEAT, 128, 8, 8, 0, false, NB, NF>(c, B, B, A);     // feature (no activation)
-        if constexpr (SAVE) save_frags<8, 256>(a.sv_feat, A, pidx, valid, q);
+        if constexpr (SAVE) save_frags<8, 256>(a.sv_feat, A, pidx, q);
         f32x4 alpha[2], rgb[2];
         tile_single<Lay::F_ALPHA, 144, 8, NB, NF>(c, B, alpha);            // row 0 = sigma
         layer16<Lay::F_VIEWS, 145, 4, 8, KD, true, NB, NF>(c, A, Dv, B);   // views_linears.0 (128 rows)
-        if constexpr (SAVE) save_frags<4, 128>(a.sv_hv, B, pidx, valid, q);
+        if constexpr (SAVE) { save_frags<4, 128>(a.sv_hv, B, pidx, q); save_bits<4>(a.sv_bits + 8 * BS, B, pidx, q); }
         tile_single<Lay::F_RGB, 153, 4, NB, NF>(c, B, rgb);                // rows 0..2
         static_for<2>([&](auto cc_) {
             constexpr int cc = cc_;

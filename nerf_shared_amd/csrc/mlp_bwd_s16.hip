@@ -7,7 +7,8 @@
 // is the forward kernel's computation with transposed weights: the gradient tile of one
 // layer, converted to bf16 in place, is the B operand of the next (earlier) layer, so the
 // whole chain stays in registers exactly like the forward activations (mlp_bf16_s16.hip).
-// ReLU masks come from the activations the training forward saved; every g_pre(l) is
+// ReLU masks come from the bit rows the training forward saved (one bit per activation, 1/16 of
+// re-reading the bf16 activations); every g_pre(l) is
 // written to HBM (slot-major bf16 rows, same layout as the saved activations) for the
 // weight-gradient GEMMs  dW_l = g_pre(l)^T h_{l-1}  that follow (backward.hip).
 // Ray gradients: the gradient with respect to the encodings (three more transposed products whose
@@ -51,48 +52,65 @@ __device__ __forceinline__ void tpair(C &c, const bf16x8 *x1, const bf16x8 *x2, 
 }
 
 // bf16 gradient fragment from a tile pair, zeroed where the saved activation is zero (ReLU').
-template <bool MASK>
-__device__ __forceinline__ bf16x8 pack_grad(const f32x4 &even, const f32x4 &odd, const bf16x8 &h) {
+// The mask bits of this fragment sit at BIT0 + i (element 2i) and 16 + BIT0 + i (element 2i + 1) of
+// `bits` (mlp_bf16_s16.hip save_bits); each bit is sign-extended to a half-word.
+template <bool MASK, int BIT0>
+__device__ __forceinline__ bf16x8 pack_grad(const f32x4 &even, const f32x4 &odd, unsigned bits) {
     bf16x8 y;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { y[r] = (__bf16)even[r]; y[4 + r] = (__bf16)odd[r]; }
     if (MASK) {
         u32x4 v = __builtin_bit_cast(u32x4, y);
-        const u32x4 hv = __builtin_bit_cast(u32x4, h);
-        const unsigned ones = 0x00010001u;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            unsigned m;
-            asm("v_pk_min_u16 %0, %1, %2\n\tv_pk_sub_u16 %0, 0, %0" : "=&v"(m) : "v"(hv[i]), "v"(ones));   // 0xffff where h != 0
-            v[i] &= m;
+            const unsigned lo = (unsigned)__builtin_amdgcn_sbfe((int)bits, BIT0 + i, 1);
+            const unsigned hi = (unsigned)__builtin_amdgcn_sbfe((int)bits, 16 + BIT0 + i, 1);
+            v[i] &= __builtin_amdgcn_perm(hi, lo, 0x05040100u);       // {hi.half, lo.half}
         }
         y = __builtin_bit_cast(bf16x8, v);
     }
     return y;
 }
 
+// Mask bytes of one layer for this lane's two points (NPAIR bytes each): loaded one layer ahead of
+// their use so the wait the compiler places before the first use never reaches back to recent DMA.
+template <int NPAIR>
+struct MaskBits {
+    unsigned w[2][NPAIR / 4];
+};
+template <int NPAIR>
+__device__ __forceinline__ MaskBits<NPAIR> load_bits(const uint8_t *base, const int64_t (&pidx)[2], int q) {
+    static_assert(NPAIR == 4 || NPAIR == 8, "one or two dwords of mask bytes");
+    MaskBits<NPAIR> m;
+    static_for<2>([&](auto cc_) {
+        constexpr int cc = cc_;
+        const uint8_t *src = base + pidx[cc] * (4 * NPAIR) + q * NPAIR;
+        if constexpr (NPAIR == 8) {
+            typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+            const u32x2 v = *reinterpret_cast<const u32x2 *>(src);
+            m.w[cc][0] = v[0]; m.w[cc][1] = v[1];
+        } else {
+            m.w[cc][0] = *reinterpret_cast<const unsigned *>(src);
+        }
+    });
+    return m;
+}
+
 // One transposed layer: NPAIR pairs of input-feature tiles -> g[2 * NPAIR]; g is masked with the
-// saved activation rows at `mask` (ROW elements per point) and stored to `dst`.
+// layer's ReLU bits and stored to `dst` (ROW elements per point, rows of padding points included:
+// the store count per pair is a compile-time constant, see BwdLedger).
 template <int F0, int NPAIR, int K1, int K2, bool MASK, int ROW, int NB, int NFRAGS, class C>
-__device__ __forceinline__ void tlayer(C &c, const bf16x8 *x1, const bf16x8 *x2, bf16x8 *g, const uint16_t *mask,
-                                       uint16_t *dst, const int64_t (&pidx)[2], const bool (&valid)[2], int q) {
+__device__ __forceinline__ void tlayer(C &c, const bf16x8 *x1, const bf16x8 *x2, bf16x8 *g, const MaskBits<NPAIR> &mask,
+                                       uint16_t *dst, const int64_t (&pidx)[2], int q) {
     static_for<NPAIR>([&](auto p_) {
         constexpr int p = p_;
-        bf16x8 h[2];
-        if constexpr (MASK) {
-            static_for<2>([&](auto cc_) {
-                constexpr int cc = cc_;
-                const int64_t row = valid[cc] ? pidx[cc] : 0;
-                h[cc] = *reinterpret_cast<const bf16x8 *>(mask + row * ROW + p * 32 + q * 8);
-            });
-        }
         f32x4 acc[2][2];
         tpair<F0 + p * 2 * (K1 + K2), K1, K2, NB, NFRAGS>(c, x1, x2, acc);
-        g[2 * p] = pack_grad<MASK>(acc[0][0], acc[1][0], h[0]);
-        g[2 * p + 1] = pack_grad<MASK>(acc[0][1], acc[1][1], h[1]);
+        g[2 * p] = pack_grad<MASK, 4 * (p % 4)>(acc[0][0], acc[1][0], mask.w[0][p / 4]);
+        g[2 * p + 1] = pack_grad<MASK, 4 * (p % 4)>(acc[0][1], acc[1][1], mask.w[1][p / 4]);
         static_for<2>([&](auto cc_) {
             constexpr int cc = cc_;
-            if (valid[cc]) *reinterpret_cast<bf16x8 *>(dst + pidx[cc] * ROW + p * 32 + q * 8) = g[2 * p + cc];
+            *reinterpret_cast<bf16x8 *>(dst + pidx[cc] * ROW + p * 32 + q * 8) = g[2 * p + cc];
         });
     });
 }
@@ -171,6 +189,20 @@ struct LayoutB {
     static constexpr int F_END = F_E0 + 32;
 };
 
+// Row stores issued before fragment n (pipeline.h LEDGER): two per finished tile pair of a tlayer
+// (the encoding products store nothing).
+struct BwdLedger {
+    static constexpr int pairs_done(int n, int f0, int frags_per_pair, int n_pairs) {
+        const int d = n <= f0 ? 0 : (n - f0) / frags_per_pair;
+        return d > n_pairs ? n_pairs : d;
+    }
+    static constexpr int stores_before(int n) {
+        return 2 * (pairs_done(n, LayoutB::F_HV, 2, 4) + pairs_done(n, LayoutB::F_FEAT, 8, 8) +
+                    pairs_done(n, LayoutB::F_H8, 18, 8) + pairs_done(n, LayoutB::F_L7, 16, 24) +
+                    pairs_done(n, LayoutB::F_L4, 16, 32));
+    }
+};
+
 template <class C>
 __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bwd_s16_kernel(MlpArgs a) {
     constexpr int WG_POINTS = C::WAVES * 32;
@@ -231,34 +263,45 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bwd_s16_kernel(MlpArgs a
         block_sync<-1, NB>(c);
         static_for<C::LA>([&](auto i_) { constexpr int i = i_; c.q[i] = ring_frag<i>(c); });
     }
-    const int64_t HS = a.P * 256;
+    const int64_t HS = pad_points(a.P) * 256, BS = pad_points(a.P) * 32;
     const int hh = q >> 1, bb = q & 1;
     bf16x8 A[16], B[16];
     float gx[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, gd[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    const MaskBits<8> none = {};
     // g_hv = relu'(hv) * (W_rgb^T g_rgb)
-    tlayer<LayoutB::F_HV, 4, 1, 0, true, 128, NB, NF>(c, Grgb, Grgb, B, a.sv_hv, a.g_hv, pidx, valid, q);
+    const MaskBits<4> m_hv = load_bits<4>(a.sv_bits + 8 * BS, pidx, q);
+    MaskBits<8> m_cur = load_bits<8>(a.sv_bits + 7 * BS, pidx, q), m_next;
+    tlayer<LayoutB::F_HV, 4, 1, 0, true, 128, NB, NF>(c, Grgb, Grgb, B, m_hv, a.g_hv, pidx, q);
     // g_feat = W_views[:, :256]^T g_hv          (feature_linear has no activation)
-    tlayer<LayoutB::F_FEAT, 8, 4, 0, false, 256, NB, NF>(c, B, B, A, nullptr, a.g_feat, pidx, valid, q);
+    tlayer<LayoutB::F_FEAT, 8, 4, 0, false, 256, NB, NF>(c, B, B, A, none, a.g_feat, pidx, q);
     {   // view-direction encoding: g_dirs = W_views[:, 256:]^T g_hv, then through the encoding
         float g[2][8];
         tenc<LayoutB::F_DIRS, 1, 4, NB, NF>(c, B, g);
         static_for<2>([&](auto cc_) { constexpr int cc = cc_; encode16_bwd<4, 1>(dv[cc][0], dv[cc][1], dv[cc][2], hh, bb, g[cc], gd[cc]); });
     }
     // g_h8 = relu'(h8) * (W_feature^T g_feat + W_alpha^T g_sigma)
-    tlayer<LayoutB::F_H8, 8, 8, 1, true, 256, NB, NF>(c, A, Gsig, B, a.sv_h + 7 * HS, a.g_h + 7 * HS, pidx, valid, q);
+    m_next = load_bits<8>(a.sv_bits + 6 * BS, pidx, q);
+    tlayer<LayoutB::F_H8, 8, 8, 1, true, 256, NB, NF>(c, A, Gsig, B, m_cur, a.g_h + 7 * HS, pidx, q);
     // g_h(l-1) = relu'(h(l-1)) * (W_l^T g_h(l)),  l = 7 .. 1   (layer 5 uses the h-columns of its [e | h] input)
-    tlayer<LayoutB::F_L7 + 0 * 128, 8, 8, 0, true, 256, NB, NF>(c, B, B, A, a.sv_h + 6 * HS, a.g_h + 6 * HS, pidx, valid, q);
-    tlayer<LayoutB::F_L7 + 1 * 128, 8, 8, 0, true, 256, NB, NF>(c, A, A, B, a.sv_h + 5 * HS, a.g_h + 5 * HS, pidx, valid, q);
-    tlayer<LayoutB::F_L7 + 2 * 128, 8, 8, 0, true, 256, NB, NF>(c, B, B, A, a.sv_h + 4 * HS, a.g_h + 4 * HS, pidx, valid, q);
+    m_cur = m_next; m_next = load_bits<8>(a.sv_bits + 5 * BS, pidx, q);
+    tlayer<LayoutB::F_L7 + 0 * 128, 8, 8, 0, true, 256, NB, NF>(c, B, B, A, m_cur, a.g_h + 6 * HS, pidx, q);
+    m_cur = m_next; m_next = load_bits<8>(a.sv_bits + 4 * BS, pidx, q);
+    tlayer<LayoutB::F_L7 + 1 * 128, 8, 8, 0, true, 256, NB, NF>(c, A, A, B, m_cur, a.g_h + 5 * HS, pidx, q);
+    m_cur = m_next; m_next = load_bits<8>(a.sv_bits + 3 * BS, pidx, q);
+    tlayer<LayoutB::F_L7 + 2 * 128, 8, 8, 0, true, 256, NB, NF>(c, B, B, A, m_cur, a.g_h + 4 * HS, pidx, q);
     {   // xyz encoding through the skip layer's [input_pts] columns (its pre-activation gradient is still in B)
         float g[2][16];
         tenc<LayoutB::F_E5, 2, 8, NB, NF>(c, B, g);
         static_for<2>([&](auto cc_) { constexpr int cc = cc_; encode16_bwd<10, 2>(xp[cc][0], xp[cc][1], xp[cc][2], hh, bb, g[cc], gx[cc]); });
     }
-    tlayer<LayoutB::F_L4 + 0 * 128, 8, 8, 0, true, 256, NB, NF>(c, A, A, B, a.sv_h + 3 * HS, a.g_h + 3 * HS, pidx, valid, q);
-    tlayer<LayoutB::F_L4 + 1 * 128, 8, 8, 0, true, 256, NB, NF>(c, B, B, A, a.sv_h + 2 * HS, a.g_h + 2 * HS, pidx, valid, q);
-    tlayer<LayoutB::F_L4 + 2 * 128, 8, 8, 0, true, 256, NB, NF>(c, A, A, B, a.sv_h + 1 * HS, a.g_h + 1 * HS, pidx, valid, q);
-    tlayer<LayoutB::F_L4 + 3 * 128, 8, 8, 0, true, 256, NB, NF>(c, B, B, A, a.sv_h + 0 * HS, a.g_h + 0 * HS, pidx, valid, q);
+    m_cur = m_next; m_next = load_bits<8>(a.sv_bits + 2 * BS, pidx, q);
+    tlayer<LayoutB::F_L4 + 0 * 128, 8, 8, 0, true, 256, NB, NF>(c, A, A, B, m_cur, a.g_h + 3 * HS, pidx, q);
+    m_cur = m_next; m_next = load_bits<8>(a.sv_bits + 1 * BS, pidx, q);
+    tlayer<LayoutB::F_L4 + 1 * 128, 8, 8, 0, true, 256, NB, NF>(c, B, B, A, m_cur, a.g_h + 2 * HS, pidx, q);
+    m_cur = m_next; m_next = load_bits<8>(a.sv_bits + 0 * BS, pidx, q);
+    tlayer<LayoutB::F_L4 + 2 * 128, 8, 8, 0, true, 256, NB, NF>(c, A, A, B, m_cur, a.g_h + 1 * HS, pidx, q);
+    m_cur = m_next;
+    tlayer<LayoutB::F_L4 + 3 * 128, 8, 8, 0, true, 256, NB, NF>(c, B, B, A, m_cur, a.g_h + 0 * HS, pidx, q);
     {   // xyz encoding through pts_linears.0
         float g[2][16];
         tenc<LayoutB::F_E0, 2, 8, NB, NF>(c, A, g);
@@ -290,7 +333,7 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bwd_s16_kernel(MlpArgs a
 }
 
 int launch_mlp_bwd_s16(const MlpArgs &a, int n_frags_used, hipStream_t s) {
-    using C = Ctx<8, 16, 4, 8, 2>;
+    using C = Ctx<8, 16, 4, 8, 2, 0, 1, 0, BwdLedger>;
     if (n_frags_used != LayoutB::F_END) return NERF_AMD_EINVAL;
     if (a.P <= 0) return NERF_AMD_OK;
     if (a.P >= (int64_t)1 << 31) return NERF_AMD_EINVAL;

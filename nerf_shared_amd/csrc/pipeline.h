@@ -35,8 +35,17 @@ __device__ __forceinline__ void static_for(F &&f) {
 //          (NP = 2 halves the LDS read traffic; needs one wave per SIMD for its registers)
 //   OPT    code-generation options for A/B runs: 1 = ReLU on fp32 registers (one integer max per
 //          value) instead of one packed 16-bit max per converted pair
-template <int WAVES_, int BF_, int NS_, int PHASE_, int LA_ = 0, int ABL_ = 0, int NP_ = 1, int OPT_ = 0>
+//   LEDGER a compile-time count of the compiler-issued global stores that sit in program order
+//          before each fragment (training kernels).  Those stores share the in-order vmcnt queue
+//          with the ring DMA; the counted waits add the stores known to be younger than the block
+//          they wait for, so the younger DMA blocks stay in flight instead of being drained.
+//          A ledger may under-count (the wait only gets stricter) but must never over-count.
+struct NoLedger {
+    static constexpr int stores_before(int) { return 0; }
+};
+template <int WAVES_, int BF_, int NS_, int PHASE_, int LA_ = 0, int ABL_ = 0, int NP_ = 1, int OPT_ = 0, class LEDGER_ = NoLedger>
 struct Ctx {
+    using Ledger = LEDGER_;
     static constexpr int WAVES = WAVES_, BF = BF_, NS = NS_, PHASE = PHASE_, LA = LA_, ABL = ABL_, NP = NP_, OPT = OPT_;
     static constexpr int WAVES_PER_SIMD = (WAVES_ * NP_ >= 8 && NP_ == 1) ? 2 : 1;
     static_assert(LA_ == 0 || (PHASE_ > 0 && LA_ <= PHASE_ && PHASE_ + LA_ <= BF_), "read-ahead would cross an unpublished block");
@@ -87,7 +96,15 @@ __device__ __forceinline__ void block_sync(const C &c) {
     if constexpr (C::ABL & 1) return;
     constexpr int need = B + C::LOOKAHEAD;
     constexpr int last_issued = (B + C::NS - 2) < (NB - 1) ? (B + C::NS - 2) : (NB - 1);
-    constexpr int cnt = (last_issued > need ? last_issued - need : 0) * C::PIECES;
+    // stores issued since the sync that started block `need`'s DMA (sync -1 sits before fragment 0)
+    constexpr int issue_sync = need - (C::NS - 1);
+    constexpr int pos_now = B >= 0 ? B * C::BF + C::PHASE : 0;
+    constexpr int pos_then = issue_sync >= 0 ? issue_sync * C::BF + C::PHASE : 0;
+    constexpr int younger_stores = (C::PHASE > 0 && issue_sync >= -1 && last_issued > need)
+                                       ? C::Ledger::stores_before(pos_now) - C::Ledger::stores_before(pos_then) : 0;
+    static_assert(younger_stores >= 0, "ledger must be monotonic");
+    constexpr int cnt = (last_issued > need ? last_issued - need : 0) * C::PIECES + younger_stores;
+    static_assert(cnt <= 63, "vmcnt field is 6 bits");
     if constexpr (C::PHASE == 0) {
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(cnt) : "memory");
     } else {

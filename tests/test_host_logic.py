@@ -185,3 +185,24 @@ def test_gather_rows_gloo_world2(tmp_path):
     procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", port]) for r in range(2)]
     codes = [p.wait(timeout=180) for p in procs]
     assert codes == [0, 0]
+
+
+def test_backward_kernel_vmcnt_ledger_matches_its_isa(tmp_path):
+    """The dX-chain kernel's ring syncs count compiler-issued stores into their vmcnt waits
+    (csrc/pipeline.h LEDGER).  Replay the compiled instruction stream and check that no sync
+    publishes a weight block whose DMA could still be in flight."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import check_vmcnt
+    src = os.path.join(REPO, "nerf_shared_amd", "csrc", "mlp_bwd_s16.hip")
+    asm = str(tmp_path / "bwd.s")
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", src, "-o", asm],
+                   check=True, capture_output=True, timeout=600)
+    stats = check_vmcnt.check(asm, "mlp_bwd_s16_kernel", verbose=False)
+    assert stats["kernels"] == 1 and stats["ok"]
+    assert stats["syncs"] == 74 and stats["dma_pieces"] == 148
+    # the checker must be able to fail: claim two more stores than the ISA has at every sync
+    assert not check_vmcnt.check(asm, "mlp_bwd_s16_kernel", verbose=False, slack=-4)["ok"]
