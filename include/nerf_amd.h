@@ -250,6 +250,11 @@ int nerf_amd_make_rays(int32_t H, int32_t W, const double *K4, const float *c2w,
 int nerf_amd_get_rays_backward(int32_t H, int32_t W, const double *K4, int64_t pix0, int64_t n, const float *g_rays_o,
                                const float *g_rays_d, float *g_c2w, void *stream);
 
+/* Image output stage: utils.to8b (utils.py:30) as used by Renderer.render_from_batch_poses
+ * (render_utils.py:312): out[i] = uint8(255 * clip(x[i], 0, 1)), truncating; NaN -> 0.
+ * x [n] fp32 DEVICE (16-byte aligned), out [n] uint8 DEVICE (4-byte aligned). */
+int nerf_amd_to8b(const float *x, int64_t n, uint8_t *out, void *stream);
+
 /* ------------------------------------------------------------------------
  * Measurement hook (bench.py): while enabled, every field-MLP launch is
  * bracketed by hipEvents on its own stream.  nerf_amd_profile_collect waits for

@@ -493,6 +493,14 @@ int nerf_amd_get_rays_backward(int32_t H, int32_t W, const double *K4, int64_t p
     return rc ? fail(rc, "get_rays backward launch failed") : NERF_AMD_OK;
 }
 
+int nerf_amd_to8b(const float *x, int64_t n, uint8_t *out, void *stream) {
+    if (n < 0 || (n > 0 && (!x || !out))) return fail(NERF_AMD_EINVAL, "bad to8b arguments");
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out) & 3))
+        return fail(NERF_AMD_EINVAL, "to8b: x must be 16-byte and out 4-byte aligned");
+    int rc = launch_to8b(x, n, out, static_cast<hipStream_t>(stream));
+    return rc ? fail(rc, "to8b launch failed") : NERF_AMD_OK;
+}
+
 int nerf_amd_make_rays(int32_t H, int32_t W, const double *K4, const float *c2w, const float *c2w_static,
                        int64_t pix0, int64_t n, float near, float far, int use_viewdirs, int ndc,
                        float *rays_out, void *stream) {

@@ -109,6 +109,7 @@ int launch_ndc_rays(int H, int W, double focal, float near, const float *rays_o,
                     float *out_o, float *out_d, hipStream_t s);
 int launch_get_rays_bwd(int H, int W, const double *K4, int64_t pix0, int64_t n, const float *g_o, const float *g_d,
                         float *g_c2w, hipStream_t s);
+int launch_to8b(const float *x, int64_t n, uint8_t *out, hipStream_t s);
 int launch_make_rays(int H, int W, const double *K4, const float *c2w, const float *c2w_static,
                      int64_t pix0, int64_t n, float near, float far, int use_viewdirs, int ndc,
                      float *rays_out, hipStream_t s);

@@ -555,6 +555,34 @@ int launch_get_rays_bwd(int H, int W, const double *K4, int64_t pix0, int64_t n,
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
 
+// utils.to8b (/root/reference/nerf_shared/utils.py:30): uint8(255 * clip(x, 0, 1)), truncating.
+// HBM-bound: 4 B read + 1 B written per element; four elements per thread (one 16-byte load, one
+// dword store).  NaN quantises to 0 (what numpy's float->uint8 cast yields on x86).
+__device__ __forceinline__ unsigned quant8(float x) {
+    const float c = fminf(fmaxf(x, 0.0f), 1.0f);        // fmaxf(NaN, 0) = 0
+    return (unsigned)__fmul_rn(255.0f, c);              // fp32 product like numpy's float32 * 255, then truncation
+}
+
+__global__ __launch_bounds__(256) void to8b_kernel(const float *x, int64_t n, uint8_t *out) {
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 v = reinterpret_cast<const float4 *>(x)[i];
+        reinterpret_cast<unsigned *>(out)[i] = quant8(v.x) | (quant8(v.y) << 8) | (quant8(v.z) << 16) | (quant8(v.w) << 24);
+    }
+    const int64_t t = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = (uint8_t)quant8(x[t]);
+}
+
+int launch_to8b(const float *x, int64_t n, uint8_t *out, hipStream_t s) {
+    if (n <= 0) return NERF_AMD_OK;
+    int64_t blocks = ((n >> 2) + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(to8b_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n, out);
+    return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
+}
+
 int launch_make_rays(int H, int W, const double *K4, const float *c2w, const float *c2w_static,
                      int64_t pix0, int64_t n, float near, float far, int use_viewdirs, int ndc,
                      float *rays_out, hipStream_t s) {

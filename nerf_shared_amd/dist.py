@@ -58,9 +58,12 @@ def pack_maps(ret):
 
 
 def render_image_sharded(renderer, H, W, K, c2w, coarse_model, fine_model, chunk=1024 * 32,
-                         gather=True, group=None):
+                         gather=True, group=None, as_uint8=False):
     """Render this rank's pixel range of an H x W view; with gather=True rank 0
-    receives the whole (rgb [H,W,3], disp [H,W], acc [H,W]) and other ranks None."""
+    receives the whole (rgb [H,W,3], disp [H,W], acc [H,W]) and other ranks None.
+    as_uint8=True quantises the colours on each rank first (utils.to8b on the device) and gathers
+    only the [n, 3] uint8 rows -- 3 instead of 20 bytes per pixel on the wire; rank 0 gets the
+    uint8 image [H, W, 3] ready for the PNG writer."""
     from . import utils
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -68,7 +71,15 @@ def render_image_sharded(renderer, H, W, K, c2w, coarse_model, fine_model, chunk
     dev = next(coarse_model.parameters()).device
     batch = utils.make_ray_batch(H, W, K, c2w, renderer.near, renderer.far, renderer.use_viewdirs,
                                  renderer.ndc, device=dev, pix0=lo, n=hi - lo)
-    local = pack_maps(renderer.render_batch(coarse_model, fine_model, batch, chunk, False))
+    ret = renderer.render_batch(coarse_model, fine_model, batch, chunk, False)
+    if as_uint8:
+        local8 = utils.to8b(ret['rgb_map'])
+        if world > 1:
+            if not gather:
+                return local8
+            local8 = gather_rows(local8, H * W, 0, group)
+        return None if local8 is None else local8.reshape(H, W, 3)
+    local = pack_maps(ret)
     if world == 1:
         full = local
     elif gather:
@@ -78,3 +89,36 @@ def render_image_sharded(renderer, H, W, K, c2w, coarse_model, fine_model, chunk
     if full is None:
         return None
     return full[:, 0:3].reshape(H, W, 3), full[:, 3].reshape(H, W), full[:, 4].reshape(H, W)
+
+
+def render_poses_sharded(renderer, H, W, K, chunk, batch_c2w, coarse_model, fine_model, save_directory,
+                         group=None, io_workers=4):
+    """Renderer.render_from_batch_poses (render_utils.py:293-319) over the ranks of one node: whole
+    frames are dealt round-robin (rank r renders poses r, r+G, ...), each rank quantises and writes
+    its own 'NNN.png' files, so the only exchange is the barrier at the end.  Returns the indices of
+    the frames this rank wrote."""
+    import os
+    from . import image_io, utils
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    os.makedirs(save_directory, exist_ok=True)
+    mine = list(range(rank, len(batch_c2w), world))
+    copy_stream = None
+    with image_io.AsyncImageWriter(max(1, io_workers)) as writer, torch.no_grad():
+        for i in mine:
+            rgb = renderer.render_from_pose(H, W, K, chunk=chunk, c2w=batch_c2w[i], coarse_model=coarse_model,
+                                            fine_model=fine_model)[0]
+            rgb8 = utils.to8b(rgb)
+            if copy_stream is None:
+                copy_stream = torch.cuda.Stream(rgb8.device)
+            host = torch.empty(rgb8.shape, dtype=torch.uint8, pin_memory=True)
+            copy_stream.wait_stream(torch.cuda.current_stream(rgb8.device))
+            with torch.cuda.stream(copy_stream):
+                host.copy_(rgb8, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(copy_stream)
+            rgb8.record_stream(copy_stream)
+            writer.submit(os.path.join(save_directory, '{:03d}.png'.format(i)), host.numpy(), before=done.synchronize)
+    if world > 1:
+        dist.barrier(group)
+    return mine

@@ -437,29 +437,55 @@ class Renderer(torch.nn.Module):
             return _Raw2OutputsFn.apply(raw_c, z, d, noise, bool(self.white_bkgd))
 
     def render_from_batch_poses(self, H, W, K, chunk, batch_c2w, coarse_model, fine_model,
-                                retraw, save_directory, b_combine_as_video=False, tb_writer=None):
-        """Render a set of poses and save them (render_utils.py:293-319).  PNG/video
-        writing needs imageio, which is outside the hot path; without it the
-        frames are saved as .npy."""
+                                retraw, save_directory, b_combine_as_video=False, tb_writer=None, io_workers=4):
+        """Render a set of poses and save them as 000.png, 001.png, ... (render_utils.py:293-319).
+
+        The reference copies every float image to the host, quantises it with numpy and writes the
+        PNG before it renders the next pose.  Here the image is quantised on the GPU (utils.to8b ->
+        nerf_amd_to8b), one quarter of the bytes crosses PCIe into pinned memory on a copy stream,
+        and PNG encoding + file writes run on `io_workers` threads while the next pose renders
+        (io_workers=0: write synchronously).  Returns the uint8 frames [H, W, 3] (the reference
+        returns nothing).  Video output needs imageio's ffmpeg plugin and is skipped without it."""
+        from . import image_io
         os.makedirs(save_directory, exist_ok=True)
+        keep_float = b_combine_as_video or tb_writer is not None
+        rgbs, frames = [], []
+        writer = image_io.AsyncImageWriter(io_workers) if io_workers > 0 else None
+        copy_stream = None
         try:
-            import imageio
-        except ImportError:
-            imageio = None
-        rgbs = []
-        with torch.no_grad():
-            for i, c2w in enumerate(batch_c2w):
-                rgb, _, _, _ = self.render_from_pose(H, W, K, chunk=chunk, c2w=c2w,
-                                                     coarse_model=coarse_model, fine_model=fine_model)
-                rgbs.append(rgb.cpu().detach().numpy())
-                rgb8 = utils.to8b(rgbs[-1])
-                if imageio is not None:
-                    imageio.imwrite(os.path.join(save_directory, '{:03d}.png'.format(i)), rgb8)
-                else:
-                    np.save(os.path.join(save_directory, '{:03d}.npy'.format(i)), rgb8)
-            if b_combine_as_video and imageio is not None:
-                imageio.mimwrite(os.path.join(save_directory, 'video.mp4'), utils.to8b(rgbs), fps=30, quality=8)
-            if tb_writer is not None:
-                rgb_tensor = torch.tensor(utils.to8b(rgbs))
-                tb_writer.add_images('Test/Images', rgb_tensor, dataformats="NHWC")
-        return rgbs
+            with torch.no_grad():
+                for i, c2w in enumerate(batch_c2w):
+                    rgb, _, _, _ = self.render_from_pose(H, W, K, chunk=chunk, c2w=c2w,
+                                                         coarse_model=coarse_model, fine_model=fine_model)
+                    rgb8 = utils.to8b(rgb)
+                    filename = os.path.join(save_directory, '{:03d}.png'.format(i))
+                    if keep_float:
+                        rgbs.append(rgb.cpu().numpy())
+                    if writer is None:
+                        frames.append(rgb8.cpu().numpy())
+                        image_io.write_png(filename, frames[-1])
+                        continue
+                    dev = rgb8.device
+                    if copy_stream is None:
+                        copy_stream = torch.cuda.Stream(dev)
+                    host = torch.empty(rgb8.shape, dtype=torch.uint8, pin_memory=True)
+                    copy_stream.wait_stream(torch.cuda.current_stream(dev))
+                    with torch.cuda.stream(copy_stream):
+                        host.copy_(rgb8, non_blocking=True)
+                        done = torch.cuda.Event()
+                        done.record(copy_stream)
+                    rgb8.record_stream(copy_stream)
+                    frames.append(host.numpy())
+                    writer.submit(filename, frames[-1], before=done.synchronize)
+        finally:
+            if writer is not None:
+                writer.close()
+        if b_combine_as_video:
+            try:
+                import imageio
+                imageio.mimwrite(os.path.join(save_directory, 'video.mp4'), utils.to8b(np.stack(rgbs)), fps=30, quality=8)
+            except ImportError:
+                print("render_from_batch_poses: imageio is not installed, video.mp4 skipped (frames are on disk)")
+        if tb_writer is not None:
+            tb_writer.add_images('Test/Images', torch.tensor(utils.to8b(np.stack(rgbs))), dataformats="NHWC")
+        return frames

@@ -20,7 +20,23 @@ from ._lib import lib
 # ---------------------------------------------------------------- metrics (utils.py:24-30)
 img2mse = lambda x, y: torch.mean((x - y) ** 2)                                      # noqa: E731
 mse2psnr = lambda x: -10. * torch.log(x) / torch.log(torch.Tensor([10.]).to(x.device))  # noqa: E731
-to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)                           # noqa: E731
+
+
+def to8b(x):
+    """uint8(255 * clip(x, 0, 1)) (utils.py:30).  numpy in -> numpy out exactly like the reference;
+    a device tensor is quantised on the GPU (uint8 device tensor out, one quarter of the bytes to
+    copy or gather afterwards)."""
+    if isinstance(x, torch.Tensor):
+        _lib.require_device(x, "x")
+        src = x.detach().contiguous().float()
+        if src.data_ptr() % 16:
+            src = src.clone()                      # a view into the middle of a storage: the kernel loads 16 bytes at a time
+        out = torch.empty(src.shape, dtype=torch.uint8, device=src.device)
+        with torch.cuda.device(src.device):
+            _lib.check(lib.nerf_amd_to8b(src.data_ptr(), src.numel(), out.data_ptr(), _lib.stream_of(src.device)),
+                       "nerf_amd_to8b")
+        return out
+    return (255 * np.clip(x, 0, 1)).astype(np.uint8)
 
 
 def _default_device():

@@ -573,6 +573,24 @@ with torch.no_grad():
         ok = torch.equal(got[0], rgb) and torch.equal(got[2], acc) and torch.equal(torch.nan_to_num(got[1]), torch.nan_to_num(disp))
     else:
         ok = got is None
+    # uint8 gather: quantised on every rank, 3 bytes per pixel on the wire
+    got8 = nd.render_image_sharded(r, H, W, K, synth.LEGO_C2W, models[0], models[1], chunk=500, as_uint8=True)
+    if rank == 0:
+        from nerf_shared_amd import utils
+        ok = ok and got8.dtype == torch.uint8 and torch.equal(got8, utils.to8b(rgb))
+    else:
+        ok = ok and got8 is None
+    # whole frames dealt round-robin, every rank writes its own PNGs
+    import numpy as np
+    from nerf_shared_amd import image_io, utils
+    poses = [torch.from_numpy(synth.pose_spherical(a)) for a in (0.0, 40.0, 80.0)]
+    mine = nd.render_poses_sharded(r, H, W, K, 4096, poses, models[0], models[1], sys.argv[4])
+    ok = ok and mine == list(range(rank, 3, world))
+    if rank == 0:
+        ok = ok and sorted(os.listdir(sys.argv[4])) == ["000.png", "001.png", "002.png"]
+        for i, c2w in enumerate(poses):
+            want = utils.to8b(r.render(H, W, K, models[0], models[1], chunk=4096, c2w=c2w, retraw=False)[0]).cpu().numpy()
+            ok = ok and np.array_equal(image_io.read_image(os.path.join(sys.argv[4], "%%03d.png" %% i)), want)
 dist.barrier(); dist.destroy_process_group()
 sys.exit(0 if ok else 1)
 """
@@ -587,7 +605,8 @@ def test_sharded_render_two_ranks_matches_single(dev, tmp_path):
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script.write_text(_SHARD_WORKER % {"repo": repo})
     port = str(29600 + os.getpid() % 2000)
-    procs = [subprocess.Popen([sys.executable, str(script), str(rk), "2", port]) for rk in range(2)]
+    frames = tmp_path / "frames"
+    procs = [subprocess.Popen([sys.executable, str(script), str(rk), "2", port, str(frames)]) for rk in range(2)]
     codes = [p.wait(timeout=170) for p in procs]
     assert codes == [0, 0]
 
@@ -619,7 +638,30 @@ def test_staticcam_overlap_and_batch_poses(dev, tmp_path):
     rgb1 = r.render(H, W, K, coarse_gpu, fine_gpu, chunk=100, c2w=c2w, c2w_staticcam=c2w_s, retraw=False)[0]
     close(rgb2, rgb1, atol=0)
     # batch of poses -> frames on disk
-    out = r.render_from_batch_poses(H, W, K, 4096, [c2w, c2w_s], coarse_gpu, fine_gpu, False, str(tmp_path / "frames"))
-    assert len(out) == 2 and out[0].shape == (H, W, 3)
-    assert len(os.listdir(tmp_path / "frames")) == 2
-    close(torch.from_numpy(out[1]), plain.cpu(), atol=0)
+    # batch of poses -> quantised on the GPU, PNG frames on disk (asynchronous and synchronous writers)
+    from nerf_shared_amd import image_io, utils as amd_utils
+    want8 = amd_utils.to8b(plain.cpu().numpy())                 # the reference's numpy to8b
+    for workers in (4, 0):
+        d = tmp_path / ("frames%d" % workers)
+        out = r.render_from_batch_poses(H, W, K, 4096, [c2w, c2w_s], coarse_gpu, fine_gpu, False, str(d), io_workers=workers)
+        assert len(out) == 2 and out[0].shape == (H, W, 3) and out[0].dtype == np.uint8
+        assert sorted(os.listdir(d)) == ["000.png", "001.png"]
+        assert np.array_equal(out[1], want8)
+        assert np.array_equal(image_io.read_image(str(d / "001.png")), want8)
+        assert np.array_equal(image_io.decode_png(open(d / "001.png", "rb").read()), want8)
+
+
+def test_to8b_matches_numpy_bit_for_bit(dev):
+    """utils.to8b on the device (nerf_amd_to8b) against the reference's numpy expression
+    (utils.py:30) on edge values, every multiple of 1/255 +- 1 ulp, and random data of odd length."""
+    from nerf_shared_amd import utils as amd_utils
+    k = np.arange(256, dtype=np.float32) / np.float32(255)
+    edge = np.concatenate([k, np.nextafter(k, np.float32(2)), np.nextafter(k, np.float32(-1)),
+                           np.array([-1e30, -1.0, -0.0, 0.0, 1e-45, 0.5, 1.0, 1.0000001, 7.0, 1e30, np.inf, -np.inf], np.float32)])
+    rng = np.random.default_rng(5)
+    rnd = rng.uniform(-0.2, 1.2, size=(401, 399, 3)).astype(np.float32)        # odd element count: tail path
+    for x in (edge, rnd, rnd.reshape(-1)[:7], rnd[:0]):
+        got = amd_utils.to8b(torch.from_numpy(x).to(dev))
+        assert got.dtype == torch.uint8 and got.shape == x.shape
+        assert np.array_equal(got.cpu().numpy(), (255 * np.clip(x, 0, 1)).astype(np.uint8))
+    assert amd_utils.to8b(torch.tensor([float("nan")], device=dev)).item() == 0

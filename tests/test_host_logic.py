@@ -206,3 +206,43 @@ def test_backward_kernel_vmcnt_ledger_matches_its_isa(tmp_path):
     assert stats["syncs"] == 74 and stats["dma_pieces"] == 148
     # the checker must be able to fail: claim two more stores than the ISA has at every sync
     assert not check_vmcnt.check(asm, "mlp_bwd_s16_kernel", verbose=False, slack=-4)["ok"]
+
+
+def test_png_codec_roundtrip_and_async_writer(tmp_path):
+    """image_io: the zlib PNG writer/reader that replaces imageio for the render output and the
+    dataset frames (render_utils.py:312-315, load_blender.py:69)."""
+    from nerf_shared_amd import image_io
+    rng = np.random.default_rng(0)
+    for shape in ((5, 7), (9, 4, 1), (16, 11, 3), (8, 8, 4)):
+        img = rng.integers(0, 256, size=shape, dtype=np.uint8)
+        back = image_io.decode_png(image_io.encode_png(img))
+        assert np.array_equal(back, img.reshape(back.shape))
+    with pytest.raises(TypeError):
+        image_io.encode_png(np.zeros((4, 4, 3), np.float32))
+    # a smooth image makes Pillow's encoder choose the Sub/Up/Average/Paeth filters: decode them all
+    try:
+        from PIL import Image
+    except ImportError:
+        Image = None
+    yy, xx = np.mgrid[0:64, 0:48]
+    smooth = np.stack([(xx * 5) % 256, (yy * 3 + xx) % 256, (xx * yy) % 256, 255 - xx], -1).astype(np.uint8)
+    if Image is not None:
+        path = str(tmp_path / "pil.png")
+        Image.fromarray(smooth).save(path, optimize=True)
+        data = open(path, "rb").read()
+        assert np.array_equal(image_io.decode_png(data), smooth)
+        assert np.array_equal(image_io.read_image(path), smooth)
+        own = str(tmp_path / "own.png")
+        image_io.write_png(own, smooth[..., :3])
+        assert np.array_equal(np.asarray(Image.open(own)), smooth[..., :3])
+    # asynchronous writer: many frames, results identical to the synchronous path, errors surface
+    frames = [rng.integers(0, 256, size=(40, 30, 3), dtype=np.uint8) for _ in range(12)]
+    with image_io.AsyncImageWriter(workers=3) as w:
+        for i, f in enumerate(frames):
+            w.submit(str(tmp_path / ("%03d.png" % i)), f)
+    for i, f in enumerate(frames):
+        assert np.array_equal(image_io.read_image(str(tmp_path / ("%03d.png" % i))), f)
+    w = image_io.AsyncImageWriter(workers=1)
+    w.submit(str(tmp_path / "missing_dir" / "x.png"), frames[0])
+    with pytest.raises(OSError):
+        w.close()
