@@ -254,6 +254,51 @@ def load_checkpoint(coarse_model, fine_model, optimizer, args, b_load_ckpnt_as_t
     return ckpt['global_step']
 
 
+# ---------------------------------------------------------------- datasets (utils.py:216-313)
+def load_datasets(args):
+    """Scene on disk -> (images, poses, render_poses, [H, W, focal], (i_train, i_val, i_test), K,
+    {'near', 'far'}) for dataset_type 'blender' and 'llff' (utils.py:216-313).  The LINEMOD and
+    deepvoxels loaders of the reference are not part of this build."""
+    from . import load_blender, load_llff
+    if args.dataset_type == 'llff':
+        images, poses, bds, render_poses, i_test = load_llff.load_llff_data(
+            args.datadir, args.factor, recenter=True, bd_factor=.75, spherify=args.spherify)
+        hwf = poses[0, :3, -1]
+        poses = poses[:, :3, :4]
+        print('Loaded llff', images.shape, render_poses.shape, hwf, args.datadir)
+        if not isinstance(i_test, list):
+            i_test = [i_test]
+        if args.llffhold > 0:
+            print('Auto LLFF holdout,', args.llffhold)
+            i_test = np.arange(images.shape[0])[::args.llffhold]
+        i_val = i_test
+        i_train = np.array([i for i in np.arange(int(images.shape[0])) if (i not in i_test and i not in i_val)])
+        if args.no_ndc:
+            near, far = np.ndarray.min(bds) * .9, np.ndarray.max(bds) * 1.
+        else:
+            near, far = 0., 1.
+        print('NEAR FAR', near, far)
+    elif args.dataset_type == 'blender':
+        images, poses, render_poses, hwf, i_split, near, far = load_blender.load_blender_data(
+            args.datadir, args.half_res, args.testskip)
+        print('Loaded blender', images.shape, render_poses.shape, hwf, args.datadir)
+        i_train, i_val, i_test = i_split
+        if args.white_bkgd:
+            images = images[..., :3] * images[..., -1:] + (1. - images[..., -1:])
+        else:
+            images = images[..., :3]
+    else:
+        raise NotImplementedError("dataset_type %r: this build reads 'blender' and 'llff' scenes" % (args.dataset_type,))
+
+    H, W, focal = hwf
+    H, W = int(H), int(W)
+    hwf = [H, W, focal]
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+    if getattr(args, 'render_test', False):
+        render_poses = np.array(poses[i_test])
+    return images, poses, render_poses, hwf, (i_train, i_val, i_test), K, {'near': near, 'far': far}
+
+
 # ---------------------------------------------------------------- training ray batches (utils.py:360-442)
 def batch_training_data(args, poses, hwf, K, images, i_train):
     """Device-resident version of utils.py:360-392: with ray batching (not args.no_batching) the
@@ -305,6 +350,8 @@ def sample_random_ray_batch(args, images, poses, rays_rgb, N_rand, use_batching,
     else:
         ys, xs = torch.arange(H, device=target.device), torch.arange(W, device=target.device)
     n = ys.numel() * xs.numel()
+    if N_rand > n:
+        raise ValueError("Cannot take a larger sample than population when 'replace=False'")    # np.random.choice's error
     sel = torch.randperm(n, device=target.device)[:N_rand]            # without replacement, as np.random.choice(replace=False)
     yy, xx = ys[sel // xs.numel()], xs[sel % xs.numel()]
     batch_rays = torch.stack([rays_o[yy, xx], rays_d[yy, xx]], 0)

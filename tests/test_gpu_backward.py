@@ -241,7 +241,10 @@ def sphere_run(dev):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from tools import train_demo
-    return train_demo.run(steps=300, res=48, views=8, verbose=False)
+    import tempfile
+    # the scene goes to disk in the NeRF-synthetic format first; training reads it back with utils.load_datasets
+    with tempfile.TemporaryDirectory() as scene:
+        return train_demo.run(steps=300, res=48, views=8, verbose=False, scene_dir=scene)
 
 
 def test_train_demo_learns_a_scene_and_checkpoints_roundtrip(dev, tmp_path, sphere_run):
@@ -249,7 +252,7 @@ def test_train_demo_learns_a_scene_and_checkpoints_roundtrip(dev, tmp_path, sphe
     held-out-view PSNR by > 10 dB; the checkpoint (reference .tar layout, utils.py:444-456) reloads
     into fresh models bit-identically."""
     from nerf_shared_amd import nerf, render_utils, utils
-    out, (coarse, fine, opt, args) = sphere_run
+    out, (coarse, fine, opt, args, renderer, (H, W, K), poses_t, images, i_test) = sphere_run
     print(out)
     assert out["psnr_after"] > out["psnr_before"] + 10.0 and out["psnr_after"] > 18.0
     args.basedir, args.expname, args.ft_path, args.no_reload = str(tmp_path), "demo", None, False
@@ -259,6 +262,13 @@ def test_train_demo_learns_a_scene_and_checkpoints_roundtrip(dev, tmp_path, sphe
     c2, f2 = utils.create_nerf_models(args, dev)
     step = utils.load_checkpoint(c2, f2, utils.get_optimizer(c2, f2, args), args)
     assert step == 300 and not any(p.requires_grad for p in c2.parameters())
+    # the held-out view through the image output stage: PNG on disk vs the ground-truth frame (8-bit PSNR)
+    from nerf_shared_amd import image_io
+    frames = renderer.render_from_batch_poses(H, W, K, 32768, [poses_t[i_test, :3, :4]], coarse, fine, False, str(tmp_path / "test"))
+    png = image_io.read_image(str(tmp_path / "test" / "000.png")).astype(np.float64) / 255.
+    assert np.array_equal(png, frames[0] / 255.)
+    psnr8 = -10. * np.log10(np.mean((png - images[i_test].cpu().numpy().astype(np.float64)) ** 2))
+    assert abs(psnr8 - out["psnr_after"]) < 0.5, (psnr8, out["psnr_after"])
     r = render_utils.Renderer(perturb=0.0, N_importance=128, N_samples=64, use_viewdirs=True, white_bkgd=True, near=2.0, far=6.0)
     K = synth.lego_intrinsics(32, 32)
     with torch.no_grad():
@@ -346,7 +356,7 @@ def test_pose_optimisation_recovers_a_translation(dev, sphere_run):
     ((ro2 * wo.cpu()).sum() + (rd2 * wd.cpu()).sum()).backward()
     assert rel_err(c2w.grad, c_cpu.grad) < 1e-5
     # (b) recover a translation offset
-    _, (mc, mf, _, _) = sphere_run
+    _, (mc, mf) = sphere_run[0], sphere_run[1][:2]
     was = [p.requires_grad for p in mc.parameters()]
     mc.requires_grad_(False)
     mf.requires_grad_(False)
@@ -373,3 +383,56 @@ def test_pose_optimisation_recovers_a_translation(dev, sphere_run):
     mc.requires_grad_(was[0])
     mf.requires_grad_(was[0])
     assert losses[-1] < 0.3 * losses[0] and dists[-1] < 0.5 * dists[0]
+
+
+def test_training_ray_bank_and_batches(dev):
+    """utils.batch_training_data / sample_random_ray_batch (utils.py:360-442) as the device-resident
+    sampler: the bank is a permutation of (get_rays(pose), pixels) of the training images only; an
+    epoch visits every ray once, then reshuffles; the per-image mode samples without replacement and
+    honours the centre crop.  Pixels carry their own (image, y, x) code so rows can be traced."""
+    from types import SimpleNamespace
+    from nerf_shared_amd import utils
+    H, W, N = 6, 10, 4
+    K = synth.lego_intrinsics(H, W)
+    poses = np.stack([np.concatenate([synth.pose_spherical(40.0 * i), [[0, 0, 0, 1]]], 0) for i in range(N)]).astype(np.float32)
+    img_i, yy, xx = np.meshgrid(np.arange(N), np.arange(H), np.arange(W), indexing="ij")
+    images = np.stack([img_i, yy, xx], -1).astype(np.float32)                      # colour = (image, row, column)
+    i_train = [0, 2, 3]
+    args = SimpleNamespace(N_rand=32, no_batching=False, precrop_iters=0, precrop_frac=0.5)
+    hwf = (H, W, K[0][0])
+    torch.manual_seed(0)
+    np.random.seed(0)
+    imgs_t, poses_t, bank, use_batching, N_rand, i_batch = utils.batch_training_data(args, poses, hwf, K, images, i_train)
+    assert use_batching and N_rand == 32 and i_batch == 0 and bank.shape == (len(i_train) * H * W, 3, 3)
+    code = bank[:, 2].cpu().numpy().astype(int)
+    assert sorted(map(tuple, code)) == sorted((i, y, x) for i in i_train for y in range(H) for x in range(W))
+    assert not np.array_equal(code, np.array(sorted(map(tuple, code))))           # shuffled
+    want = {i: O.get_rays(H, W, K, torch.from_numpy(poses[i, :3, :4])) for i in i_train}
+    ro = torch.stack([want[i][0][y, x] for i, y, x in code])
+    rd = torch.stack([want[i][1][y, x] for i, y, x in code])
+    assert torch.equal(bank[:, 0].cpu(), ro) and (bank[:, 1].cpu() - rd).abs().max() < 1e-6
+    # one epoch: every ray once; the batch that completes it triggers a reshuffle
+    seen, steps = [], -(-bank.shape[0] // 32)
+    for i in range(steps):
+        rays, target, bank2, i_batch = utils.sample_random_ray_batch(args, imgs_t, poses_t, bank, 32, True, i_batch, i_train, hwf, K, 0, i)
+        assert rays.shape[0] == 2 and rays.shape[2] == 3 and target.shape == (rays.shape[1], 3)
+        seen += list(map(tuple, target.cpu().numpy().astype(int)))
+        if i < steps - 1:
+            assert bank2 is bank
+    assert sorted(seen) == sorted(map(tuple, code)) and i_batch == 0
+    assert not torch.equal(bank2, bank) and sorted(map(tuple, bank2[:, 2].cpu().numpy().astype(int))) == sorted(map(tuple, code))
+    # per-image sampling, cropped then full frame
+    args = SimpleNamespace(N_rand=6, no_batching=True, precrop_iters=3, precrop_frac=0.5)
+    imgs_t, poses_t, bank, use_batching, N_rand, i_batch = utils.batch_training_data(args, poses, hwf, K, images, i_train)
+    assert not use_batching and i_batch is None and bank.numel() == 0
+    for it in (0, 5):
+        rays, target, _, _ = utils.sample_random_ray_batch(args, imgs_t, poses_t, bank, 6, False, None, i_train, hwf, K, 0, it)
+        c = target.cpu().numpy().astype(int)
+        assert len(set(map(tuple, c))) == 6 and len(set(c[:, 0])) == 1 and c[0, 0] in i_train        # one image, no repeats
+        if it < 3:       # dH = int(3 * .5) = 1, dW = int(5 * .5) = 2: rows 2..3, columns 3..6
+            assert c[:, 1].min() >= 2 and c[:, 1].max() <= 3 and c[:, 2].min() >= 3 and c[:, 2].max() <= 6
+        o, d = want[c[0, 0]]
+        assert torch.equal(rays[0].cpu(), torch.stack([o[y, x] for _, y, x in c]))
+        assert (rays[1].cpu() - torch.stack([d[y, x] for _, y, x in c])).abs().max() < 1e-6
+    with pytest.raises(ValueError):          # 12 distinct pixels out of a 2 x 4 crop: np.random.choice refuses, so do we
+        utils.sample_random_ray_batch(args, imgs_t, poses_t, bank, 12, False, None, i_train, hwf, K, 0, 0)

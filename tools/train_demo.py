@@ -37,7 +37,26 @@ def sphere_image(H, W, K, c2w, dev, radius=1.0):
     return img
 
 
-def run(steps=600, res=64, views=12, n_rand=1024, seed=0, verbose=True):
+def write_blender_scene(root, H, W, poses, images, i_train, i_test):
+    """The analytic frames as a NeRF-synthetic scene on disk: transforms_{train,val,test}.json (with the
+    reference's near / far keys, load_blender.py:57) + RGBA PNGs (alpha = 0 on the white background)."""
+    from nerf_shared_amd import image_io
+    angle_x = 2.0 * np.arctan(0.5 * W / synth.lego_intrinsics(H, W)[0, 0])
+    for split, ids in (("train", i_train), ("val", [i_test]), ("test", [i_test])):
+        os.makedirs(os.path.join(root, split), exist_ok=True)
+        meta = {"camera_angle_x": float(angle_x), "near": 2.0, "far": 6.0, "frames": []}
+        for k, i in enumerate(ids):
+            rgb = images[i].cpu().numpy()
+            alpha = (np.abs(rgb - 1.0).max(-1, keepdims=True) > 0).astype(np.float32)       # background is exactly white
+            image_io.write_png(os.path.join(root, split, "r_%d.png" % k), utils.to8b(np.concatenate([rgb, alpha], -1)))
+            meta["frames"].append({"file_path": "./%s/r_%d" % (split, k), "transform_matrix": poses[i].tolist()})
+        with open(os.path.join(root, "transforms_%s.json" % split), "w") as f:
+            json.dump(meta, f)
+
+
+def run(steps=600, res=64, views=12, n_rand=1024, seed=0, verbose=True, scene_dir=None):
+    """scene_dir: write the scene to disk in the Blender format first and train from what
+    utils.load_datasets reads back (8-bit frames) instead of from the in-memory float images."""
     torch.manual_seed(seed)
     np.random.seed(seed)
     dev = torch.device("cuda:0")
@@ -47,12 +66,22 @@ def run(steps=600, res=64, views=12, n_rand=1024, seed=0, verbose=True):
                       for i, th in enumerate(np.linspace(-180, 180, views + 1)[:-1])], 0).astype(np.float32)
     images = torch.stack([sphere_image(H, W, K, p[:3, :4], dev) for p in poses], 0)
     i_train, i_test = list(range(1, views)), 0
+    near, far = 2.0, 6.0
+    if scene_dir is not None:
+        write_blender_scene(scene_dir, H, W, poses, images, i_train, i_test)
+        largs = SimpleNamespace(dataset_type="blender", datadir=scene_dir, half_res=False, testskip=1, white_bkgd=True,
+                                render_test=False)
+        imgs_np, poses, _, hwf, (i_train, _, i_test_arr), K, bds = utils.load_datasets(largs)
+        assert hwf[:2] == [H, W] and abs(hwf[2] - synth.lego_intrinsics(H, W)[0, 0]) < 1e-3 * hwf[2]
+        images = torch.from_numpy(np.ascontiguousarray(imgs_np)).float().to(dev)
+        i_train, i_test = list(i_train), int(i_test_arr[0])
+        near, far = bds["near"], bds["far"]
     args = SimpleNamespace(N_rand=n_rand, no_batching=False, lrate=5e-4, lrate_decay=250, netdepth=8, netwidth=256,
                            netdepth_fine=8, netwidth_fine=256, N_importance=128, use_viewdirs=True, multires=10,
                            multires_views=4, i_embed=0)
     coarse, fine = utils.create_nerf_models(args, dev)
     renderer = render_utils.Renderer(perturb=1.0, N_importance=128, N_samples=64, use_viewdirs=True, white_bkgd=True,
-                                     raw_noise_std=0.0, near=2.0, far=6.0)
+                                     raw_noise_std=0.0, near=near, far=far)
     opt = utils.get_optimizer(coarse, fine, args)
     images, poses_t, rays_rgb, use_batching, N_rand, i_batch = utils.batch_training_data(args, poses, (H, W, K[0][0]), K, images, i_train)
 
@@ -81,7 +110,7 @@ def run(steps=600, res=64, views=12, n_rand=1024, seed=0, verbose=True):
     dt = time.perf_counter() - t0
     out = {"steps": steps, "rays_per_step": n_rand, "train_s": dt, "steps_per_s": steps / dt,
            "psnr_before": psnr0, "psnr_after": test_psnr(), "final_loss": float(loss.detach())}
-    return out, (coarse, fine, opt, args)
+    return out, (coarse, fine, opt, args, renderer, (H, W, K), poses_t, images, i_test)
 
 
 if __name__ == "__main__":
@@ -89,5 +118,6 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=600)
     ap.add_argument("--res", type=int, default=64)
     ap.add_argument("--views", type=int, default=12)
+    ap.add_argument("--scene-dir", default=None, help="write the scene in the Blender format here and train from disk")
     a = ap.parse_args()
-    print(json.dumps(run(a.steps, a.res, a.views)[0]))
+    print(json.dumps(run(a.steps, a.res, a.views, scene_dir=a.scene_dir)[0]))
