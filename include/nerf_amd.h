@@ -146,14 +146,14 @@ int nerf_amd_raw2outputs_backward(const float *raw, int32_t raw_ch, const float 
 
 /* ------------------------------------------------------------------------
  * Training (what loss.backward() does through NeRF.forward, main.py:85-104).
- * Covered: the D=8, W=256, skips=[4], multires 10/4 view-branch model; gradients of the parameters,
+ * Covered: the D=8, W=256, skips=[4] view-branch model with multires 10/4 or 15/6 (every config the
+ * reference ships); gradients of the parameters,
  * of the points / rays (through the positional encoding) and of the view directions; bf16 operands /
  * fp32 accumulation.
  *   forward_train : the fused bf16 forward (explicit pts + viewdirs, or rays + z_vals with pts = o + d z) that also saves every
  *                   layer's activations in `workspace` (nerf_amd_train_workspace bytes, 256-B aligned)
  *   backward      : dL/draw [P,4] -> gradients of every nn.Linear weight [out,in] and bias [out]
- *                   (fp32 device tensors in nerf_amd_model_update order; the kernels ACCUMULATE into
- *                   them with float atomics, so pass zeroed tensors for plain gradients)
+ *                   (fp32 device tensors in nerf_amd_model_update order, overwritten)
  * ------------------------------------------------------------------------ */
 int     nerf_amd_model_supports_training(const nerf_amd_model *m);
 int64_t nerf_amd_train_workspace(const nerf_amd_model *m, int64_t n_points);

@@ -308,7 +308,8 @@ int64_t carve(const Program &p, int64_t P_points, char *base, TrainWs *w) {
 
 bool train_supported(const Program &p) {
     const nerf_amd_arch &a = p.arch;
-    return p.bf16_ok && a.use_viewdirs && a.i_embed == 0 && a.multires == 10 && a.multires_views == 4;
+    return p.bf16_ok && a.use_viewdirs && a.i_embed == 0 &&
+           ((a.multires == 10 && a.multires_views == 4) || (a.multires == 15 && a.multires_views == 6));
 }
 
 int64_t train_workspace_bytes(const Program &p, int64_t P) { return carve(p, P, nullptr, nullptr); }
@@ -357,19 +358,21 @@ static int weight_grad(hipStream_t s, int64_t P, float *slab, const uint16_t *X,
     r.out_kind = PERM_ACC; r.in_kind = in_kind; r.in_L = in_L; r.n_valid = n_valid; r.m_valid = m_valid;
     if (n_out_slots == 256 && n_in_slots == 256) return launch_dw<16, 16, 4, 2>(a, r, s);
     if (n_out_slots == 256 && n_in_slots == 64) return launch_dw<16, 4, 8, 1>(a, r, s);
+    if (n_out_slots == 256 && n_in_slots == 96) return launch_dw<16, 6, 4, 2>(a, r, s);
+    if (n_out_slots == 128 && n_in_slots == 64) return launch_dw<8, 4, 8, 1>(a, r, s);
     if (n_out_slots == 128 && n_in_slots == 256) return launch_dw<8, 16, 4, 2>(a, r, s);
     if (n_out_slots == 128 && n_in_slots == 32) return launch_dw<8, 2, 8, 1>(a, r, s);
     return NERF_AMD_EUNSUPPORTED;
 }
 
-// Parameter gradients of the view-branch (10,4) model from the saved activations and the
+// Parameter gradients of the view-branch model from the saved activations and the
 // pre-activation gradients the dX-chain kernel left in the workspace.  Every product overwrites
 // its destination (no accumulation into gw / gb).
 int train_param_grads(const Program &p, int64_t P, void *workspace, float *const *gw, float *const *gb, hipStream_t s) {
     TrainWs w;
     carve(p, P, static_cast<char *>(workspace), &w);
     const int D = p.arch.D, W = p.arch.W, E = 32 * p.KE16, Dd = 32 * p.KD16, ic = p.input_ch, icv = p.input_ch_views;
-    if (W != 256 || E != 64 || Dd != 32) return NERF_AMD_EUNSUPPORTED;
+    if (W != 256 || (E != 64 && E != 96) || (Dd != 32 && Dd != 64)) return NERF_AMD_EUNSUPPORTED;
     const int64_t HS = pad_points(P) * 256;
     const int Lx = p.arch.multires, Ld = p.arch.multires_views;
     int rc = 0;

@@ -284,7 +284,7 @@ int nerf_amd_field_forward_train(const nerf_amd_model *m, const float *pts, cons
     if (!m || R < 0 || S < 1) return fail(NERF_AMD_EINVAL, "bad forward_train arguments");
     if (!pts && ray_ch != 11) return fail(NERF_AMD_EINVAL, "rays must be [R,11]");
     if (pts && !viewdirs) return fail(NERF_AMD_EINVAL, "pts mode needs viewdirs [R,3]");
-    if (!train_supported(m->prog)) return fail(NERF_AMD_EUNSUPPORTED, "training kernels cover the D=8, W=256, skips=[4], multires 10/4 view-branch model");
+    if (!train_supported(m->prog)) return fail(NERF_AMD_EUNSUPPORTED, "training kernels cover the D=8, W=256, skips=[4] view-branch model with multires 10/4 or 15/6");
     if (!m->packed) return fail(NERF_AMD_EINVAL, "model has no parameters yet");
     if (R == 0) return NERF_AMD_OK;
     const int64_t P = R * S;
@@ -297,7 +297,7 @@ int nerf_amd_field_forward_train(const nerf_amd_model *m, const float *pts, cons
     else { a.rays = rays; a.ray_stride = ray_ch; a.z_vals = z_vals; a.viewdirs = rays + 8; a.vd_stride = ray_ch; }
     a.P = P; a.S = S; a.out = raw; a.out_ch = 4;
     train_fill_args(m->prog, P, workspace, &a);
-    int rc = launch_mlp_bf16_s16_save(a, m->prog.n_frags16_used, (int)m->prog.tiles16.size(), static_cast<hipStream_t>(stream));
+    int rc = launch_mlp_bf16_s16_save(a, m->prog.arch.multires, m->prog.arch.multires_views, m->prog.n_frags16_used, (int)m->prog.tiles16.size(), static_cast<hipStream_t>(stream));
     return rc ? fail(rc, "training forward launch failed") : NERF_AMD_OK;
 }
 
@@ -309,7 +309,7 @@ int nerf_amd_field_backward(const nerf_amd_model *m, const float *g_raw, const f
     const int64_t n_points = R * S;
     if (!m || R < 0 || S < 1 || !grad_weights || !grad_biases) return fail(NERF_AMD_EINVAL, "bad backward arguments");
     if ((!pts && (ray_ch != 11 || !rays || !z_vals)) || (pts && !viewdirs)) return fail(NERF_AMD_EINVAL, "backward needs the forward's inputs (pts + viewdirs, or rays [R,11] + z_vals)");
-    if (!train_supported(m->prog)) return fail(NERF_AMD_EUNSUPPORTED, "training kernels cover the D=8, W=256, skips=[4], multires 10/4 view-branch model");
+    if (!train_supported(m->prog)) return fail(NERF_AMD_EUNSUPPORTED, "training kernels cover the D=8, W=256, skips=[4] view-branch model with multires 10/4 or 15/6");
     if (n_tensors != (int)m->prog.tensors.size()) return fail(NERF_AMD_EINVAL, "wrong number of gradient tensors");
     if (n_points == 0) return NERF_AMD_OK;
     if (!g_raw || !workspace || workspace_bytes < train_workspace_bytes(m->prog, n_points))
@@ -322,7 +322,7 @@ int nerf_amd_field_backward(const nerf_amd_model *m, const float *g_raw, const f
     else { a.rays = rays; a.ray_stride = ray_ch; a.z_vals = z_vals; a.viewdirs = rays + 8; a.vd_stride = ray_ch; }
     a.g_pts = g_pts; a.g_rays = g_rays; a.g_vd = g_viewdirs;
     train_fill_args(m->prog, n_points, workspace, &a);
-    int rc = launch_mlp_bwd_s16(a, m->prog.n_frags_bwd_used, s);
+    int rc = launch_mlp_bwd_s16(a, m->prog.arch.multires, m->prog.arch.multires_views, m->prog.n_frags_bwd_used, s);
     if (rc) return fail(rc, "backward kernel launch failed");
     rc = train_param_grads(m->prog, n_points, workspace, grad_weights, grad_biases, s);
     return rc ? fail(rc, "weight-gradient GEMMs failed") : NERF_AMD_OK;

@@ -79,8 +79,9 @@ int launch_pack(const Program &p, const FragDesc *d_frags, const TileDesc *d_til
 void pack_bf16_host(const Program &p, int shape, const float *const *w, const float *const *b, uint16_t *stream, float *bias);
 int launch_mlp_bf16_s16(const MlpArgs &a, int multires, int multires_views, int use_viewdirs,
                         int n_frags_used, int n_tiles, hipStream_t s);
-int launch_mlp_bf16_s16_save(const MlpArgs &a, int n_frags_used, int n_tiles, hipStream_t s);   // (10,4) view-branch model
-int launch_mlp_bwd_s16(const MlpArgs &a, int n_frags_used, hipStream_t s);
+// training kernels: the view-branch model with multires 10/4 or 15/6
+int launch_mlp_bf16_s16_save(const MlpArgs &a, int multires, int multires_views, int n_frags_used, int n_tiles, hipStream_t s);
+int launch_mlp_bwd_s16(const MlpArgs &a, int multires, int multires_views, int n_frags_used, hipStream_t s);
 
 // backward.hip
 bool train_supported(const Program &p);

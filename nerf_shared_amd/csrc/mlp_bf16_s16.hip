@@ -378,8 +378,10 @@ int launch_mlp_bf16_s16(const MlpArgs &a, int multires, int multires_views, int 
     return NERF_AMD_EUNSUPPORTED;
 }
 
-int launch_mlp_bf16_s16_save(const MlpArgs &a, int n_frags_used, int n_tiles, hipStream_t s) {
-    return launch_wg16<10, 4, true, Cfg16, true>(a, n_frags_used, n_tiles, s);
+int launch_mlp_bf16_s16_save(const MlpArgs &a, int multires, int multires_views, int n_frags_used, int n_tiles, hipStream_t s) {
+    if (multires == 10 && multires_views == 4) return launch_wg16<10, 4, true, Cfg16, true>(a, n_frags_used, n_tiles, s);
+    if (multires == 15 && multires_views == 6) return launch_wg16<15, 6, true, Cfg16, true>(a, n_frags_used, n_tiles, s);
+    return NERF_AMD_EUNSUPPORTED;
 }
 
 }  // namespace na

@@ -1,5 +1,5 @@
 // mlp_bwd_s16.hip -- backward of the fused 8x256 NeRF MLP with respect to every
-// layer's pre-activation (the "dX chain"), for the view-branch (10,4) model.
+// layer's pre-activation (the "dX chain"), for the view-branch models (multires 10/4 and 15/6).
 //
 // What torch.autograd computes for NeRF.MLP (/root/reference/nerf_shared/nerf.py:110-134)
 // given dL/draw: walking the layers in reverse,
@@ -177,35 +177,40 @@ __device__ __forceinline__ void tenc(C &c, const bf16x8 *x1, float (&g)[2][8 * N
     });
 }
 
+// Fragment offsets of the backward stream (program.cpp frags_bwd) for encodings of KE / KD k-steps.
+template <int KE, int KD>
 struct LayoutB {
-    static constexpr int F_HV = 0;                 // 4 pairs x 1 k-step
-    static constexpr int F_FEAT = F_HV + 8;        // 8 pairs x 4 k-steps
-    static constexpr int F_DIRS = F_FEAT + 64;     // view-direction encoding slots: 1 pair x 4 k-steps
-    static constexpr int F_H8 = F_DIRS + 8;        // 8 pairs x (8 + 1) k-steps
-    static constexpr int F_L7 = F_H8 + 144;        // pts_linears.7, .6, .5: 8 pairs x 8 k-steps each
-    static constexpr int F_E5 = F_L7 + 3 * 128;    // xyz encoding slots through pts_linears.5: 2 pairs x 8 k-steps
-    static constexpr int F_L4 = F_E5 + 32;         // pts_linears.4 .. .1
-    static constexpr int F_E0 = F_L4 + 4 * 128;    // xyz encoding slots through pts_linears.0
-    static constexpr int F_END = F_E0 + 32;
+    static constexpr int F_HV = 0;                       // 4 pairs x 1 k-step
+    static constexpr int F_FEAT = F_HV + 8;              // 8 pairs x 4 k-steps
+    static constexpr int F_DIRS = F_FEAT + 64;           // view-direction encoding slots: KD pairs x 4 k-steps
+    static constexpr int F_H8 = F_DIRS + 8 * KD;         // 8 pairs x (8 + 1) k-steps
+    static constexpr int F_L7 = F_H8 + 144;              // pts_linears.7, .6, .5: 8 pairs x 8 k-steps each
+    static constexpr int F_E5 = F_L7 + 3 * 128;          // xyz encoding slots through pts_linears.5: KE pairs x 8 k-steps
+    static constexpr int F_L4 = F_E5 + 16 * KE;          // pts_linears.4 .. .1
+    static constexpr int F_E0 = F_L4 + 4 * 128;          // xyz encoding slots through pts_linears.0
+    static constexpr int F_END = F_E0 + 16 * KE;
 };
 
 // Row stores issued before fragment n (pipeline.h LEDGER): two per finished tile pair of a tlayer
 // (the encoding products store nothing).
+template <int KE, int KD>
 struct BwdLedger {
+    using L = LayoutB<KE, KD>;
     static constexpr int pairs_done(int n, int f0, int frags_per_pair, int n_pairs) {
         const int d = n <= f0 ? 0 : (n - f0) / frags_per_pair;
         return d > n_pairs ? n_pairs : d;
     }
     static constexpr int stores_before(int n) {
-        return 2 * (pairs_done(n, LayoutB::F_HV, 2, 4) + pairs_done(n, LayoutB::F_FEAT, 8, 8) +
-                    pairs_done(n, LayoutB::F_H8, 18, 8) + pairs_done(n, LayoutB::F_L7, 16, 24) +
-                    pairs_done(n, LayoutB::F_L4, 16, 32));
+        return 2 * (pairs_done(n, L::F_HV, 2, 4) + pairs_done(n, L::F_FEAT, 8, 8) + pairs_done(n, L::F_H8, 18, 8) +
+                    pairs_done(n, L::F_L7, 16, 24) + pairs_done(n, L::F_L4, 16, 32));
     }
 };
 
-template <class C>
+template <int LX, int LD, class C>
 __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bwd_s16_kernel(MlpArgs a) {
     constexpr int WG_POINTS = C::WAVES * 32;
+    constexpr int KE = gen16_ksteps(LX), KD = gen16_ksteps(LD);
+    using LayoutB = LayoutB<KE, KD>;
     constexpr int NF = LayoutB::F_END, NB = (NF + C::BF - 1) / C::BF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -275,9 +280,9 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bwd_s16_kernel(MlpArgs a
     // g_feat = W_views[:, :256]^T g_hv          (feature_linear has no activation)
     tlayer<LayoutB::F_FEAT, 8, 4, 0, false, 256, NB, NF>(c, B, B, A, none, a.g_feat, pidx, q);
     {   // view-direction encoding: g_dirs = W_views[:, 256:]^T g_hv, then through the encoding
-        float g[2][8];
-        tenc<LayoutB::F_DIRS, 1, 4, NB, NF>(c, B, g);
-        static_for<2>([&](auto cc_) { constexpr int cc = cc_; encode16_bwd<4, 1>(dv[cc][0], dv[cc][1], dv[cc][2], hh, bb, g[cc], gd[cc]); });
+        float g[2][8 * KD];
+        tenc<LayoutB::F_DIRS, KD, 4, NB, NF>(c, B, g);
+        static_for<2>([&](auto cc_) { constexpr int cc = cc_; encode16_bwd<LD, KD>(dv[cc][0], dv[cc][1], dv[cc][2], hh, bb, g[cc], gd[cc]); });
     }
     // g_h8 = relu'(h8) * (W_feature^T g_feat + W_alpha^T g_sigma)
     m_next = load_bits<8>(a.sv_bits + 6 * BS, pidx, q);
@@ -290,9 +295,9 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bwd_s16_kernel(MlpArgs a
     m_cur = m_next; m_next = load_bits<8>(a.sv_bits + 3 * BS, pidx, q);
     tlayer<LayoutB::F_L7 + 2 * 128, 8, 8, 0, true, 256, NB, NF>(c, B, B, A, m_cur, a.g_h + 4 * HS, pidx, q);
     {   // xyz encoding through the skip layer's [input_pts] columns (its pre-activation gradient is still in B)
-        float g[2][16];
-        tenc<LayoutB::F_E5, 2, 8, NB, NF>(c, B, g);
-        static_for<2>([&](auto cc_) { constexpr int cc = cc_; encode16_bwd<10, 2>(xp[cc][0], xp[cc][1], xp[cc][2], hh, bb, g[cc], gx[cc]); });
+        float g[2][8 * KE];
+        tenc<LayoutB::F_E5, KE, 8, NB, NF>(c, B, g);
+        static_for<2>([&](auto cc_) { constexpr int cc = cc_; encode16_bwd<LX, KE>(xp[cc][0], xp[cc][1], xp[cc][2], hh, bb, g[cc], gx[cc]); });
     }
     m_cur = m_next; m_next = load_bits<8>(a.sv_bits + 2 * BS, pidx, q);
     tlayer<LayoutB::F_L4 + 0 * 128, 8, 8, 0, true, 256, NB, NF>(c, A, A, B, m_cur, a.g_h + 3 * HS, pidx, q);
@@ -303,9 +308,9 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bwd_s16_kernel(MlpArgs a
     m_cur = m_next;
     tlayer<LayoutB::F_L4 + 3 * 128, 8, 8, 0, true, 256, NB, NF>(c, B, B, A, m_cur, a.g_h + 0 * HS, pidx, q);
     {   // xyz encoding through pts_linears.0
-        float g[2][16];
-        tenc<LayoutB::F_E0, 2, 8, NB, NF>(c, A, g);
-        static_for<2>([&](auto cc_) { constexpr int cc = cc_; encode16_bwd<10, 2>(xp[cc][0], xp[cc][1], xp[cc][2], hh, bb, g[cc], gx[cc]); });
+        float g[2][8 * KE];
+        tenc<LayoutB::F_E0, KE, 8, NB, NF>(c, A, g);
+        static_for<2>([&](auto cc_) { constexpr int cc = cc_; encode16_bwd<LX, KE>(xp[cc][0], xp[cc][1], xp[cc][2], hh, bb, g[cc], gx[cc]); });
     }
     // ---- point / ray gradients: sum the four lane quarters of each point, then one lane per point writes
     static_for<2>([&](auto cc_) {
@@ -332,22 +337,30 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bwd_s16_kernel(MlpArgs a
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // no LDS-DMA may outlive the workgroup
 }
 
-int launch_mlp_bwd_s16(const MlpArgs &a, int n_frags_used, hipStream_t s) {
-    using C = Ctx<8, 16, 4, 8, 2, 0, 1, 0, BwdLedger>;
-    if (n_frags_used != LayoutB::F_END) return NERF_AMD_EINVAL;
+template <int LX, int LD>
+static int launch_bwd(const MlpArgs &a, int n_frags_used, hipStream_t s) {
+    constexpr int KE = gen16_ksteps(LX), KD = gen16_ksteps(LD);
+    using C = Ctx<8, 16, 4, 8, 2, 0, 1, 0, BwdLedger<KE, KD>>;
+    if (n_frags_used != LayoutB<KE, KD>::F_END) return NERF_AMD_EINVAL;
     if (a.P <= 0) return NERF_AMD_OK;
     if (a.P >= (int64_t)1 << 31) return NERF_AMD_EINVAL;
     const size_t lds = C::RING_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_bwd_s16_kernel<C>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_bwd_s16_kernel<LX, LD, C>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return NERF_AMD_EHIP;
         attr_set = true;
     }
     const int64_t groups = (a.P + 255) / 256;
-    hipLaunchKernelGGL((mlp_bwd_s16_kernel<C>), dim3((unsigned)groups), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((mlp_bwd_s16_kernel<LX, LD, C>), dim3((unsigned)groups), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
+}
+
+int launch_mlp_bwd_s16(const MlpArgs &a, int multires, int multires_views, int n_frags_used, hipStream_t s) {
+    if (multires == 10 && multires_views == 4) return launch_bwd<10, 4>(a, n_frags_used, s);
+    if (multires == 15 && multires_views == 6) return launch_bwd<15, 6>(a, n_frags_used, s);
+    return NERF_AMD_EUNSUPPORTED;
 }
 
 }  // namespace na

@@ -7,7 +7,7 @@ Signatures, attribute names and state_dict keys follow the reference
 with ``load_state_dict`` unchanged.
 
 Inference runs the forward-only kernels.  With gradients enabled, the standard model
-(D=8, W=256, skips=[4], viewdirs, multires 10/4, bf16) runs the training kernels and
+(D=8, W=256, skips=[4], viewdirs, multires 10/4 or 15/6, bf16) runs the training kernels and
 loss.backward() reaches its parameters, the points / view directions and the rays
 (SURVEY.md section 8f rank 1).
 """

@@ -201,11 +201,13 @@ def test_backward_kernel_vmcnt_ledger_matches_its_isa(tmp_path):
     asm = str(tmp_path / "bwd.s")
     subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", src, "-o", asm],
                    check=True, capture_output=True, timeout=600)
-    stats = check_vmcnt.check(asm, "mlp_bwd_s16_kernel", verbose=False)
-    assert stats["kernels"] == 1 and stats["ok"]
-    assert stats["syncs"] == 74 and stats["dma_pieces"] == 148
-    # the checker must be able to fail: claim two more stores than the ISA has at every sync
-    assert not check_vmcnt.check(asm, "mlp_bwd_s16_kernel", verbose=False, slack=-4)["ok"]
+    # one instantiation per supported encoding pair; fragments = LayoutB<KE, KD>::F_END, 16 per ring block
+    for tag, frags in (("mlp_bwd_s16_kernelILi10ELi4E", 1184), ("mlp_bwd_s16_kernelILi15ELi6E", 1224)):
+        stats = check_vmcnt.check(asm, tag, verbose=False)
+        assert stats["kernels"] == 1 and stats["ok"], tag
+        assert stats["syncs"] == -(-frags // 16) and stats["dma_pieces"] == 2 * -(-frags // 16), (tag, stats)
+        # the checker must be able to fail: claim more stores than the ISA has at every sync
+        assert not check_vmcnt.check(asm, tag, verbose=False, slack=-4)["ok"]
 
 
 def test_png_codec_roundtrip_and_async_writer(tmp_path):

@@ -34,9 +34,9 @@ def check(path, want="", verbose=True, slack=0):
             ins = line.strip().split(" ")[0] if line.strip() else ""
             if ins.startswith("global_load_lds"):
                 queue.append(("dma", n_dma // pieces)); n_dma += 1
-            elif ins.startswith("global_store") or ins.startswith("global_atomic"):
+            elif ins.startswith(("global_store", "global_atomic", "scratch_store", "buffer_store", "flat_store")):
                 queue.append(("st",))
-            elif ins.startswith("global_load"):
+            elif ins.startswith(("global_load", "scratch_load", "buffer_load", "flat_load")):
                 queue.append(("ld",))
             elif ins == "s_waitcnt":
                 m = re.search(r"vmcnt\((\d+)\)", line)

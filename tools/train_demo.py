@@ -54,7 +54,7 @@ def write_blender_scene(root, H, W, poses, images, i_train, i_test):
             json.dump(meta, f)
 
 
-def run(steps=600, res=64, views=12, n_rand=1024, seed=0, verbose=True, scene_dir=None):
+def run(steps=600, res=64, views=12, n_rand=1024, seed=0, verbose=True, scene_dir=None, multires=10, multires_views=4):
     """scene_dir: write the scene to disk in the Blender format first and train from what
     utils.load_datasets reads back (8-bit frames) instead of from the in-memory float images."""
     torch.manual_seed(seed)
@@ -77,8 +77,8 @@ def run(steps=600, res=64, views=12, n_rand=1024, seed=0, verbose=True, scene_di
         i_train, i_test = list(i_train), int(i_test_arr[0])
         near, far = bds["near"], bds["far"]
     args = SimpleNamespace(N_rand=n_rand, no_batching=False, lrate=5e-4, lrate_decay=250, netdepth=8, netwidth=256,
-                           netdepth_fine=8, netwidth_fine=256, N_importance=128, use_viewdirs=True, multires=10,
-                           multires_views=4, i_embed=0)
+                           netdepth_fine=8, netwidth_fine=256, N_importance=128, use_viewdirs=True, multires=multires,
+                           multires_views=multires_views, i_embed=0)
     coarse, fine = utils.create_nerf_models(args, dev)
     renderer = render_utils.Renderer(perturb=1.0, N_importance=128, N_samples=64, use_viewdirs=True, white_bkgd=True,
                                      raw_noise_std=0.0, near=near, far=far)
@@ -119,5 +119,7 @@ if __name__ == "__main__":
     ap.add_argument("--res", type=int, default=64)
     ap.add_argument("--views", type=int, default=12)
     ap.add_argument("--scene-dir", default=None, help="write the scene in the Blender format here and train from disk")
+    ap.add_argument("--multires", type=int, default=10)
+    ap.add_argument("--multires-views", type=int, default=4)
     a = ap.parse_args()
-    print(json.dumps(run(a.steps, a.res, a.views, scene_dir=a.scene_dir)[0]))
+    print(json.dumps(run(a.steps, a.res, a.views, scene_dir=a.scene_dir, multires=a.multires, multires_views=a.multires_views)[0]))
