@@ -448,3 +448,34 @@ def test_training_ray_bank_and_batches(dev):
         assert (rays[1].cpu() - torch.stack([d[y, x] for _, y, x in c])).abs().max() < 1e-6
     with pytest.raises(ValueError):          # 12 distinct pixels out of a 2 x 4 crop: np.random.choice refuses, so do we
         utils.sample_random_ray_batch(args, imgs_t, poses_t, bank, 12, False, None, i_train, hwf, K, 0, 0)
+
+
+def test_trained_scene_psnr_within_a_tenth_of_a_db_of_the_oracle(dev, sphere_run):
+    """BASELINE.json's quality clause on *trained* weights: the held-out view of the trained sphere scene
+    rendered by the HIP path (bf16 and fp32 modes) and by the fp32 CPU oracle from the same state_dicts;
+    PSNR against the ground-truth frame must agree within 0.1 dB (and the images themselves closely)."""
+    from nerf_shared_amd import utils
+    out, (coarse, fine, _, _, renderer, (H, W, K), poses_t, images, i_test) = sphere_run
+    c2w = poses_t[i_test, :3, :4]
+    gt = images[i_test].cpu()
+    cfg = O.RenderCfg(perturb=0.0, N_importance=128, N_samples=64, use_viewdirs=True, white_bkgd=True,
+                      raw_noise_std=0.0, ndc=False, lindisp=False, near=float(renderer.near), far=float(renderer.far))
+    sd = [O.state_dict_to_torch({k: v.detach().cpu() for k, v in m.state_dict().items()}) for m in (coarse, fine)]
+    ref = O.render(cfg, H, W, K, (sd[0], O.Arch(**VD)), (sd[1], O.Arch(**VD)), chunk=4096, c2w=c2w.cpu(), retraw=False)[0]
+    psnr = lambda a: float(utils.mse2psnr(utils.img2mse(a, gt)))          # noqa: E731
+    p_ref = psnr(ref)
+    was = renderer.perturb
+    renderer.perturb = 0.0
+    try:
+        with torch.no_grad():
+            for prec in ("bf16", "fp32"):
+                coarse.precision = fine.precision = prec
+                rgb = renderer.render(H, W, K, coarse, fine, chunk=4096, c2w=c2w, retraw=False)[0].cpu()
+                p = psnr(rgb)
+                between = float(utils.mse2psnr(utils.img2mse(rgb, ref)))
+                print("%s: PSNR vs GT %.3f dB (oracle %.3f dB), vs oracle image %.1f dB" % (prec, p, p_ref, between))
+                assert abs(p - p_ref) <= 0.1, (prec, p, p_ref)
+                assert between > (35.0 if prec == "bf16" else 60.0), (prec, between)
+    finally:
+        coarse.precision = fine.precision = "bf16"
+        renderer.perturb = was
