@@ -364,6 +364,10 @@ int launch_mlp_bf16_s16(const MlpArgs &a, int multires, int multires_views, int 
             case 23: return launch_wg16<10, 4, true, Ctx<8, 16, 6, 8, 2>>(a, n_frags_used, n_tiles, s);            // 96-KiB ring
             case 24: return launch_wg16<10, 4, true, Ctx<8, 32, 4, 16, 4>>(a, n_frags_used, n_tiles, s);           // 32-fragment blocks
             case 25: return launch_wg16<10, 4, true, Ctx<8, 16, 3, 0>>(a, n_frags_used, n_tiles, s);               // block-boundary sync
+            // timing-only ablations (WRONG results): what the syncs / the LDS fragment reads / the encoding cost
+            case 26: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 2, 1>>(a, n_frags_used, n_tiles, s);         // no syncs, no DMA
+            case 27: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 2, 2>>(a, n_frags_used, n_tiles, s);         // no LDS fragment reads
+            case 28: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 2, 3>>(a, n_frags_used, n_tiles, s);         // neither
             default: break;
         }
     }

@@ -41,7 +41,7 @@ def main():
     for sharpen in args.sharpen:
         m = nerf.NeRF(**ARCH)
         m.load_state_dict(synth.torch_state_dict(1, sharpen, **{**ARCH, "skips": (4,)}))
-        m = m.to(dev)
+        m = m.to(dev).requires_grad_(False)          # inference kernels (with gradients on, NeRF.forward saves activations)
         m.precision = args.precision
         outs, times = {}, {v: [] for v in variants}
         for v in variants:                        # warm-up + reference outputs
