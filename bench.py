@@ -226,6 +226,9 @@ def main():
                          "frac": achieved / peak, "traffic": traffic[0] if traffic else None,
                          "traffic_unit": "bytes per launch (HBM, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)",
                          "traffic_source": ("profiles/" + traffic[1]) if traffic else None,
+                         "traffic_note": "measured traffic = algorithmic bytes + one L2 fill of the 1.2 MB bf16 weight stream per XCD "
+                                         "(8 x 1.2 MB; FETCH_SIZE counts L2 misses, including those the MALL serves); "
+                                         "the kernel is MFMA-bound, 21.6 MB per 0.43 ms launch is 50 GB/s",
                          "algorithmic_bytes_per_launch": CHUNK * 44 + (CHUNK * (2 * N_SAMPLES + N_IMPORTANCE) // 2) * 20,
                          "kernel": "mlp_bf16_s16_kernel" if cls == 1 else "mlp_f32_kernel",
                          "launches": int(launches[cls]),

@@ -21,7 +21,7 @@ import torch
 
 from . import _lib, utils
 from ._lib import lib
-from .nerf import NeRF, get_default_precision
+from .nerf import NeRF
 
 DEBUG = False
 

@@ -20,7 +20,6 @@ the reference itself (tests/golden/make_golden.py imports /root/reference in
 the build container; fixtures are committed under tests/golden/*.npz) by
 tests/test_oracle_golden.py.
 """
-import math
 
 import numpy as np
 import torch

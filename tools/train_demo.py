@@ -18,7 +18,7 @@ os.environ.setdefault("NERF_AMD_QUIET", "1")
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from nerf_shared_amd import nerf, render_utils, synth, utils  # noqa: E402
+from nerf_shared_amd import render_utils, synth, utils  # noqa: E402
 
 
 def sphere_image(H, W, K, c2w, dev, radius=1.0):
