@@ -152,6 +152,22 @@ class _FieldTrainFn(torch.autograd.Function):
         return (None, g_pts, g_vd if (pts is not None and need_vd) else None, g_rays, None, None, None) + tuple(grads)
 
 
+# The packed device copy of a model's weights is refreshed when a parameter's (data_ptr, _version)
+# changes.  Optimizers that update through fused multi-tensor kernels (torch.optim.Adam(fused=True))
+# do not bump `_version`, so every optimizer step also marks all live models stale.  Writes through
+# `param.data` are invisible to both: call `model.weights_changed()` after them.
+_LIVE_MODELS = weakref.WeakSet()
+
+
+def _after_optimizer_step(optimizer, args, kwargs):
+    for m in list(_LIVE_MODELS):
+        m._packed_key = None
+
+
+from torch.optim import optimizer as _torch_optimizer  # noqa: E402
+_torch_optimizer.register_optimizer_step_post_hook(_after_optimizer_step)
+
+
 class NeRF(nn.Module):
     """The reference's field model (nerf.py:61-143), same constructor, same
     parameters; ``forward`` runs on the MI355X kernels."""
@@ -188,6 +204,22 @@ class NeRF(nn.Module):
         self._handle_device = None
         self._packed_key = None
         self._finalizer = None
+        _LIVE_MODELS.add(self)
+
+    def __getstate__(self):
+        # copies / pickles never share the library handle: the copy creates its own on first use
+        state = self.__dict__.copy()
+        state.update(_handle=None, _handle_device=None, _packed_key=None, _finalizer=None)
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        _LIVE_MODELS.add(self)
+
+    def weights_changed(self):
+        """Force a re-pack of the parameters on the next call (needed only after writing through
+        `param.data` or other paths that bypass autograd's version counters)."""
+        self._packed_key = None
 
     # -- device-side packed copy of the parameters --------------------------------
     def _linears(self):

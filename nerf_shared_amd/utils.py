@@ -207,11 +207,14 @@ def get_renderer(args, bds_dict):
 
 # ---------------------------------------------------------------- optimizer + checkpoints (utils.py:163-214, 444-456)
 def get_optimizer(coarse_model, fine_model, args):
-    """Adam over both models' parameters, lr = args.lrate (utils.py:163-172)."""
+    """Adam over both models' parameters, lr = args.lrate (utils.py:163-172).  With the parameters on
+    the GPU the single-kernel ("fused") implementation of torch.optim.Adam is used: the step is host-bound
+    otherwise (48 small tensors; 2.5 vs 3.3 ms per 1024-ray training step)."""
     params = list(coarse_model.parameters())
     if fine_model is not None:
         params += list(fine_model.parameters())
-    return torch.optim.Adam(params=params, lr=args.lrate, betas=(0.9, 0.999))
+    fused = len(params) > 0 and all(p.is_cuda for p in params)
+    return torch.optim.Adam(params=params, lr=args.lrate, betas=(0.9, 0.999), fused=fused)
 
 
 def save_checkpoints(args, coarse_model, fine_model, optimizer, global_step, i):

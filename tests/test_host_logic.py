@@ -248,3 +248,28 @@ def test_png_codec_roundtrip_and_async_writer(tmp_path):
     w.submit(str(tmp_path / "missing_dir" / "x.png"), frames[0])
     with pytest.raises(OSError):
         w.close()
+
+
+def test_packed_weights_go_stale_after_optimizer_steps_and_copies_get_their_own_handle():
+    """The device-side packed weights are keyed on (data_ptr, _version); fused optimizers do not bump
+    _version, so any optimizer step must invalidate the key.  Copies must not share a library handle."""
+    import copy
+    m = nerf.NeRF(D=8, W=256, output_ch=5, skips=[4], use_viewdirs=True)
+    other = nerf.NeRF(D=8, W=256, output_ch=5, skips=[4], use_viewdirs=True)
+    m._packed_key, other._packed_key = "packed", "packed"
+    lin = torch.nn.Linear(2, 2)                       # an unrelated optimizer: still invalidates (cheap, always safe)
+    opt = torch.optim.SGD(lin.parameters(), lr=0.1)
+    lin.weight.grad, lin.bias.grad = torch.zeros_like(lin.weight), torch.zeros_like(lin.bias)
+    opt.step()
+    assert m._packed_key is None and other._packed_key is None
+    m._packed_key = "packed"
+    m.weights_changed()
+    assert m._packed_key is None
+    m._handle, m._packed_key = "library handle", "packed"
+    c = copy.deepcopy(m)
+    assert c._handle is None and c._packed_key is None and m._handle == "library handle"
+    c._packed_key = "packed"
+    opt.step()
+    assert c._packed_key is None                      # the copy is tracked too
+    m._handle = None
+    assert torch.equal(c.pts_linears[3].weight, m.pts_linears[3].weight)

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--rays", type=int, default=1024)      # N_rand of configs/lego.txt:15
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--adam", choices=["foreach", "fused"], default="fused", help="torch.optim.Adam implementation")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     models = []
@@ -34,7 +35,8 @@ def main():
         models.append(m.to(dev))
     r = render_utils.Renderer(perturb=1.0, N_importance=128, N_samples=64, use_viewdirs=True, white_bkgd=True,
                               raw_noise_std=0.0, near=2.0, far=6.0)
-    opt = torch.optim.Adam(list(models[0].parameters()) + list(models[1].parameters()), lr=5e-4)
+    opt = torch.optim.Adam(list(models[0].parameters()) + list(models[1].parameters()), lr=5e-4, betas=(0.9, 0.999),
+                           fused=args.adam == "fused")
     rng = np.random.default_rng(0)
     K = synth.lego_intrinsics(400, 400)
     idx = rng.choice(160000, size=args.rays, replace=False)
@@ -60,7 +62,7 @@ def main():
     dt = (time.perf_counter() - t0) / args.steps
     pts = args.rays * 256
     print(json.dumps({"rays_per_step": args.rays, "ms_per_step": dt * 1e3, "steps_per_s": 1 / dt,
-                      "rays_per_s": args.rays / dt, "loss": float(loss),
+                      "rays_per_s": args.rays / dt, "loss": float(loss), "adam": args.adam,
                       "model_tflops": pts * 1186816 * 3 / dt / 1e12}))
 
 
