@@ -367,11 +367,57 @@ int launch_sample_pdf(const float *bins, const float *weights, const float *u, c
 // ---------------------------------------------------------------------------
 // The resampling step of render_rays (render_utils.py:140-148, :168) fused:
 //   z_mid -> sample_pdf(z_mid, weights[1:-1]) -> z_std -> sort(cat[z, z_samples])
-// Per-ray LDS: cdf[Nc-1] + bins[Nc-1] + sort buffer[pow2 >= Nc+Ni].
+// The concatenation is two runs that are almost always sorted already (coarse depths are monotone; the
+// samples are monotone in u, and u is sorted in the deterministic mode), so torch.sort's result is
+// produced as a merge: each run is checked, sorted in place only if it has to be (bitonic network
+// private to the wave), and every element finds its output position with one binary search in the
+// other run.  Comparisons use the floats' bits mapped to an unsigned total order (NaN last, as
+// torch.sort places it).
+// Per-ray LDS: cdf[Nc-1] + bins[Nc-1] + run A[pow2 >= Nc] + run B[pow2 >= Ni].
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned order_key(float v) {
+    const unsigned b = __builtin_bit_cast(unsigned, v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+// true when x[0..n) is non-decreasing (wave-uniform result)
+__device__ __forceinline__ bool wave_is_sorted(const float *x, int n, int lane) {
+    bool ok = true;
+    for (int i = lane; i + 1 < n; i += 64) ok = ok && order_key(x[i]) <= order_key(x[i + 1]);
+    return __all(ok);
+}
+
+// ascending bitonic sort of x[0..npad), npad a power of two (padding = +inf), private to this wave.
+// Every lane owns one compare-exchange per pass: pair t <-> elements (i, i + j), i = 2j*(t / j) + t % j.
+__device__ __forceinline__ void wave_bitonic_sort(float *x, int npad, int lane) {
+    for (int k = 2; k <= npad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = lane; t < (npad >> 1); t += 64) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const float a = x[i], b = x[i + j];
+                const bool up = (i & k) == 0;
+                if ((order_key(a) > order_key(b)) == up) { x[i] = b; x[i + j] = a; }
+            }
+            wave_lds_sync();
+        }
+    }
+}
+
+// number of elements of the sorted run x[0..n) whose key is < k (STRICT) or <= k
+template <bool STRICT>
+__device__ __forceinline__ int count_below(const float *x, int n, unsigned k) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const unsigned km = order_key(x[mid]);
+        if (STRICT ? km < k : km <= k) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
 __global__ __launch_bounds__(64 * RAYS_PER_WG) void resample_kernel(const float *z_coarse, const float *weights,
                                                                     const float *u, const float *t_lin, int64_t R,
-                                                                    int Nc, int Ni, int npad, float *z_fine,
+                                                                    int Nc, int Ni, int pad_c, int pad_s, float *z_fine,
                                                                     float *z_std) {
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -379,58 +425,57 @@ __global__ __launch_bounds__(64 * RAYS_PER_WG) void resample_kernel(const float 
     const bool live = r < R;
     if (!live) r = R - 1;
     const int nb = Nc - 1;
-    float *cdf = lds + wv * (2 * nb + npad), *bl = cdf + nb, *sb = bl + nb;
+    float *cdf = lds + wv * (2 * nb + pad_c + pad_s), *bl = cdf + nb, *za = bl + nb, *zs = za + pad_c;
     const float *zr = z_coarse + r * Nc;
     const float *wr = weights + r * Nc + 1;                       // weights[..., 1:-1]
     build_cdf([&](int i) { return wr[i]; }, nb, cdf, lane);
     for (int i = lane; i < nb; i += 64) bl[i] = 0.5f * (zr[i + 1] + zr[i]);
-    for (int i = lane; i < Nc; i += 64) sb[i] = zr[i];
-    for (int i = Nc + Ni + lane; i < npad; i += 64) sb[i] = INFINITY;
+    for (int i = lane; i < pad_c; i += 64) za[i] = i < Nc ? zr[i] : INFINITY;
+    for (int i = Ni + lane; i < pad_s; i += 64) zs[i] = INFINITY;
     wave_lds_sync();
     double sum = 0.0;
     for (int i = lane; i < Ni; i += 64) {
         const float uu = u ? u[r * Ni + i] : t_lin[i];
         const float v = invert_cdf(cdf, bl, nb, uu);
-        sb[Nc + i] = v;
+        zs[i] = v;
         sum += (double)v;
     }
     // std(z_samples, unbiased=False): two-pass in fp64
     const double mean = wave_sum(sum) / (double)Ni;
     double ss = 0.0;
     for (int i = lane; i < Ni; i += 64) {
-        const double dv = (double)sb[Nc + i] - mean;
+        const double dv = (double)zs[i] - mean;
         ss += dv * dv;
     }
     ss = wave_sum(ss);
     if (live && lane == 0 && z_std) z_std[r] = (float)sqrt(ss / (double)Ni);
     wave_lds_sync();
-    // bitonic sort of sb[0..npad), ascending, private to this wave.  Every lane owns one
-    // compare-exchange per pass: pair t <-> elements (i, i + j), i = 2j*(t / j) + t % j.
-    for (int k = 2; k <= npad; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = lane; t < (npad >> 1); t += 64) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const float a = sb[i], b = sb[i + j];
-                const bool up = (i & k) == 0;
-                if ((a > b) == up) { sb[i] = b; sb[i + j] = a; }
-            }
-            wave_lds_sync();
-        }
-    }
+    if (!wave_is_sorted(zs, Ni, lane)) wave_bitonic_sort(zs, pad_s, lane);      // random u (perturb > 0)
+    if (!wave_is_sorted(za, Nc, lane)) wave_bitonic_sort(za, pad_c, lane);      // an ulp of jitter rounding, if ever
     if (!live) return;
-    for (int i = lane; i < Nc + Ni; i += 64) z_fine[r * (Nc + Ni) + i] = sb[i];
+    // merge: ties keep the coarse value first (any consistent rule yields the same sorted values)
+    float *out = z_fine + r * (Nc + Ni);
+    for (int i = lane; i < Nc; i += 64) {
+        const float v = za[i];
+        out[i + count_below<true>(zs, Ni, order_key(v))] = v;
+    }
+    for (int j = lane; j < Ni; j += 64) {
+        const float v = zs[j];
+        out[j + count_below<false>(za, Nc, order_key(v))] = v;
+    }
 }
 
 int launch_resample(const float *z_coarse, const float *weights, const float *u, const float *t_lin,
                     int64_t R, int Nc, int Ni, float *z_fine, float *z_std, hipStream_t s) {
     if (R <= 0) return NERF_AMD_OK;
     if (Nc < 3 || Ni < 1 || Nc + Ni > 4096) return NERF_AMD_EINVAL;
-    int npad = 2;
-    while (npad < Nc + Ni) npad <<= 1;
+    int pad_c = 2, pad_s = 2;
+    while (pad_c < Nc) pad_c <<= 1;
+    while (pad_s < Ni) pad_s <<= 1;
     const int64_t blocks = (R + RAYS_PER_WG - 1) / RAYS_PER_WG;
-    const size_t lds = (size_t)RAYS_PER_WG * (2 * (Nc - 1) + npad) * sizeof(float);
+    const size_t lds = (size_t)RAYS_PER_WG * (2 * (Nc - 1) + pad_c + pad_s) * sizeof(float);
     hipLaunchKernelGGL(resample_kernel, dim3((unsigned)blocks), dim3(64 * RAYS_PER_WG), lds, s, z_coarse, weights, u,
-                       t_lin, R, Nc, Ni, npad, z_fine, z_std);
+                       t_lin, R, Nc, Ni, pad_c, pad_s, z_fine, z_std);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
 

@@ -665,3 +665,39 @@ def test_to8b_matches_numpy_bit_for_bit(dev):
         assert got.dtype == torch.uint8 and got.shape == x.shape
         assert np.array_equal(got.cpu().numpy(), (255 * np.clip(x, 0, 1)).astype(np.uint8))
     assert amd_utils.to8b(torch.tensor([float("nan")], device=dev)).item() == 0
+
+
+def test_resample_stage_against_sample_pdf_and_torch_sort(dev):
+    """nerf_amd_resample = z_mid -> sample_pdf(weights[1:-1]) -> z_std -> sort(cat) (render_utils.py:140-148,
+    :168).  The kernel merges two runs instead of sorting the concatenation: check it against
+    utils.sample_pdf + torch.sort bit for bit when (a) both runs arrive sorted (deterministic u), (b) the
+    samples arrive unsorted (random u), (c) the coarse depths themselves are unsorted and full of ties."""
+    from nerf_shared_amd import _lib, utils as amd_utils
+    lib = _lib.lib
+    rng = np.random.default_rng(9)
+    R, Nc, Ni = 333, 64, 128
+    for case in ("sorted", "random_u", "unsorted_coarse_with_ties", "odd_sizes"):
+        nc, ni = (Nc, Ni) if case != "odd_sizes" else (37, 50)
+        z = np.sort(rng.uniform(2, 6, size=(R, nc)).astype(np.float32), -1)
+        if case == "unsorted_coarse_with_ties":
+            z = np.round(z * 4) / 4                                     # many equal depths
+            z = np.take_along_axis(z, rng.permuted(np.tile(np.arange(nc), (R, 1)), axis=1), -1).astype(np.float32)
+        w = rng.uniform(0, 1, size=(R, nc)).astype(np.float32)
+        w[5] = 0.0                                                      # all-zero row: uniform pdf
+        u = None if case == "sorted" else rng.uniform(0, 1, size=(R, ni)).astype(np.float32)
+        zt, wt = torch.from_numpy(z).to(dev), torch.from_numpy(w).to(dev)
+        ut = None if u is None else torch.from_numpy(u).to(dev)
+        t_lin = torch.linspace(0., 1., ni, device=dev)
+        z_fine = torch.empty(R, nc + ni, device=dev)
+        z_std = torch.empty(R, device=dev)
+        _lib.check(lib.nerf_amd_resample(zt.data_ptr(), wt.data_ptr(), _lib.ptr(ut), t_lin.data_ptr(), R, nc, ni,
+                                         z_fine.data_ptr(), z_std.data_ptr(), _lib.stream_of(dev)), "nerf_amd_resample")
+        # expected: the same library's sample_pdf (itself golden-tested) on the draws, then torch
+        z_mid = .5 * (zt[:, 1:] + zt[:, :-1])
+        samples = torch.empty(R, ni, device=dev)
+        zm, wm = z_mid.contiguous(), wt[:, 1:-1].contiguous()
+        _lib.check(lib.nerf_amd_sample_pdf(zm.data_ptr(), wm.data_ptr(), _lib.ptr(ut), t_lin.data_ptr(),
+                                           R, nc - 1, ni, samples.data_ptr(), _lib.stream_of(dev)), "nerf_amd_sample_pdf")
+        want = torch.sort(torch.cat([zt, samples], -1), -1)[0]
+        assert torch.equal(z_fine, want), case
+        close(z_std, torch.std(samples, -1, unbiased=False), atol=2e-6)
