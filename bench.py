@@ -126,6 +126,9 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     args = ap.parse_args()
     workload_name = select_workload(args.workload)
+    if os.environ.get("NERF_AMD_OVERLAP_CHUNKS") == "1":      # A/B knob: two-stream chunk pipeline of render_batch
+        from nerf_shared_amd import render_utils as _ru
+        _ru.Renderer.overlap_chunks = True
 
     import torch
     import torch.distributed as dist

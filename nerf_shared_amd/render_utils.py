@@ -323,7 +323,7 @@ class Renderer(torch.nn.Module):
                     print(f"! [Numerical Error] {k} contains nan or inf.")
         return ret
 
-    overlap_chunks = False    # opt-in: two-stream chunk pipeline of render_batch (+~2 % at 4096-ray chunks)
+    overlap_chunks = False    # opt-in: two-stream chunk pipeline of render_batch (+~3 % at 4096-ray chunks)
 
     def render_batch(self, coarse_model, fine_model, rays_flat, chunk=1024 * 32, retraw=False):
         """Render rays in chunks (render_utils.py:51-65).  Outputs of every chunk land
@@ -331,7 +331,7 @@ class Renderer(torch.nn.Module):
         without the copy).  With ``Renderer.overlap_chunks = True`` consecutive chunks
         alternate between two HIP streams (each with its own workspace) so the small
         per-ray kernels and launch/drain gaps of one chunk hide under the field kernel
-        of the other; results do not depend on it.  Off by default: the gain is ~2 % and
+        of the other; results do not depend on it.  Off by default: the gain is ~3 % and
         concurrent kernels blur per-kernel timings."""
         _lib.require_device(rays_flat, "rays_flat")
         rays = rays_flat.detach().contiguous().float()
