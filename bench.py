@@ -148,7 +148,7 @@ def main():
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend)
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     models = []
     for seed in (0, 10):
