@@ -448,11 +448,11 @@ int nerf_amd_render_rays(const nerf_amd_render_cfg *cfg, const nerf_amd_model *c
                               cfg->white_bkgd, io->rgb_map, io->disp_map, io->acc_map, w_c, nullptr, s);
         return rc ? fail(rc, "composite launch failed") : NERF_AMD_OK;
     }
-    rc = launch_composite(raw_c, och, z_c, rays_d, io->ray_ch, cfg->use_noise ? io->noise0 : nullptr, R, Nc,
-                          cfg->white_bkgd, io->rgb0, io->disp0, io->acc0, w_c, nullptr, s);
-    if (rc) return fail(rc, "composite launch failed");
-    rc = launch_resample(z_c, w_c, io->u, io->t_lin_imp, R, Nc, Ni, z_f, io->z_std, s);
-    if (rc) return fail(rc, "resample launch failed (N_samples + N_importance must be <= 4096)");
+    // coarse raw2outputs + z_mid / sample_pdf / sort(cat) in one launch (the weights stay in LDS)
+    rc = launch_composite_resample(raw_c, och, z_c, rays_d, io->ray_ch, cfg->use_noise ? io->noise0 : nullptr, R, Nc, Ni,
+                                   cfg->white_bkgd, io->rgb0, io->disp0, io->acc0, nullptr, io->u, io->t_lin_imp, z_f,
+                                   io->z_std, s);
+    if (rc) return fail(rc, "composite/resample launch failed (N_samples + N_importance must be <= 4096)");
     a.z_vals = z_f; a.P = R * (int64_t)Nf; a.S = Nf; a.out = raw_f;
     if ((rc = run_field(fm, a, cfg->precision, s))) return rc;
     rc = launch_composite(raw_f, och, z_f, rays_d, io->ray_ch, cfg->use_noise ? io->noise1 : nullptr, R, Nf,

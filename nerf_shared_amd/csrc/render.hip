@@ -89,13 +89,12 @@ int launch_coarse_z(const float *rays, int ray_stride, const float *t_vals, cons
 // The transmittance product is carried in fp64 like ATen's CPU cumprod
 // (acc_type<float> = double) and rounded to fp32 per sample.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64 * RAYS_PER_WG) void composite_kernel(
-    const float *raw, int raw_ch, const float *z, const float *rays_d, int rays_d_stride, const float *noise,
-    int64_t R, int S, int white_bkgd, float *rgb_map, float *disp_map, float *acc_map, float *weights,
-    float *depth_map) {
-    const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * RAYS_PER_WG + (threadIdx.x >> 6);
-    if (r >= R) return;
+// raw2outputs for ray r by one wave; store_w(s, w) receives every sample's weight.
+template <class StoreW>
+__device__ __forceinline__ void composite_ray(const float *raw, int raw_ch, const float *z, const float *rays_d,
+                                              int rays_d_stride, const float *noise, int64_t r, int S, int white_bkgd,
+                                              float *rgb_map, float *disp_map, float *acc_map, float *depth_map, int lane,
+                                              StoreW store_w) {
     const float *d = rays_d + r * rays_d_stride;
     const float dnorm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
     const float *zr = z + r * S;
@@ -129,7 +128,7 @@ __global__ __launch_bounds__(64 * RAYS_PER_WG) void composite_kernel(
         carry = carry * __shfl(incl, 63);
         if (in) {
             w = alpha * T;
-            if (weights) weights[r * S + s] = w;
+            store_w(s, w);
         }
         sr += w * cr; sg += w * cg; sb += w * cb;
         sdepth += w * zc; sacc += w;
@@ -147,6 +146,17 @@ __global__ __launch_bounds__(64 * RAYS_PER_WG) void composite_kernel(
             disp_map[r] = 1.0f / m;
         }
     }
+}
+
+__global__ __launch_bounds__(64 * RAYS_PER_WG) void composite_kernel(
+    const float *raw, int raw_ch, const float *z, const float *rays_d, int rays_d_stride, const float *noise,
+    int64_t R, int S, int white_bkgd, float *rgb_map, float *disp_map, float *acc_map, float *weights,
+    float *depth_map) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * RAYS_PER_WG + (threadIdx.x >> 6);
+    if (r >= R) return;
+    composite_ray(raw, raw_ch, z, rays_d, rays_d_stride, noise, r, S, white_bkgd, rgb_map, disp_map, acc_map, depth_map, lane,
+                  [&](int s, float w) { if (weights) weights[r * S + s] = w; });
 }
 
 int launch_composite(const float *raw, int raw_ch, const float *z, const float *rays_d, int rays_d_stride,
@@ -353,6 +363,11 @@ __global__ __launch_bounds__(64 * RAYS_PER_WG) void sample_pdf_kernel(const floa
     }
 }
 
+int launch_composite_resample(const float *raw, int raw_ch, const float *z_coarse, const float *rays_d, int rays_d_stride,
+                              const float *noise, int64_t R, int Nc, int Ni, int white_bkgd, float *rgb0, float *disp0,
+                              float *acc0, float *weights, const float *u, const float *t_lin, float *z_fine, float *z_std,
+                              hipStream_t s);
+
 int launch_sample_pdf(const float *bins, const float *weights, const float *u, const float *t_lin,
                       int64_t R, int n_bins, int n_samples, float *samples, hipStream_t s) {
     if (R <= 0 || n_samples <= 0) return NERF_AMD_OK;
@@ -415,20 +430,16 @@ __device__ __forceinline__ int count_below(const float *x, int n, unsigned k) {
     return lo;
 }
 
-__global__ __launch_bounds__(64 * RAYS_PER_WG) void resample_kernel(const float *z_coarse, const float *weights,
-                                                                    const float *u, const float *t_lin, int64_t R,
-                                                                    int Nc, int Ni, int pad_c, int pad_s, float *z_fine,
-                                                                    float *z_std) {
-    extern __shared__ float lds[];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int64_t r = (int64_t)blockIdx.x * RAYS_PER_WG + wv;
-    const bool live = r < R;
-    if (!live) r = R - 1;
+// The resampling of ray r by one wave (scratch: cdf[nb] + bins[nb] + run A[pad_c] + run B[pad_s] floats of
+// LDS); load_w(i) returns weights[r][1 + i].  `live` is false for the padding waves of the last workgroup.
+template <class LoadW>
+__device__ __forceinline__ void resample_ray(const float *z_coarse, LoadW load_w, const float *u, const float *t_lin,
+                                             int64_t r, bool live, int Nc, int Ni, int pad_c, int pad_s, float *scratch,
+                                             float *z_fine, float *z_std, int lane) {
     const int nb = Nc - 1;
-    float *cdf = lds + wv * (2 * nb + pad_c + pad_s), *bl = cdf + nb, *za = bl + nb, *zs = za + pad_c;
+    float *cdf = scratch, *bl = cdf + nb, *za = bl + nb, *zs = za + pad_c;
     const float *zr = z_coarse + r * Nc;
-    const float *wr = weights + r * Nc + 1;                       // weights[..., 1:-1]
-    build_cdf([&](int i) { return wr[i]; }, nb, cdf, lane);
+    build_cdf(load_w, nb, cdf, lane);
     for (int i = lane; i < nb; i += 64) bl[i] = 0.5f * (zr[i + 1] + zr[i]);
     for (int i = lane; i < pad_c; i += 64) za[i] = i < Nc ? zr[i] : INFINITY;
     for (int i = Ni + lane; i < pad_s; i += 64) zs[i] = INFINITY;
@@ -463,6 +474,41 @@ __global__ __launch_bounds__(64 * RAYS_PER_WG) void resample_kernel(const float 
         const float v = zs[j];
         out[j + count_below<false>(za, Nc, order_key(v))] = v;
     }
+}
+
+__global__ __launch_bounds__(64 * RAYS_PER_WG) void resample_kernel(const float *z_coarse, const float *weights,
+                                                                    const float *u, const float *t_lin, int64_t R,
+                                                                    int Nc, int Ni, int pad_c, int pad_s, float *z_fine,
+                                                                    float *z_std) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int64_t r = (int64_t)blockIdx.x * RAYS_PER_WG + wv;
+    const bool live = r < R;
+    if (!live) r = R - 1;
+    const float *wr = weights + r * Nc + 1;                       // weights[..., 1:-1]
+    resample_ray(z_coarse, [&](int i) { return wr[i]; }, u, t_lin, r, live, Nc, Ni, pad_c, pad_s,
+                 lds + wv * (2 * (Nc - 1) + pad_c + pad_s), z_fine, z_std, lane);
+}
+
+// The coarse pass's raw2outputs and the resampling in one launch (render_rays between its two field
+// evaluations, render_utils.py:135-148): the weights go from the compositing to the inverse-CDF
+// sampling through LDS; one dependent launch less per chunk.
+__global__ __launch_bounds__(64 * RAYS_PER_WG) void composite_resample_kernel(
+    const float *raw, int raw_ch, const float *z_coarse, const float *rays_d, int rays_d_stride, const float *noise,
+    int64_t R, int Nc, int Ni, int pad_c, int pad_s, int white_bkgd, float *rgb0, float *disp0, float *acc0, float *weights,
+    const float *u, const float *t_lin, float *z_fine, float *z_std) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int64_t r = (int64_t)blockIdx.x * RAYS_PER_WG + wv;
+    const bool live = r < R;
+    if (!live) r = R - 1;
+    float *wl = lds + wv * (Nc + 2 * (Nc - 1) + pad_c + pad_s);
+    composite_ray(raw, raw_ch, z_coarse, rays_d, rays_d_stride, noise, r, Nc, white_bkgd, live ? rgb0 : nullptr,
+                  live ? disp0 : nullptr, live ? acc0 : nullptr, nullptr, lane,
+                  [&](int s, float w) { wl[s] = w; if (live && weights) weights[r * Nc + s] = w; });
+    wave_lds_sync();
+    resample_ray(z_coarse, [&](int i) { return wl[1 + i]; }, u, t_lin, r, live, Nc, Ni, pad_c, pad_s, wl + Nc, z_fine,
+                 z_std, lane);
 }
 
 int launch_resample(const float *z_coarse, const float *weights, const float *u, const float *t_lin,
@@ -640,6 +686,23 @@ int launch_make_rays(int H, int W, const double *K4, const float *c2w, const flo
     g.sx = (float)(-1.0 / ((double)W / (2.0 * K4[0])));
     g.sy = (float)(-1.0 / ((double)H / (2.0 * K4[0])));
     hipLaunchKernelGGL(make_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, pix0, n, rays_out);
+    return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
+}
+
+int launch_composite_resample(const float *raw, int raw_ch, const float *z_coarse, const float *rays_d, int rays_d_stride,
+                              const float *noise, int64_t R, int Nc, int Ni, int white_bkgd, float *rgb0, float *disp0,
+                              float *acc0, float *weights, const float *u, const float *t_lin, float *z_fine, float *z_std,
+                              hipStream_t s) {
+    if (R <= 0) return NERF_AMD_OK;
+    if (raw_ch < 4 || Nc < 3 || Ni < 1 || Nc + Ni > 4096) return NERF_AMD_EINVAL;
+    int pad_c = 2, pad_s = 2;
+    while (pad_c < Nc) pad_c <<= 1;
+    while (pad_s < Ni) pad_s <<= 1;
+    const int64_t blocks = (R + RAYS_PER_WG - 1) / RAYS_PER_WG;
+    const size_t lds = (size_t)RAYS_PER_WG * (Nc + 2 * (Nc - 1) + pad_c + pad_s) * sizeof(float);
+    hipLaunchKernelGGL(composite_resample_kernel, dim3((unsigned)blocks), dim3(64 * RAYS_PER_WG), lds, s, raw, raw_ch,
+                       z_coarse, rays_d, rays_d_stride, noise, R, Nc, Ni, pad_c, pad_s, white_bkgd, rgb0, disp0, acc0, weights,
+                       u, t_lin, z_fine, z_std);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
 
