@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NERF_AMD_ABI_VERSION 1
+#define NERF_AMD_ABI_VERSION 2
 
 #define NERF_AMD_OK            0
 #define NERF_AMD_EINVAL       -1   /* bad argument / unsupported shape        */
@@ -216,6 +216,9 @@ typedef struct nerf_amd_render_io {
     const float *noise1;       /* [R,N_samples+N_importance], fine pass                    */
     const float *u;            /* [R,N_importance] sample_pdf draws; NULL => det  (utils.py:83-86) */
     const float *t_lin_imp;    /* [N_importance] torch.linspace(0,1,N_importance), used when u == NULL */
+    const float *z_coarse;     /* optional [R,N_samples]: coarse depths already computed by nerf_amd_coarse_z (a caller
+                                  that renders many chunks makes them for all rays in one launch); NULL = computed here
+                                  from t_vals / t_rand */
     /* outputs (NULL = not wanted) */
     float *rgb_map, *disp_map, *acc_map;      /* [R,3] [R] [R]  from the last pass         */
     float *rgb0, *disp0, *acc0;               /* coarse-pass maps (N_importance > 0)       */

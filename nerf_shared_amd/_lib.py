@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnerf_amd.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 PREC_FP32, PREC_BF16 = 0, 1
 MAX_SKIPS = 8
 
@@ -42,7 +42,7 @@ class RenderCfg(Structure):
 class RenderIO(Structure):
     _fields_ = [("rays", c_void_p), ("ray_ch", c_int32), ("pad0", c_int32),
                 ("t_vals", c_void_p), ("t_rand", c_void_p), ("noise0", c_void_p), ("noise1", c_void_p),
-                ("u", c_void_p), ("t_lin_imp", c_void_p),
+                ("u", c_void_p), ("t_lin_imp", c_void_p), ("z_coarse", c_void_p),
                 ("rgb_map", c_void_p), ("disp_map", c_void_p), ("acc_map", c_void_p),
                 ("rgb0", c_void_p), ("disp0", c_void_p), ("acc0", c_void_p),
                 ("z_std", c_void_p), ("raw", c_void_p), ("weights", c_void_p), ("z_vals", c_void_p),

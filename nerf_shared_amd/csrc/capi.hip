@@ -400,7 +400,7 @@ int nerf_amd_render_rays(const nerf_amd_render_cfg *cfg, const nerf_amd_model *c
     if (Ni > 0 && Nc < 3) return fail(NERF_AMD_EINVAL, "hierarchical sampling needs N_samples >= 3");
     if (!io->rays || (io->ray_ch != 8 && io->ray_ch != 11)) return fail(NERF_AMD_EINVAL, "rays must be [R,8] or [R,11]");
     if (!io->t_vals) return fail(NERF_AMD_EINVAL, "t_vals missing");
-    if (cfg->perturb && !io->t_rand) return fail(NERF_AMD_EINVAL, "perturb set but t_rand missing");
+    if (cfg->perturb && !io->t_rand && !io->z_coarse) return fail(NERF_AMD_EINVAL, "perturb set but t_rand missing");
     if (cfg->use_noise && (!io->noise0 || (Ni > 0 && !io->noise1))) return fail(NERF_AMD_EINVAL, "use_noise set but noise missing");
     if (Ni > 0 && !io->u && !io->t_lin_imp) return fail(NERF_AMD_EINVAL, "need u or t_lin_imp for sample_pdf");
     const nerf_amd_model *fm = fine ? fine : coarse;
@@ -431,8 +431,17 @@ int nerf_amd_render_rays(const nerf_amd_render_cfg *cfg, const nerf_amd_model *c
         if (io->weights) w_c = io->weights;
     }
 
-    int rc = launch_coarse_z(io->rays, io->ray_ch, io->t_vals, cfg->perturb ? io->t_rand : nullptr, R, Nc,
+    int rc = 0;
+    if (io->z_coarse) {
+        if (Ni == 0 && io->z_vals)      // the caller wants z_vals back: they are its own coarse depths
+            rc = hipMemcpyAsync(io->z_vals, io->z_coarse, R * Nc * sizeof(float), hipMemcpyDeviceToDevice, s) == hipSuccess
+                     ? 0 : NERF_AMD_EHIP;
+        else
+            z_c = const_cast<float *>(io->z_coarse);
+    } else {
+        rc = launch_coarse_z(io->rays, io->ray_ch, io->t_vals, cfg->perturb ? io->t_rand : nullptr, R, Nc,
                              cfg->lindisp, cfg->perturb, z_c, s);
+    }
     if (rc) return fail(rc, "coarse_z launch failed");
 
     MlpArgs a;

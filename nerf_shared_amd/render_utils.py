@@ -158,9 +158,10 @@ class Renderer(torch.nn.Module):
             raise TypeError("%s must be a nerf_shared_amd.nerf.NeRF (got %s); load a reference model's "
                             "state_dict into one" % (name, type(m).__name__))
 
-    def _launch(self, rays, coarse_model, fine_model, outs, retraw, retweights, pytest, slot=0):
+    def _launch(self, rays, coarse_model, fine_model, outs, retraw, retweights, pytest, slot=0, z_pre=None):
         """Enqueue render_rays for contiguous fp32 rays [R, 8|11]; writes into the
-        tensors of ``outs`` (rows [0, R))."""
+        tensors of ``outs`` (rows [0, R)).  z_pre: coarse depths [R, N_samples] made beforehand (render_batch
+        computes them for all chunks in one launch)."""
         R, dev = rays.shape[0], rays.device
         Nc, Ni = int(self.N_samples), int(self.N_importance)
         Nf = Nc + Ni
@@ -177,7 +178,7 @@ class Renderer(torch.nn.Module):
 
         # --- random draws, in the reference's order and shapes
         t_rand = noise0 = noise1 = u = None
-        if self.perturb > 0.:
+        if self.perturb > 0. and z_pre is None:
             t_rand = _pytest_uniform([R, Nc], dev) if pytest else torch.rand([R, Nc], device=dev)
         if self.raw_noise_std > 0.:
             noise0 = (_pytest_uniform([R, Nc], dev) if pytest else torch.randn([R, Nc], device=dev)) * self.raw_noise_std
@@ -203,6 +204,7 @@ class Renderer(torch.nn.Module):
         io.t_vals = _linspace01(Nc, dev).data_ptr()
         io.t_rand, io.noise0, io.noise1 = _lib.ptr(t_rand), _lib.ptr(noise0), _lib.ptr(noise1)
         io.u, io.t_lin_imp = _lib.ptr(u), _lib.ptr(t_lin)
+        io.z_coarse = _lib.ptr(z_pre)
         for k in ('rgb_map', 'disp_map', 'acc_map', 'rgb0', 'disp0', 'acc0', 'z_std', 'raw', 'weights', 'z_vals'):
             setattr(io, k, _lib.ptr(outs.get(k)))
         nbytes = lib.nerf_amd_render_rays_workspace(cfg, R, out_ch)
@@ -350,9 +352,19 @@ class Renderer(torch.nn.Module):
                     parts.setdefault(k, []).append(v)
             return {k: torch.cat(v, 0) for k, v in parts.items()}
         if not (self.overlap_chunks and len(starts) > 1):
+            z_all = None
+            if len(starts) > 1:          # coarse depths of every chunk in one launch instead of one per chunk
+                Nc = int(self.N_samples)
+                t_rand = torch.rand([N, Nc], device=dev) if self.perturb > 0. else None
+                z_all = torch.empty(N, Nc, device=dev, dtype=torch.float32)
+                with torch.cuda.device(dev):
+                    _lib.check(lib.nerf_amd_coarse_z(rays.data_ptr(), rays.shape[1], _linspace01(Nc, dev).data_ptr(),
+                                                     _lib.ptr(t_rand), N, Nc, int(bool(self.lindisp)), int(self.perturb > 0.),
+                                                     z_all.data_ptr(), _lib.stream_of(dev)), "nerf_amd_coarse_z")
             for i in starts:
                 part = {k: v[i:i + chunk] for k, v in full.items()}
-                self._launch(rays[i:i + chunk], coarse_model, fine_model, part, retraw, False, False)
+                self._launch(rays[i:i + chunk], coarse_model, fine_model, part, retraw, False, False,
+                             z_pre=None if z_all is None else z_all[i:i + chunk])
             return full
         # pack parameters and build the cached linspaces on the caller's stream first, then fan out
         _linspace01(int(self.N_samples), dev)

@@ -30,13 +30,13 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "library does not export %s" % name
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert lib.nerf_amd_abi_version() == 1
+    assert lib.nerf_amd_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.Arch) == 4 * (8 + 8)
     assert ctypes.sizeof(_lib.RenderCfg) == 32
-    assert ctypes.sizeof(_lib.RenderIO) == 8 + 8 + 8 * 17 + 8
+    assert ctypes.sizeof(_lib.RenderIO) == 8 + 8 + 8 * 18 + 8
 
 
 def test_program_validation_errors():
