@@ -1,0 +1,18 @@
+#!/bin/bash
+# Round-end measurement pass on the GPU box: the bench line and the rocprofv3 summaries that go under profiles/.
+#   tools/final_profile.sh <tag>      -> gpurun_out/final_<tag>/...
+set -o pipefail
+TAG=${1:-r01}
+OUT=gpurun_out/final_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+python bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
+tail -c 600 $OUT/bench.json
+# kernel trace + stats of the same command (no CPU leg: it only adds host time)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.err || exit 1
+# counters: separate passes, --pmc only
+for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "MfmaUtil" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES" "GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY"; do
+  N=$(echo $C | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$N -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_$N.json 2> $OUT/pmc_$N.err || echo "pmc pass $N failed"
+done
+echo final-profile-done
