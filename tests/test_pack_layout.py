@@ -366,10 +366,14 @@ def frags_to_rows(frags, n_ks):
     return rows
 
 
-def test_backward_stream_matches_kernel_dataflow():
+@pytest.mark.parametrize("arch", CASES[:2], ids=["vd_10_4", "vd_15_6"])
+def test_backward_stream_matches_kernel_dataflow(arch):
     """mlp_bwd_s16.hip's dX chain replayed on the host-packed transposed stream (shape 17): the
-    pre-activation gradients of every layer against a plain numpy backward with the same roundings."""
-    arch = CASES[0]
+    pre-activation gradients of every layer against a plain numpy backward with the same roundings,
+    for both encodings the training kernels are instantiated for."""
+    LX, LD = arch["multires"], arch["multires_views"]
+    KE, KD = gen16_ksteps(LX), gen16_ksteps(LD)
+    ic, icv = 3 + 6 * LX, 3 + 6 * LD
     rng = np.random.default_rng(9)
     pts = rng.uniform(-3, 3, size=(32, 3)).astype(np.float32)
     dirs = rng.normal(size=(32, 3)).astype(np.float32)
@@ -379,7 +383,7 @@ def test_backward_stream_matches_kernel_dataflow():
     emulate16(arch, sd, pts, dirs, keep)
     g_raw = rng.normal(size=(32, 4)).astype(np.float32)
     stream, _ = host_pack(arch, sd, 17)
-    assert stream.shape[0] % 192 == 0 and stream.shape[0] >= 1112
+    assert stream.shape[0] % 192 == 0
     w = WaveEmu16(stream, np.zeros((400, 16), np.float32))
 
     def gen_frag(cols):                      # FRAG_TG16 operand: k slot (q=0, j) = column j of g_raw
@@ -400,9 +404,16 @@ def test_backward_stream_matches_kernel_dataflow():
 
     Grgb, Gsig = gen_frag([0, 1, 2]), gen_frag([3])
     G = {}
-    # fragment offsets of mlp_bwd_s16.hip's LayoutB
-    F_HV, F_FEAT, F_DIRS, F_H8, F_L7, F_E5, F_L4, F_E0 = 0, 8, 72, 80, 224, 608, 640, 1152
-    assert stream.shape[0] >= F_E0 + 32
+    # fragment offsets of mlp_bwd_s16.hip's LayoutB<KE, KD>
+    F_HV, F_FEAT, F_DIRS = 0, 8, 72
+    F_H8 = F_DIRS + 8 * KD
+    F_L7 = F_H8 + 144
+    F_E5 = F_L7 + 3 * 128
+    F_L4 = F_E5 + 16 * KE
+    F_E0 = F_L4 + 4 * 128
+    assert stream.shape[0] >= F_E0 + 16 * KE
+    if (LX, LD) == (10, 4):
+        assert (F_H8, F_L7, F_E5, F_L4, F_E0) == (80, 224, 608, 640, 1152)
 
     def enc_slots(f0, npair, x, L, n_cols):
         """FRAG_TE16 products: per point, gradient of every encoding column (from the lane that owns its slot)."""
@@ -420,17 +431,17 @@ def test_backward_stream_matches_kernel_dataflow():
 
     G["hv"] = tlayer(F_HV, 4, Grgb, 1, mask=keep["hv"])
     G["feat"] = tlayer(F_FEAT, 8, G["hv"], 4)
-    g_dirs = enc_slots(F_DIRS, 1, G["hv"], 4, 27)
+    g_dirs = enc_slots(F_DIRS, KD, G["hv"], LD, icv)
     g = tlayer(F_H8, 8, G["feat"], 8, Gsig, 1, mask=keep["h"][7])
     G[7] = g
     g_e = None
     for n, l in enumerate(range(6, -1, -1)):
         f0 = F_L7 + 128 * n if l >= 4 else F_L4 + 128 * (3 - l)
         if l == 4:
-            g_e = enc_slots(F_E5, 2, g, 10, 63)              # g here is the gradient of pts_linears.5's pre-activation
+            g_e = enc_slots(F_E5, KE, g, LX, ic)             # g here is the gradient of pts_linears.5's pre-activation
         g = tlayer(f0, 8, g, 8, mask=keep["h"][l])
         G[l] = g
-    g_e = g_e + enc_slots(F_E0, 2, g, 10, 63)
+    g_e = g_e + enc_slots(F_E0, KE, g, LX, ic)
 
     # plain numpy backward on natural-order rows with the same bf16 roundings
     Wb = {k: bf16_round(v).astype(np.float64) for k, v in sd.items() if k.endswith("weight")}
@@ -445,16 +456,16 @@ def test_backward_stream_matches_kernel_dataflow():
     g_prev = g8
     for l in range(7, 0, -1):
         Wl = Wb["pts_linears.%d.weight" % l]
-        if Wl.shape[1] == 319:
-            Wl = Wl[:, 63:]
+        if Wl.shape[1] == ic + 256:
+            Wl = Wl[:, ic:]
         g_prev = rb((g_prev @ Wl) * (h[l - 1] != 0))
         ref[l - 1] = g_prev
     for key, n_ks in (("hv", 4), ("feat", 8), (7, 8), (4, 8), (0, 8)):
         got = frags_to_rows(G[key], n_ks)
         np.testing.assert_allclose(got, ref[key], atol=2e-2 * float(np.abs(ref[key]).max()), rtol=0, err_msg=str(key))
     # gradients of the encodings (inputs of the ray gradients)
-    ref_dirs = ref["hv"] @ Wb["views_linears.0.weight"][:, 256:283]
-    ref_e = ref[5] @ Wb["pts_linears.5.weight"][:, :63] + ref[0] @ Wb["pts_linears.0.weight"]
+    ref_dirs = ref["hv"] @ Wb["views_linears.0.weight"][:, 256:256 + icv]
+    ref_e = ref[5] @ Wb["pts_linears.5.weight"][:, :ic] + ref[0] @ Wb["pts_linears.0.weight"]
     np.testing.assert_allclose(g_dirs, ref_dirs, atol=2e-2 * float(np.abs(ref_dirs).max()), rtol=0)
     np.testing.assert_allclose(g_e, ref_e, atol=2e-2 * float(np.abs(ref_e).max()), rtol=0)
 
