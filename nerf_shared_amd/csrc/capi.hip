@@ -55,8 +55,6 @@ struct nerf_amd_model {
     TileDesc *d_tiles = nullptr;
     LayerF32 *d_layers = nullptr;
     TensorDesc *d_tensors = nullptr;
-    const float **d_wptrs = nullptr, **d_bptrs = nullptr;
-    std::vector<const float *> h_wptrs, h_bptrs;
     uint16_t *stream_bf16 = nullptr, *stream_s16 = nullptr, *stream_bwd = nullptr;
     FragDesc *d_frags_bwd = nullptr;
     float *bias_bf16 = nullptr, *stream_f32 = nullptr, *bias_f32 = nullptr, *bias_s16 = nullptr;
@@ -81,7 +79,10 @@ int nerf_amd_model_create(const nerf_amd_arch *arch, int device, nerf_amd_model 
         return fail(NERF_AMD_EINVAL, err);
     }
     m->device = device;
-    HIP_TRY(hipSetDevice(device));
+    if (hipError_t e0 = hipSetDevice(device); e0 != hipSuccess) {
+        delete m;
+        return hip_fail(e0, "hipSetDevice");
+    }
     const Program &p = m->prog;
     int rc;
     if ((rc = upload(&m->d_frags, p.frags)) || (rc = upload(&m->d_tiles, p.tiles)) ||
@@ -91,10 +92,8 @@ int nerf_amd_model_create(const nerf_amd_arch *arch, int device, nerf_amd_model 
         nerf_amd_model_destroy(m);
         return rc;
     }
-    const size_t nt = p.tensors.size();
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&m->d_wptrs), nt * sizeof(float *));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->d_bptrs), nt * sizeof(float *));
-    if (e == hipSuccess && p.bf16_ok) {
+    hipError_t e = hipSuccess;
+    if (p.bf16_ok) {
         e = hipMalloc(reinterpret_cast<void **>(&m->stream_bf16), p.frags.size() * 1024);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->bias_bf16), p.tiles.size() * 32 * sizeof(float));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->stream_s16), p.frags16.size() * 1024);
@@ -137,7 +136,6 @@ int nerf_amd_model_update(nerf_amd_model *m, const float *const *weights, const 
 void nerf_amd_model_destroy(nerf_amd_model *m) {
     if (!m) return;
     (void)hipFree(m->d_frags); (void)hipFree(m->d_tiles); (void)hipFree(m->d_layers); (void)hipFree(m->d_tensors);
-    (void)hipFree(m->d_wptrs); (void)hipFree(m->d_bptrs);
     (void)hipFree(m->d_frags_bwd); (void)hipFree(m->stream_bwd);
     (void)hipFree(m->d_frags16); (void)hipFree(m->d_tiles16); (void)hipFree(m->stream_s16); (void)hipFree(m->bias_s16);
     (void)hipFree(m->stream_bf16); (void)hipFree(m->bias_bf16); (void)hipFree(m->stream_f32); (void)hipFree(m->bias_f32);
