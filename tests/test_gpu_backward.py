@@ -479,3 +479,56 @@ def test_trained_scene_psnr_within_a_tenth_of_a_db_of_the_oracle(dev, sphere_run
     finally:
         coarse.precision = fine.precision = "bf16"
         renderer.perturb = was
+
+
+@pytest.mark.parametrize("variant", ["single_model_both_passes", "coarse_only", "noise_lindisp"])
+def test_training_gradients_of_the_other_render_configurations(dev, monkeypatch, variant):
+    """render_rays' other branches under autograd: fine_model=None (the coarse network evaluates both
+    passes, render_utils.py:150-151, so its gradient is the sum of two backward passes), N_importance=0
+    (single pass), and lindisp + sigma noise (configs/fern.txt uses raw_noise_std = 1).  Against
+    torch.autograd on the oracle with the kernel's roundings."""
+    from nerf_shared_amd import render_utils
+    batch, target = _batch(64, 5)
+    cfg = dict(BASE, N_samples=32, N_importance=0 if variant == "coarse_only" else 40)
+    draws = {}
+    if variant == "noise_lindisp":
+        cfg.update(lindisp=True, raw_noise_std=1.0)
+    r = render_utils.Renderer(**cfg)
+    mc, cc = _models(dev, 1, 1.0)
+    mf, cf = _models(dev, 11, 1.0)
+    # default-scale weights give sigma <= 0 almost everywhere (zero gradient): lift the density bias so the
+    # volume is semi-transparent -- non-degenerate gradients and a well-conditioned resampling
+    with torch.no_grad():
+        for m, sd in ((mc, cc), (mf, cf)):
+            m.alpha_linear.bias += 0.3
+            sd["alpha_linear.bias"] += 0.3
+    use_fine = variant == "noise_lindisp"
+    kw = dict(pytest=True) if variant == "noise_lindisp" else {}      # seeded draws on both sides
+    out = r.render_rays(batch.to(dev), mc, mf if use_fine else None, **kw)
+    t = target.to(dev)
+    loss = ((out["rgb_map"] - t) ** 2).mean()
+    if "rgb0" in out:
+        loss = loss + ((out["rgb0"] - t) ** 2).mean()
+    loss.backward()
+    assert all(p.grad is None for p in mf.parameters()) or use_fine
+
+    monkeypatch.setattr(O, "nerf_forward", lambda sd, arch, pts, vd, netchunk=0: bf16_field(sd, pts, vd))
+    c = {k: v.detach().clone().requires_grad_(True) for k, v in cc.items()}
+    f = {k: v.detach().clone().requires_grad_(True) for k, v in cf.items()}
+    o = O.render_rays(O.RenderCfg(**cfg), batch, (c, O.Arch(**VD)), (f, O.Arch(**VD)) if use_fine else None, **kw, **draws)
+    l = ((o["rgb_map"] - target) ** 2).mean()
+    if "rgb0" in o:
+        l = l + ((o["rgb0"] - target) ** 2).mean()
+    l.backward()
+    monkeypatch.undo()
+    assert abs(float(loss) - float(l)) < 3e-3 * max(1.0, abs(float(l)))
+    worst = 0.0
+    for m, ref in ((mc, c),) + (((mf, f),) if use_fine else ()):
+        for name, p in m.named_parameters():
+            assert p.grad is not None and torch.isfinite(p.grad).all(), name
+            e = rel_err(p.grad.detach().cpu(), ref[name].grad)
+            print("   %-26s %.4f   |g| %.3e" % (name, e, float(ref[name].grad.norm())))
+            assert float(ref[name].grad.norm()) > 0, "degenerate test: zero gradient"
+            worst = max(worst, e)
+    print(variant, "worst relative gradient error %.4f" % worst)
+    assert worst < 8e-2, worst
