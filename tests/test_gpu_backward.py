@@ -532,3 +532,45 @@ def test_training_gradients_of_the_other_render_configurations(dev, monkeypatch,
             worst = max(worst, e)
     print(variant, "worst relative gradient error %.4f" % worst)
     assert worst < 8e-2, worst
+
+
+def test_training_gradients_through_render_with_ndc_rays(dev, monkeypatch):
+    """The LLFF training configuration (configs/fern.txt: NDC rays, near/far 0/1, 64+64 samples, sigma
+    noise): Renderer.render(rays=..., ndc=True) under autograd, parameter gradients against
+    torch.autograd on the oracle with the kernel's roundings."""
+    from nerf_shared_amd import render_utils
+    H, W, focal = 378, 504, 408.0
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+    rng = np.random.default_rng(12)
+    c2w = np.array([[1, 0, 0, 0.05], [0, 1, 0, -0.02], [0, 0, 1, 0.1]], np.float32)
+    idx = np.sort(rng.choice(H * W, size=72, replace=False))
+    ro, rd = synth.rays_np(H, W, K, c2w, idx)
+    rays = (torch.from_numpy(ro), torch.from_numpy(rd))
+    target = torch.from_numpy(rng.uniform(0, 1, size=(72, 3)).astype(np.float32))
+    cfg = dict(BASE, N_samples=32, N_importance=32, ndc=True, near=0.0, far=1.0, white_bkgd=False)
+    r = render_utils.Renderer(**cfg)
+    mc, cc = _models(dev, 1, 1.0)
+    mf, cf = _models(dev, 11, 1.0)
+    with torch.no_grad():
+        for m, sd in ((mc, cc), (mf, cf)):
+            m.alpha_linear.bias += 0.3
+            sd["alpha_linear.bias"] += 0.3
+    rgb, disp, acc, extras = r.render(H, W, K, mc, mf, chunk=50, rays=(rays[0].to(dev), rays[1].to(dev)), retraw=True)
+    t = target.to(dev)
+    loss = ((rgb - t) ** 2).mean() + ((extras["rgb0"] - t) ** 2).mean()
+    loss.backward()
+    monkeypatch.setattr(O, "nerf_forward", lambda sd, arch, pts, vd, netchunk=0: bf16_field(sd, pts, vd))
+    c = {k: v.detach().clone().requires_grad_(True) for k, v in cc.items()}
+    f = {k: v.detach().clone().requires_grad_(True) for k, v in cf.items()}
+    o = O.render(O.RenderCfg(**cfg), H, W, K, (c, O.Arch(**VD)), (f, O.Arch(**VD)), chunk=50, rays=rays, retraw=True)
+    l = ((o[0] - target) ** 2).mean() + ((o[3]["rgb0"] - target) ** 2).mean()
+    l.backward()
+    monkeypatch.undo()
+    assert abs(float(loss.detach()) - float(l.detach())) < 3e-3 * max(1.0, abs(float(l.detach())))
+    worst = 0.0
+    for m, ref in ((mc, c), (mf, f)):
+        for name, p in m.named_parameters():
+            assert float(ref[name].grad.norm()) > 0 and torch.isfinite(p.grad).all(), name
+            worst = max(worst, rel_err(p.grad.detach().cpu(), ref[name].grad))
+    print("ndc training: worst relative gradient error %.4f" % worst)
+    assert worst < 8e-2, worst
