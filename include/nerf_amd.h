@@ -123,6 +123,13 @@ int nerf_amd_mlp_embedded(const nerf_amd_model *m, const float *x, int64_t n, fl
 int nerf_amd_ndc_rays(int32_t H, int32_t W, double focal, float near, const float *rays_o, const float *rays_d,
                       int64_t n, float *out_o, float *out_d, void *stream);
 
+/* Backward of nerf_amd_ndc_rays (pose estimation on forward-facing scenes differentiates through the warp):
+ * gradients of its two outputs [n,3] (either may be NULL = zero) -> gradients of rays_o / rays_d [n,3]
+ * (either may be NULL = not wanted), overwritten. */
+int nerf_amd_ndc_rays_backward(int32_t H, int32_t W, double focal, float near, const float *rays_o, const float *rays_d,
+                               const float *g_out_o, const float *g_out_d, int64_t n, float *g_rays_o, float *g_rays_d,
+                               void *stream);
+
 /* ------------------------------------------------------------------------
  * a10  Renderer.raw2outputs                   render_utils.py:241-290
  * raw [R,S,raw_ch] (channels 0..2 rgb, 3 sigma), z_vals [R,S], rays_d with row

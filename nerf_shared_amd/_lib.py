@@ -24,7 +24,7 @@ EXPORTS = (
     "nerf_amd_render_rays_workspace", "nerf_amd_render_rays", "nerf_amd_make_rays",
     "nerf_amd_profile_enable", "nerf_amd_profile_collect", "nerf_amd_set_tuning",
     "nerf_amd_model_supports_training", "nerf_amd_train_workspace", "nerf_amd_field_forward_train",
-    "nerf_amd_field_backward", "nerf_amd_coarse_z", "nerf_amd_resample", "nerf_amd_get_rays_backward", "nerf_amd_to8b",
+    "nerf_amd_field_backward", "nerf_amd_coarse_z", "nerf_amd_resample", "nerf_amd_get_rays_backward", "nerf_amd_to8b", "nerf_amd_ndc_rays_backward",
 )
 
 
@@ -96,6 +96,8 @@ def _load():
         "nerf_amd_get_rays_backward": (c_int, [c_int32, c_int32, POINTER(c_double), c_int64, c_int64, c_void_p, c_void_p,
                                                c_void_p, c_void_p]),
         "nerf_amd_to8b": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+        "nerf_amd_ndc_rays_backward": (c_int, [c_int32, c_int32, c_double, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_int64, c_void_p, c_void_p, c_void_p]),
         "nerf_amd_profile_enable": (c_int, [c_int]),
         "nerf_amd_profile_collect": (c_int, [POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),
     }

@@ -269,6 +269,16 @@ int nerf_amd_ndc_rays(int32_t H, int32_t W, double focal, float near, const floa
     return rc ? fail(rc, "ndc_rays launch failed") : NERF_AMD_OK;
 }
 
+int nerf_amd_ndc_rays_backward(int32_t H, int32_t W, double focal, float near, const float *rays_o, const float *rays_d,
+                               const float *g_out_o, const float *g_out_d, int64_t n, float *g_rays_o, float *g_rays_d,
+                               void *stream) {
+    if (H < 1 || W < 1 || n < 0 || (n > 0 && (!rays_o || !rays_d)))
+        return fail(NERF_AMD_EINVAL, "bad ndc_rays_backward arguments");
+    int rc = launch_ndc_rays_bwd(H, W, focal, near, rays_o, rays_d, g_out_o, g_out_d, n, g_rays_o, g_rays_d,
+                                 static_cast<hipStream_t>(stream));
+    return rc ? fail(rc, "ndc_rays backward launch failed") : NERF_AMD_OK;
+}
+
 int nerf_amd_model_supports_training(const nerf_amd_model *m) { return m && train_supported(m->prog) ? 1 : 0; }
 
 int64_t nerf_amd_train_workspace(const nerf_amd_model *m, int64_t n_points) {

@@ -110,6 +110,8 @@ int launch_composite_resample(const float *raw, int raw_ch, const float *z_coars
                               const float *noise, int64_t R, int Nc, int Ni, int white_bkgd, float *rgb0, float *disp0,
                               float *acc0, float *weights, const float *u, const float *t_lin, float *z_fine, float *z_std,
                               hipStream_t s);
+int launch_ndc_rays_bwd(int H, int W, double focal, float near, const float *rays_o, const float *rays_d, const float *g_oo,
+                        const float *g_od, int64_t n, float *g_ro, float *g_rd, hipStream_t s);
 int launch_ndc_rays(int H, int W, double focal, float near, const float *rays_o, const float *rays_d, int64_t n,
                     float *out_o, float *out_d, hipStream_t s);
 int launch_get_rays_bwd(int H, int W, const double *K4, int64_t pix0, int64_t n, const float *g_o, const float *g_d,

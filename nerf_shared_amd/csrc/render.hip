@@ -597,6 +597,48 @@ __global__ __launch_bounds__(256) void ndc_rays_kernel(float sx, float sy, float
     od[3 * i + 2] = -2.0f * nearp / o[2];
 }
 
+// Backward of the NDC warp above: gradients of (oo, od) -> gradients of (ro, rd), per ray, following the
+// forward's own sequence of operations (what torch.autograd differentiates in utils.py:54-71).
+__global__ __launch_bounds__(256) void ndc_rays_bwd_kernel(float sx, float sy, float nearp, const float *ro, const float *rd,
+                                                           const float *g_oo, const float *g_od, int64_t n, float *g_ro,
+                                                           float *g_rd) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float o[3] = {ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]};
+    const float d[3] = {rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]};
+    const float t = -(nearp + o[2]) / d[2];
+    const float p[3] = {o[0] + t * d[0], o[1] + t * d[1], o[2] + t * d[2]};
+    const float go[3] = {g_oo ? g_oo[3 * i] : 0.f, g_oo ? g_oo[3 * i + 1] : 0.f, g_oo ? g_oo[3 * i + 2] : 0.f};
+    const float gd[3] = {g_od ? g_od[3 * i] : 0.f, g_od ? g_od[3 * i + 1] : 0.f, g_od ? g_od[3 * i + 2] : 0.f};
+    const float ipz = 1.0f / p[2], idz = 1.0f / d[2];
+    const float ax = sx * (go[0] - gd[0]), ay = sy * (go[1] - gd[1]);       // weights of px/pz and py/pz
+    float gp[3];
+    gp[0] = ax * ipz;
+    gp[1] = ay * ipz;
+    gp[2] = -(ax * p[0] + ay * p[1]) * ipz * ipz + 2.0f * nearp * ipz * ipz * (gd[2] - go[2]);
+    float gdir[3];
+    gdir[0] = sx * gd[0] * idz;
+    gdir[1] = sy * gd[1] * idz;
+    gdir[2] = -(sx * gd[0] * d[0] + sy * gd[1] * d[1]) * idz * idz;
+    const float gt = gp[0] * d[0] + gp[1] * d[1] + gp[2] * d[2];            // p = o + t d
+    float gor[3] = {gp[0], gp[1], gp[2]};
+    gdir[0] += t * gp[0]; gdir[1] += t * gp[1]; gdir[2] += t * gp[2];
+    gor[2] += -gt * idz;                                                     // t = -(near + oz) / dz
+    gdir[2] += -gt * t * idz;
+    if (g_ro) { g_ro[3 * i] = gor[0]; g_ro[3 * i + 1] = gor[1]; g_ro[3 * i + 2] = gor[2]; }
+    if (g_rd) { g_rd[3 * i] = gdir[0]; g_rd[3 * i + 1] = gdir[1]; g_rd[3 * i + 2] = gdir[2]; }
+}
+
+int launch_ndc_rays_bwd(int H, int W, double focal, float near, const float *rays_o, const float *rays_d, const float *g_oo,
+                        const float *g_od, int64_t n, float *g_ro, float *g_rd, hipStream_t s) {
+    if (n <= 0) return NERF_AMD_OK;
+    const float sx = (float)(-1.0 / ((double)W / (2.0 * focal)));
+    const float sy = (float)(-1.0 / ((double)H / (2.0 * focal)));
+    hipLaunchKernelGGL(ndc_rays_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sx, sy, near, rays_o, rays_d,
+                       g_oo, g_od, n, g_ro, g_rd);
+    return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
+}
+
 int launch_ndc_rays(int H, int W, double focal, float near, const float *rays_o, const float *rays_d, int64_t n,
                     float *out_o, float *out_d, hipStream_t s) {
     if (n <= 0) return NERF_AMD_OK;

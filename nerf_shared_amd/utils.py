@@ -121,18 +121,50 @@ def get_rays_np(H, W, K, c2w):
     return rays_o, rays_d
 
 
-def ndc_rays(H, W, focal, near, rays_o, rays_d):
-    """Forward-facing NDC warp of explicit rays (utils.py:54-71)."""
-    _lib.require_device(rays_d, "rays_d")
-    dev = rays_d.device
-    shape = rays_d.shape
-    o = rays_o.detach().expand(shape).reshape(-1, 3).contiguous().float()
-    d = rays_d.detach().reshape(-1, 3).contiguous().float()
+def _ndc_forward(H, W, focal, near, o, d):
     oo, od = torch.empty_like(o), torch.empty_like(d)
-    with torch.cuda.device(dev):
+    with torch.cuda.device(d.device):
         _lib.check(lib.nerf_amd_ndc_rays(int(H), int(W), float(focal), float(near), o.data_ptr(), d.data_ptr(),
-                                         o.shape[0], oo.data_ptr(), od.data_ptr(), _lib.stream_of(dev)),
+                                         o.shape[0], oo.data_ptr(), od.data_ptr(), _lib.stream_of(d.device)),
                    "nerf_amd_ndc_rays")
+    return oo, od
+
+
+class _NdcRaysFn(torch.autograd.Function):
+    """ndc_rays with gradients with respect to the rays (nerf_amd_ndc_rays_backward)."""
+
+    @staticmethod
+    def forward(ctx, o, d, H, W, focal, near):
+        ctx.save_for_backward(o, d)
+        ctx.args = (int(H), int(W), float(focal), float(near))
+        return _ndc_forward(H, W, focal, near, o, d)
+
+    @staticmethod
+    def backward(ctx, g_oo, g_od):
+        o, d = ctx.saved_tensors
+        H, W, focal, near = ctx.args
+        g_oo = None if g_oo is None else g_oo.contiguous().float()
+        g_od = None if g_od is None else g_od.contiguous().float()
+        g_o, g_d = torch.empty_like(o), torch.empty_like(d)
+        with torch.cuda.device(d.device):
+            _lib.check(lib.nerf_amd_ndc_rays_backward(H, W, focal, near, o.data_ptr(), d.data_ptr(), _lib.ptr(g_oo), _lib.ptr(g_od),
+                                                      o.shape[0], g_o.data_ptr(), g_d.data_ptr(), _lib.stream_of(d.device)),
+                       "nerf_amd_ndc_rays_backward")
+        return g_o, g_d, None, None, None, None
+
+
+def ndc_rays(H, W, focal, near, rays_o, rays_d):
+    """Forward-facing NDC warp of explicit rays (utils.py:54-71).  Differentiable with respect to the rays."""
+    _lib.require_device(rays_d, "rays_d")
+    shape = rays_d.shape
+    if torch.is_grad_enabled() and (rays_o.requires_grad or rays_d.requires_grad):
+        o = rays_o.expand(shape).reshape(-1, 3).contiguous().float()
+        d = rays_d.reshape(-1, 3).contiguous().float()
+        oo, od = _NdcRaysFn.apply(o, d, H, W, focal, near)
+    else:
+        o = rays_o.detach().expand(shape).reshape(-1, 3).contiguous().float()
+        d = rays_d.detach().reshape(-1, 3).contiguous().float()
+        oo, od = _ndc_forward(H, W, focal, near, o, d)
     return oo.reshape(shape), od.reshape(shape)
 
 

@@ -574,3 +574,51 @@ def test_training_gradients_through_render_with_ndc_rays(dev, monkeypatch):
             worst = max(worst, rel_err(p.grad.detach().cpu(), ref[name].grad))
     print("ndc training: worst relative gradient error %.4f" % worst)
     assert worst < 8e-2, worst
+
+
+def test_ndc_rays_backward_and_ray_gradients_through_the_ndc_render(dev, monkeypatch):
+    """utils.ndc_rays under autograd (nerf_amd_ndc_rays_backward) against torch.autograd on the oracle's
+    restatement of utils.py:54-71, then the whole chain rays -> NDC warp -> render -> loss with frozen
+    networks (pose estimation on a forward-facing scene)."""
+    from nerf_shared_amd import render_utils, utils
+    H, W, focal = 378, 504, 408.0
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+    rng = np.random.default_rng(14)
+    c2w = np.array([[1, 0, 0, 0.05], [0, 1, 0, -0.02], [0, 0, 1, 0.1]], np.float32)
+    idx = np.sort(rng.choice(H * W, size=60, replace=False))
+    ro, rd = synth.rays_np(H, W, K, c2w, idx)
+    ro = ro + rng.normal(scale=0.05, size=ro.shape).astype(np.float32)            # distinct origins
+    wo, wd = (torch.from_numpy(rng.normal(size=(60, 3)).astype(np.float32)) for _ in range(2))
+    # (1) the warp alone
+    o_g, d_g = torch.from_numpy(ro).to(dev).requires_grad_(True), torch.from_numpy(rd).to(dev).requires_grad_(True)
+    oo, od = utils.ndc_rays(H, W, focal, 1., o_g, d_g)
+    ((oo * wo.to(dev)).sum() + (od * wd.to(dev)).sum()).backward()
+    o_c, d_c = torch.from_numpy(ro).requires_grad_(True), torch.from_numpy(rd).requires_grad_(True)
+    oo_c, od_c = O.ndc_rays(H, W, focal, 1., o_c, d_c)
+    ((oo_c * wo).sum() + (od_c * wd).sum()).backward()
+    assert (oo.cpu() - oo_c.detach()).abs().max() < 1e-6 and (od.detach().cpu() - od_c.detach()).abs().max() < 1e-6
+    assert rel_err(o_g.grad, o_c.grad) < 1e-5 and rel_err(d_g.grad, d_c.grad) < 1e-5
+    # (2) through the render
+    cfg = dict(BASE, N_samples=32, N_importance=32, ndc=True, near=0.0, far=1.0, white_bkgd=False)
+    r = render_utils.Renderer(**cfg)
+    mc, cc = _models(dev, 1, 1.0)
+    mf, cf = _models(dev, 11, 1.0)
+    with torch.no_grad():
+        for m, sd in ((mc, cc), (mf, cf)):
+            m.alpha_linear.bias += 0.3
+            sd["alpha_linear.bias"] += 0.3
+    mc.requires_grad_(False)
+    mf.requires_grad_(False)
+    target = torch.from_numpy(rng.uniform(0, 1, size=(60, 3)).astype(np.float32))
+    o_g, d_g = torch.from_numpy(ro).to(dev).requires_grad_(True), torch.from_numpy(rd).to(dev).requires_grad_(True)
+    rgb = r.render(H, W, K, mc, mf, chunk=64, rays=(o_g, d_g), retraw=False)[0]
+    ((rgb - target.to(dev)) ** 2).mean().backward()
+    monkeypatch.setattr(O, "nerf_forward", lambda sd, arch, pts, vd, netchunk=0: bf16_field(sd, pts, vd))
+    o_c, d_c = torch.from_numpy(ro).requires_grad_(True), torch.from_numpy(rd).requires_grad_(True)
+    out = O.render(O.RenderCfg(**cfg), H, W, K, ({k: v.detach() for k, v in cc.items()}, O.Arch(**VD)),
+                   ({k: v.detach() for k, v in cf.items()}, O.Arch(**VD)), chunk=64, rays=(o_c, d_c), retraw=False)
+    ((out[0] - target) ** 2).mean().backward()
+    monkeypatch.undo()
+    eo, ed = rel_err(o_g.grad, o_c.grad), rel_err(d_g.grad, d_c.grad)
+    print("ndc render: rays_o grad err %.4f, rays_d grad err %.4f" % (eo, ed))
+    assert float(o_c.grad.norm()) > 0 and eo < 8e-2 and ed < 8e-2
