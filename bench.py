@@ -185,6 +185,8 @@ def main():
         torch.cuda.synchronize()
 
     with torch.no_grad():
+        if world > 1:      # communicator set-up must not land in the timed region, whatever --warmup is
+            nd.gather_rows(torch.zeros(hi - lo, 5, device=dev), n_total, 0)
         for _ in range(args.warmup):
             step()
         fence()
