@@ -233,9 +233,17 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16_kernel(MlpArgs 
     c.ring_u32 = (uint32_t)(uintptr_t)smem;
     c.bias_half = bias_lds + q * 4;          // this lane's 4 rows of every 16-row tile
 
-    pipeline_prologue<NB>(c);
-
     for (int i = tid; i < Lay::N_TILES * 16; i += WG_THREADS) bias_lds[i] = a.bias_s16[i];
+
+    // A workgroup walks 256-point tiles blockIdx.x, blockIdx.x + gridDim.x, ...: with one workgroup per CU
+    // (the launcher's choice for large P) the dispatch of a fresh workgroup per tile disappears.
+    const int64_t n_point_tiles = (a.P + WG_POINTS - 1) / WG_POINTS;
+#pragma unroll 1
+    for (int64_t tile = blockIdx.x; tile < n_point_tiles; tile += gridDim.x) {
+    // opaque per-iteration copy of the stream pointer: otherwise the 148 DMA source addresses of the body are
+    // loop-invariant, get hoisted in front of the loop and cost ~300 VGPRs
+    asm volatile("" : "+v"(c.gstream));
+    pipeline_prologue<NB>(c);
 
     // ---- this lane's two points: column tile cc, column lane&15 (all four lane quarters hold the same points)
     bf16x8 E[KE * 2];
@@ -244,7 +252,7 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16_kernel(MlpArgs 
     bool valid[2];
     static_for<2>([&](auto cc_) {
         constexpr int cc = cc_;
-        const int64_t p = (int64_t)blockIdx.x * WG_POINTS + c.wave * 32 + cc * 16 + (lane & 15);
+        const int64_t p = tile * WG_POINTS + c.wave * 32 + cc * 16 + (lane & 15);
         pidx[cc] = p;
         valid[cc] = p < a.P;
         const int64_t pc = valid[cc] ? p : a.P - 1;
@@ -328,7 +336,9 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16_kernel(MlpArgs 
             }
         });
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // no LDS-DMA may outlive the workgroup
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // no LDS-DMA may outlive the tile (or the workgroup)
+    __syncthreads();                                           // every wave is done with the ring before it is refilled
+    }
 }
 
 template <int LX, int LD, bool VD, class C, bool SAVE = false>
@@ -344,9 +354,18 @@ static int launch_wg16(const MlpArgs &a, int n_frags_used, int n_tiles, hipStrea
         if (e != hipSuccess) return NERF_AMD_EHIP;
         attr_set = true;
     }
-    const int64_t groups = (a.P + WG_POINTS - 1) / WG_POINTS;
+    int64_t groups = (a.P + WG_POINTS - 1) / WG_POINTS;
     if (groups <= 0) return NERF_AMD_OK;
     if (a.P >= (int64_t)1 << 31) return NERF_AMD_EINVAL;
+    if (g_variant != 31) {                 // one workgroup per CU walks the tiles (+1 %: no per-tile dispatch); 31 = A/B off
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        }
+        if (groups > n_cu) groups = n_cu;
+    }
     hipLaunchKernelGGL((mlp_bf16_s16_kernel<LX, LD, VD, C, SAVE>), dim3((unsigned)groups), dim3(WG_THREADS), lds, s, a);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
