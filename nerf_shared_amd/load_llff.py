@@ -41,42 +41,45 @@ def _minify(basedir, factors=(), resolutions=()):
                 im.convert('RGB').resize(size, Image.LANCZOS).save(os.path.join(dst, os.path.splitext(f)[0] + '.png'))
 
 
-def _load_data(basedir, factor=None, width=None, height=None, load_imgs=True):
-    """poses [3,5,N] (with H, W, focal/factor in column 4), bds [2,N], imgs [H,W,3,N] in 0..1."""
-    arr = np.load(os.path.join(basedir, 'poses_bounds.npy'))
-    poses = arr[:, :-2].reshape([-1, 3, 5]).transpose([1, 2, 0])
-    bds = arr[:, -2:].transpose([1, 0])
+def _frame_files(folder):
+    return [os.path.join(folder, f) for f in sorted(os.listdir(folder)) if f.endswith(('JPG', 'jpg', 'png'))]
 
-    full = os.path.join(basedir, 'images')
-    first = [os.path.join(full, f) for f in sorted(os.listdir(full)) if f.endswith(('JPG', 'jpg', 'png'))][0]
-    sh = image_io.read_image(first).shape
-    sfx = ''
+
+def _load_data(basedir, factor=None, width=None, height=None, load_imgs=True):
+    """poses [3,5,N] (with H, W, focal/factor in column 4), bds [2,N], imgs [H,W,3,N] in 0..1.
+    Exactly one of factor / height / width selects the down-sized frame folder (none: images/)."""
+    table = np.load(os.path.join(basedir, 'poses_bounds.npy'))            # [N, 17]: 3x5 pose, near, far
+    poses = table[:, :-2].reshape([-1, 3, 5]).transpose([1, 2, 0])
+    bds = table[:, -2:].transpose([1, 0])
+
+    full_h, full_w = image_io.read_image(_frame_files(os.path.join(basedir, 'images'))[0]).shape[:2]
+    suffix = ''
     if factor is not None:
-        sfx = '_{}'.format(factor)
         _minify(basedir, factors=[factor])
-    elif height is not None:
-        factor = sh[0] / float(height)
-        width = int(sh[1] / factor)
+        suffix = '_{}'.format(factor)
+    elif height is not None or width is not None:
+        if height is not None:
+            factor = full_h / float(height)
+            width = int(full_w / factor)
+        else:
+            factor = full_w / float(width)
+            height = int(full_h / factor)
         _minify(basedir, resolutions=[[height, width]])
-        sfx = '_{}x{}'.format(width, height)
-    elif width is not None:
-        factor = sh[1] / float(width)
-        height = int(sh[0] / factor)
-        _minify(basedir, resolutions=[[height, width]])
-        sfx = '_{}x{}'.format(width, height)
+        suffix = '_{}x{}'.format(width, height)
     else:
         factor = 1
 
-    imgdir = os.path.join(basedir, 'images' + sfx)
-    if not os.path.exists(imgdir):
-        print(imgdir, 'does not exist, returning')
+    folder = os.path.join(basedir, 'images' + suffix)
+    if not os.path.exists(folder):
+        print(folder, 'does not exist, returning')
         return
-    files = [os.path.join(imgdir, f) for f in sorted(os.listdir(imgdir)) if f.endswith(('JPG', 'jpg', 'png'))]
-    if poses.shape[-1] != len(files):
+    files = _frame_files(folder)
+    if len(files) != poses.shape[-1]:
         print('Mismatch between imgs {} and poses {} !!!!'.format(len(files), poses.shape[-1]))
         return
-    sh = image_io.read_image(files[0]).shape
-    poses[:2, 4, :] = np.array(sh[:2]).reshape([2, 1])
+    # the hwf column describes the frames actually loaded: their size, and the focal length scaled with them
+    h, w = image_io.read_image(files[0]).shape[:2]
+    poses[:2, 4, :] = np.array([h, w]).reshape([2, 1])
     poses[2, 4, :] = poses[2, 4, :] * 1. / factor
     if not load_imgs:
         return poses, bds
