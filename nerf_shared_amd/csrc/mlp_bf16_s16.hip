@@ -245,33 +245,62 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16_kernel(MlpArgs 
     asm volatile("" : "+v"(c.gstream));
     pipeline_prologue<NB>(c);
 
-    // ---- this lane's two points: column tile cc, column lane&15 (all four lane quarters hold the same points)
+    // ---- this lane's two points: column tile cc, column lane&15 (all four lane quarters hold the same points).
+    // All loads of both points are issued before anything is computed from them (one branch on the input mode,
+    // one round trip to memory per tile instead of four: the encodings below are long enough that the compiler
+    // does not move the second point's loads above them by itself).
     bf16x8 E[KE * 2];
     bf16x8 Dv[(VD ? KD : 1) * 2];
     int64_t pidx[2];
     bool valid[2];
+    float xs[2][3], dv[2][3];
+    {
+        int64_t pc[2], ray[2];
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const int64_t p = tile * WG_POINTS + c.wave * 32 + cc * 16 + (lane & 15);
+            pidx[cc] = p;
+            valid[cc] = p < a.P;
+            pc[cc] = valid[cc] ? p : a.P - 1;
+            ray[cc] = (int64_t)((uint32_t)pc[cc] / (uint32_t)a.S);   // P < 2^31 (checked at launch)
+        }
+        auto load_dirs = [&]() {
+            if constexpr (VD) {
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    const float *d = a.viewdirs + ray[cc] * a.vd_stride;
+                    dv[cc][0] = d[0]; dv[cc][1] = d[1]; dv[cc][2] = d[2];
+                }
+            }
+        };
+        if (a.pts) {
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                xs[cc][0] = a.pts[3 * pc[cc] + 0]; xs[cc][1] = a.pts[3 * pc[cc] + 1]; xs[cc][2] = a.pts[3 * pc[cc] + 2];
+            }
+            load_dirs();
+        } else {
+            float o[2][6], z[2];
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const float *r = a.rays + ray[cc] * a.ray_stride;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) o[cc][k] = r[k];
+                z[cc] = a.z_vals[pc[cc]];
+            }
+            load_dirs();
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {                       // pts = o + d z, rounded like the reference's two ops
+                xs[cc][0] = __fadd_rn(o[cc][0], __fmul_rn(o[cc][3], z[cc]));
+                xs[cc][1] = __fadd_rn(o[cc][1], __fmul_rn(o[cc][4], z[cc]));
+                xs[cc][2] = __fadd_rn(o[cc][2], __fmul_rn(o[cc][5], z[cc]));
+            }
+        }
+    }
     static_for<2>([&](auto cc_) {
         constexpr int cc = cc_;
-        const int64_t p = tile * WG_POINTS + c.wave * 32 + cc * 16 + (lane & 15);
-        pidx[cc] = p;
-        valid[cc] = p < a.P;
-        const int64_t pc = valid[cc] ? p : a.P - 1;
-        const int64_t ray = (int64_t)((uint32_t)pc / (uint32_t)a.S);   // P < 2^31 (checked at launch)
-        float x0, x1, x2;
-        if (a.pts) {
-            x0 = a.pts[3 * pc + 0]; x1 = a.pts[3 * pc + 1]; x2 = a.pts[3 * pc + 2];
-        } else {
-            const float *r = a.rays + ray * a.ray_stride;
-            const float z = a.z_vals[pc];
-            x0 = __fadd_rn(r[0], __fmul_rn(r[3], z));
-            x1 = __fadd_rn(r[1], __fmul_rn(r[4], z));
-            x2 = __fadd_rn(r[2], __fmul_rn(r[5], z));
-        }
-        encode16<LX, KE, 2>(x0, x1, x2, q >> 1, q & 1, E + cc);
-        if constexpr (VD) {
-            const float *d = a.viewdirs + ray * a.vd_stride;
-            encode16<LD, KD, 2>(d[0], d[1], d[2], q >> 1, q & 1, Dv + cc);
-        }
+        encode16<LX, KE, 2>(xs[cc][0], xs[cc][1], xs[cc][2], q >> 1, q & 1, E + cc);
+        if constexpr (VD) encode16<LD, KD, 2>(dv[cc][0], dv[cc][1], dv[cc][2], q >> 1, q & 1, Dv + cc);
     });
 
     if constexpr (C::PHASE > 0) {
