@@ -135,6 +135,9 @@ def main():
     if os.environ.get("NERF_AMD_OVERLAP_CHUNKS") == "1":      # A/B knob: two-stream chunk pipeline of render_batch
         from nerf_shared_amd import render_utils as _ru
         _ru.Renderer.overlap_chunks = True
+    if os.environ.get("NERF_AMD_FUSE_CHUNKS") == "0":         # A/B knob: one render_rays call per chunk
+        from nerf_shared_amd import render_utils as _ru
+        _ru.Renderer.fuse_chunk_launches = False
 
     import torch
     import torch.distributed as dist

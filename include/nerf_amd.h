@@ -243,6 +243,16 @@ int     nerf_amd_render_rays(const nerf_amd_render_cfg *cfg, const nerf_amd_mode
                              const nerf_amd_model *fine /* NULL: reuse coarse (:150) */,
                              const nerf_amd_render_io *io, int64_t R, void *stream);
 
+/* Renderer.render_batch (render_utils.py:51-65): the chunk loop around render_rays, as one call.
+ * ios[i] / R[i] describe chunk i exactly as for nerf_amd_render_rays (own draws, own output rows);
+ * consecutive chunks must have distinct workspaces (two buffers used alternately are enough).
+ * Results are those of n calls of nerf_amd_render_rays, all on `stream`.  Between the two field kernels
+ * of chunk k a single launch does the coarse compositing + resampling of chunk k AND the final compositing
+ * of chunk k-1, so a chunk costs three dependent launches instead of four. */
+int     nerf_amd_render_chunks(const nerf_amd_render_cfg *cfg, const nerf_amd_model *coarse,
+                               const nerf_amd_model *fine, const nerf_amd_render_io *ios, const int64_t *R,
+                               int32_t n_chunks, void *stream);
+
 /* ------------------------------------------------------------------------
  * a12/a13 + ray-batch assembly of Renderer.render   utils.py:33-71, render_utils.py:200-226
  * Generates rays for flat pixel range [pix0, pix0+n) of an H x W image straight

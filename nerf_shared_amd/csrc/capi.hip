@@ -399,10 +399,24 @@ int64_t nerf_amd_render_rays_workspace(const nerf_amd_render_cfg *cfg, int64_t R
     return (int64_t)b;
 }
 
-int nerf_amd_render_rays(const nerf_amd_render_cfg *cfg, const nerf_amd_model *coarse, const nerf_amd_model *fine,
-                         const nerf_amd_render_io *io, int64_t R, void *stream) {
+}  // extern "C"
+
+// ---- render_rays over one chunk's buffers, in stages: z_vals, coarse field, coarse compositing (+ resampling),
+// fine field, final compositing.  nerf_amd_render_chunks interleaves the stages of consecutive chunks.
+namespace {
+struct ChunkPlan {
+    const nerf_amd_render_cfg *cfg;
+    const nerf_amd_model *coarse, *fm;
+    const nerf_amd_render_io *io;
+    int64_t R;
+    int Nc, Ni, Nf, och;
+    bool has_vd;
+    float *z_c, *raw_c, *w_c, *z_f, *raw_f;
+};
+
+int plan_chunk(const nerf_amd_render_cfg *cfg, const nerf_amd_model *coarse, const nerf_amd_model *fine,
+               const nerf_amd_render_io *io, int64_t R, ChunkPlan *p) {
     if (!cfg || !coarse || !io || R < 0) return fail(NERF_AMD_EINVAL, "null argument");
-    if (R == 0) return NERF_AMD_OK;
     const int Nc = cfg->N_samples, Ni = cfg->N_importance, Nf = Nc + Ni;
     if (Nc < 1 || Ni < 0) return fail(NERF_AMD_EINVAL, "bad sample counts");
     if (Ni > 0 && Nc < 3) return fail(NERF_AMD_EINVAL, "hierarchical sampling needs N_samples >= 3");
@@ -420,61 +434,139 @@ int nerf_amd_render_rays(const nerf_amd_render_cfg *cfg, const nerf_amd_model *c
         return fail(NERF_AMD_EINVAL, "ray batch width does not match the models' use_viewdirs");
     if (io->workspace_bytes < nerf_amd_render_rays_workspace(cfg, R, och) || !io->workspace)
         return fail(NERF_AMD_EINVAL, "workspace too small");
-    hipStream_t s = static_cast<hipStream_t>(stream);
+    p->cfg = cfg; p->coarse = coarse; p->fm = fm; p->io = io; p->R = R;
+    p->Nc = Nc; p->Ni = Ni; p->Nf = Nf; p->och = och; p->has_vd = has_vd;
 
     char *w = static_cast<char *>(io->workspace);
-    auto take = [&](size_t bytes) { float *p = reinterpret_cast<float *>(w); w += align_up(bytes); return p; };
-    float *z_c = take(R * Nc * sizeof(float));
-    float *raw_c = take(R * Nc * och * sizeof(float));
-    float *w_c = take(R * Nc * sizeof(float));
-    float *z_f = nullptr, *raw_f = nullptr;
+    auto take = [&](size_t bytes) { float *q = reinterpret_cast<float *>(w); w += align_up(bytes); return q; };
+    p->z_c = take(R * Nc * sizeof(float));
+    p->raw_c = take(R * Nc * och * sizeof(float));
+    p->w_c = take(R * Nc * sizeof(float));
+    p->z_f = p->raw_f = nullptr;
     if (Ni > 0) {
-        z_f = take(R * (size_t)Nf * sizeof(float));
-        raw_f = take(R * (size_t)Nf * och * sizeof(float));
-        if (io->z_vals) z_f = io->z_vals;
-        if (io->raw) raw_f = io->raw;
+        p->z_f = take(R * (size_t)Nf * sizeof(float));
+        p->raw_f = take(R * (size_t)Nf * och * sizeof(float));
+        if (io->z_vals) p->z_f = io->z_vals;
+        if (io->raw) p->raw_f = io->raw;
     } else {
-        if (io->z_vals) z_c = io->z_vals;
-        if (io->raw) raw_c = io->raw;
-        if (io->weights) w_c = io->weights;
+        if (io->z_vals) p->z_c = io->z_vals;
+        if (io->raw) p->raw_c = io->raw;
+        if (io->weights) p->w_c = io->weights;
     }
+    return NERF_AMD_OK;
+}
 
+int stage_z(ChunkPlan &p, hipStream_t s) {
+    const nerf_amd_render_io *io = p.io;
     int rc = 0;
     if (io->z_coarse) {
-        if (Ni == 0 && io->z_vals)      // the caller wants z_vals back: they are its own coarse depths
-            rc = hipMemcpyAsync(io->z_vals, io->z_coarse, R * Nc * sizeof(float), hipMemcpyDeviceToDevice, s) == hipSuccess
+        if (p.Ni == 0 && io->z_vals)      // the caller wants z_vals back: they are its own coarse depths
+            rc = hipMemcpyAsync(io->z_vals, io->z_coarse, p.R * p.Nc * sizeof(float), hipMemcpyDeviceToDevice, s) == hipSuccess
                      ? 0 : NERF_AMD_EHIP;
         else
-            z_c = const_cast<float *>(io->z_coarse);
+            p.z_c = const_cast<float *>(io->z_coarse);
     } else {
-        rc = launch_coarse_z(io->rays, io->ray_ch, io->t_vals, cfg->perturb ? io->t_rand : nullptr, R, Nc,
-                             cfg->lindisp, cfg->perturb, z_c, s);
+        rc = launch_coarse_z(io->rays, io->ray_ch, io->t_vals, p.cfg->perturb ? io->t_rand : nullptr, p.R, p.Nc,
+                             p.cfg->lindisp, p.cfg->perturb, p.z_c, s);
     }
-    if (rc) return fail(rc, "coarse_z launch failed");
+    return rc ? fail(rc, "coarse_z launch failed") : NERF_AMD_OK;
+}
 
+int stage_field(const ChunkPlan &p, bool fine_pass, hipStream_t s) {
     MlpArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.rays = io->rays; a.ray_stride = io->ray_ch; a.z_vals = z_c;
-    a.viewdirs = has_vd ? io->rays + 8 : nullptr; a.vd_stride = io->ray_ch;
-    a.P = R * Nc; a.S = Nc; a.out = raw_c;
-    if ((rc = run_field(coarse, a, cfg->precision, s))) return rc;
-
-    const float *rays_d = io->rays + 3;
-    if (Ni == 0) {
-        rc = launch_composite(raw_c, och, z_c, rays_d, io->ray_ch, cfg->use_noise ? io->noise0 : nullptr, R, Nc,
-                              cfg->white_bkgd, io->rgb_map, io->disp_map, io->acc_map, w_c, nullptr, s);
-        return rc ? fail(rc, "composite launch failed") : NERF_AMD_OK;
+    a.rays = p.io->rays; a.ray_stride = p.io->ray_ch;
+    a.viewdirs = p.has_vd ? p.io->rays + 8 : nullptr; a.vd_stride = p.io->ray_ch;
+    if (!fine_pass) {
+        a.z_vals = p.z_c; a.P = p.R * p.Nc; a.S = p.Nc; a.out = p.raw_c;
+        return run_field(p.coarse, a, p.cfg->precision, s);
     }
-    // coarse raw2outputs + z_mid / sample_pdf / sort(cat) in one launch (the weights stay in LDS)
-    rc = launch_composite_resample(raw_c, och, z_c, rays_d, io->ray_ch, cfg->use_noise ? io->noise0 : nullptr, R, Nc, Ni,
-                                   cfg->white_bkgd, io->rgb0, io->disp0, io->acc0, nullptr, io->u, io->t_lin_imp, z_f,
-                                   io->z_std, s);
-    if (rc) return fail(rc, "composite/resample launch failed (N_samples + N_importance must be <= 4096)");
-    a.z_vals = z_f; a.P = R * (int64_t)Nf; a.S = Nf; a.out = raw_f;
-    if ((rc = run_field(fm, a, cfg->precision, s))) return rc;
-    rc = launch_composite(raw_f, och, z_f, rays_d, io->ray_ch, cfg->use_noise ? io->noise1 : nullptr, R, Nf,
-                          cfg->white_bkgd, io->rgb_map, io->disp_map, io->acc_map, io->weights, nullptr, s);
+    a.z_vals = p.z_f; a.P = p.R * (int64_t)p.Nf; a.S = p.Nf; a.out = p.raw_f;
+    return run_field(p.fm, a, p.cfg->precision, s);
+}
+
+CompositeJob final_job(const ChunkPlan &p) {       // compositing of the last pass of a chunk
+    const nerf_amd_render_io *io = p.io;
+    CompositeJob j;
+    std::memset(&j, 0, sizeof(j));
+    const bool two_pass = p.Ni > 0;
+    j.raw = two_pass ? p.raw_f : p.raw_c; j.raw_ch = p.och; j.z = two_pass ? p.z_f : p.z_c;
+    j.rays_d = io->rays + 3; j.rays_d_stride = io->ray_ch;
+    j.noise = p.cfg->use_noise ? (two_pass ? io->noise1 : io->noise0) : nullptr;
+    j.R = p.R; j.S = two_pass ? p.Nf : p.Nc; j.white_bkgd = p.cfg->white_bkgd;
+    j.rgb = io->rgb_map; j.disp = io->disp_map; j.acc = io->acc_map; j.weights = two_pass ? io->weights : p.w_c;
+    return j;
+}
+
+int stage_final(const ChunkPlan &p, hipStream_t s) {
+    const CompositeJob j = final_job(p);
+    int rc = launch_composite(j.raw, j.raw_ch, j.z, j.rays_d, j.rays_d_stride, j.noise, j.R, j.S, j.white_bkgd, j.rgb, j.disp,
+                              j.acc, j.weights, nullptr, s);
     return rc ? fail(rc, "composite launch failed") : NERF_AMD_OK;
+}
+
+// coarse compositing + resampling of `p` (N_importance > 0), together with the final compositing of `prev` if given
+int stage_mid(const ChunkPlan &p, const ChunkPlan *prev, hipStream_t s) {
+    const nerf_amd_render_io *io = p.io;
+    CompositeJob cj;
+    std::memset(&cj, 0, sizeof(cj));
+    cj.raw = p.raw_c; cj.raw_ch = p.och; cj.z = p.z_c; cj.rays_d = io->rays + 3; cj.rays_d_stride = io->ray_ch;
+    cj.noise = p.cfg->use_noise ? io->noise0 : nullptr; cj.R = p.R; cj.S = p.Nc; cj.white_bkgd = p.cfg->white_bkgd;
+    cj.rgb = io->rgb0; cj.disp = io->disp0; cj.acc = io->acc0; cj.weights = nullptr;
+    ResampleJob rj;
+    std::memset(&rj, 0, sizeof(rj));
+    rj.u = io->u; rj.t_lin = io->t_lin_imp; rj.Ni = p.Ni; rj.z_fine = p.z_f; rj.z_std = io->z_std;
+    CompositeJob fj;
+    if (prev) fj = final_job(*prev);
+    int rc = launch_mid_stage(cj, rj, prev ? &fj : nullptr, s);
+    return rc ? fail(rc, "composite/resample launch failed (N_samples + N_importance must be <= 4096)") : NERF_AMD_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int nerf_amd_render_rays(const nerf_amd_render_cfg *cfg, const nerf_amd_model *coarse, const nerf_amd_model *fine,
+                         const nerf_amd_render_io *io, int64_t R, void *stream) {
+    if (R == 0 && cfg && coarse && io) return NERF_AMD_OK;
+    ChunkPlan p;
+    int rc = plan_chunk(cfg, coarse, fine, io, R, &p);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if ((rc = stage_z(p, s)) || (rc = stage_field(p, false, s))) return rc;
+    if (p.Ni == 0) return stage_final(p, s);
+    if ((rc = stage_mid(p, nullptr, s)) || (rc = stage_field(p, true, s))) return rc;
+    return stage_final(p, s);
+}
+
+int nerf_amd_render_chunks(const nerf_amd_render_cfg *cfg, const nerf_amd_model *coarse, const nerf_amd_model *fine,
+                           const nerf_amd_render_io *ios, const int64_t *R, int32_t n_chunks, void *stream) {
+    if (n_chunks < 0 || (n_chunks > 0 && (!ios || !R))) return fail(NERF_AMD_EINVAL, "bad chunk list");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    std::vector<ChunkPlan> plans;
+    plans.reserve(n_chunks);
+    for (int i = 0; i < n_chunks; ++i) {
+        if (R[i] <= 0) continue;
+        ChunkPlan p;
+        int rc = plan_chunk(cfg, coarse, fine, &ios[i], R[i], &p);
+        if (rc) return rc;
+        plans.push_back(p);
+    }
+    const int n = (int)plans.size();
+    // the final compositing of chunk k-1 runs while chunk k is under way: neighbours need their own workspaces
+    for (int i = 0; i + 1 < n; ++i)
+        if (plans[i].io->workspace == plans[i + 1].io->workspace)
+            return fail(NERF_AMD_EINVAL, "consecutive chunks must use distinct workspaces");
+    int rc = 0;
+    for (int k = 0; k < n && !rc; ++k) {
+        ChunkPlan &p = plans[k];
+        if ((rc = stage_z(p, s)) || (rc = stage_field(p, false, s))) break;
+        if (p.Ni == 0) { rc = stage_final(p, s); continue; }
+        // one launch: this chunk's coarse compositing + resampling, and the previous chunk's final compositing
+        if ((rc = stage_mid(p, k > 0 ? &plans[k - 1] : nullptr, s))) break;
+        rc = stage_field(p, true, s);
+    }
+    if (!rc && n > 0 && plans[n - 1].Ni > 0) rc = stage_final(plans[n - 1], s);
+    return rc;
 }
 
 int nerf_amd_set_tuning(int key, int value) {

@@ -106,10 +106,18 @@ int launch_sample_pdf(const float *bins, const float *weights, const float *u, c
                       int64_t R, int n_bins, int n_samples, float *samples, hipStream_t s);
 int launch_resample(const float *z_coarse, const float *weights, const float *u, const float *t_lin,
                     int64_t R, int Nc, int Ni, float *z_fine, float *z_std, hipStream_t s);
-int launch_composite_resample(const float *raw, int raw_ch, const float *z_coarse, const float *rays_d, int rays_d_stride,
-                              const float *noise, int64_t R, int Nc, int Ni, int white_bkgd, float *rgb0, float *disp0,
-                              float *acc0, float *weights, const float *u, const float *t_lin, float *z_fine, float *z_std,
-                              hipStream_t s);
+// one compositing job (raw2outputs over R rays of S samples) and the resampling that may follow it
+struct CompositeJob {
+    const float *raw; int raw_ch; const float *z; const float *rays_d; int rays_d_stride; const float *noise;
+    int64_t R; int S; int white_bkgd;
+    float *rgb, *disp, *acc, *weights;
+};
+struct ResampleJob {
+    const float *u, *t_lin; int Ni, pad_c, pad_s;
+    float *z_fine, *z_std;
+};
+int launch_mid_stage(const CompositeJob &coarse, const ResampleJob &resample, const CompositeJob *final_of_previous_chunk,
+                     hipStream_t s);
 int launch_ndc_rays_bwd(int H, int W, double focal, float near, const float *rays_o, const float *rays_d, const float *g_oo,
                         const float *g_od, int64_t n, float *g_ro, float *g_rd, hipStream_t s);
 int launch_ndc_rays(int H, int W, double focal, float near, const float *rays_o, const float *rays_d, int64_t n,

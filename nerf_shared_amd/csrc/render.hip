@@ -8,6 +8,7 @@
 // Compiled with -ffp-contract=off: the reference's ATen ops round after every
 // multiply and add, so no fused multiply-add may be formed here.
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include <math.h>
 
 #include "kernels.h"
@@ -363,11 +364,6 @@ __global__ __launch_bounds__(64 * RAYS_PER_WG) void sample_pdf_kernel(const floa
     }
 }
 
-int launch_composite_resample(const float *raw, int raw_ch, const float *z_coarse, const float *rays_d, int rays_d_stride,
-                              const float *noise, int64_t R, int Nc, int Ni, int white_bkgd, float *rgb0, float *disp0,
-                              float *acc0, float *weights, const float *u, const float *t_lin, float *z_fine, float *z_std,
-                              hipStream_t s);
-
 int launch_sample_pdf(const float *bins, const float *weights, const float *u, const float *t_lin,
                       int64_t R, int n_bins, int n_samples, float *samples, hipStream_t s) {
     if (R <= 0 || n_samples <= 0) return NERF_AMD_OK;
@@ -490,25 +486,52 @@ __global__ __launch_bounds__(64 * RAYS_PER_WG) void resample_kernel(const float 
                  lds + wv * (2 * (Nc - 1) + pad_c + pad_s), z_fine, z_std, lane);
 }
 
-// The coarse pass's raw2outputs and the resampling in one launch (render_rays between its two field
-// evaluations, render_utils.py:135-148): the weights go from the compositing to the inverse-CDF
-// sampling through LDS; one dependent launch less per chunk.
-__global__ __launch_bounds__(64 * RAYS_PER_WG) void composite_resample_kernel(
-    const float *raw, int raw_ch, const float *z_coarse, const float *rays_d, int rays_d_stride, const float *noise,
-    int64_t R, int Nc, int Ni, int pad_c, int pad_s, int white_bkgd, float *rgb0, float *disp0, float *acc0, float *weights,
-    const float *u, const float *t_lin, float *z_fine, float *z_std) {
+// Between the two field kernels of a chunk, ONE launch does two independent jobs (the weights go from the
+// compositing to the inverse-CDF sampling through LDS): the coarse compositing + resampling of chunk k (blocks [0, cr_blocks)) and the final
+// compositing of chunk k-1 (the remaining blocks) -- one dependent launch less per chunk than running the
+// final compositing on its own.
+__global__ __launch_bounds__(64 * RAYS_PER_WG) void mid_stage_kernel(CompositeJob cj, ResampleJob rj, CompositeJob fj,
+                                                                     int cr_blocks) {
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int64_t r = (int64_t)blockIdx.x * RAYS_PER_WG + wv;
-    const bool live = r < R;
-    if (!live) r = R - 1;
-    float *wl = lds + wv * (Nc + 2 * (Nc - 1) + pad_c + pad_s);
-    composite_ray(raw, raw_ch, z_coarse, rays_d, rays_d_stride, noise, r, Nc, white_bkgd, live ? rgb0 : nullptr,
-                  live ? disp0 : nullptr, live ? acc0 : nullptr, nullptr, lane,
-                  [&](int s, float w) { wl[s] = w; if (live && weights) weights[r * Nc + s] = w; });
-    wave_lds_sync();
-    resample_ray(z_coarse, [&](int i) { return wl[1 + i]; }, u, t_lin, r, live, Nc, Ni, pad_c, pad_s, wl + Nc, z_fine,
-                 z_std, lane);
+    if ((int)blockIdx.x < cr_blocks) {
+        int64_t r = (int64_t)blockIdx.x * RAYS_PER_WG + wv;
+        const bool live = r < cj.R;
+        if (!live) r = cj.R - 1;
+        const int Nc = cj.S;
+        float *wl = lds + wv * (Nc + 2 * (Nc - 1) + rj.pad_c + rj.pad_s);
+        composite_ray(cj.raw, cj.raw_ch, cj.z, cj.rays_d, cj.rays_d_stride, cj.noise, r, Nc, cj.white_bkgd,
+                      live ? cj.rgb : nullptr, live ? cj.disp : nullptr, live ? cj.acc : nullptr, nullptr, lane,
+                      [&](int s, float w) { wl[s] = w; if (live && cj.weights) cj.weights[r * Nc + s] = w; });
+        wave_lds_sync();
+        resample_ray(cj.z, [&](int i) { return wl[1 + i]; }, rj.u, rj.t_lin, r, live, Nc, rj.Ni, rj.pad_c, rj.pad_s,
+                     wl + Nc, rj.z_fine, rj.z_std, lane);
+    } else {
+        const int64_t r = (int64_t)((int)blockIdx.x - cr_blocks) * RAYS_PER_WG + wv;
+        if (r >= fj.R) return;
+        composite_ray(fj.raw, fj.raw_ch, fj.z, fj.rays_d, fj.rays_d_stride, fj.noise, r, fj.S, fj.white_bkgd, fj.rgb, fj.disp,
+                      fj.acc, nullptr, lane, [&](int s, float w) { if (fj.weights) fj.weights[r * fj.S + s] = w; });
+    }
+}
+
+int launch_mid_stage(const CompositeJob &cj, const ResampleJob &rj, const CompositeJob *fj, hipStream_t s) {
+    if (cj.R <= 0) return NERF_AMD_EINVAL;
+    const int Nc = cj.S, Ni = rj.Ni;
+    if (cj.raw_ch < 4 || Nc < 3 || Ni < 1 || Nc + Ni > 4096) return NERF_AMD_EINVAL;
+    ResampleJob r2 = rj;
+    r2.pad_c = 2; r2.pad_s = 2;
+    while (r2.pad_c < Nc) r2.pad_c <<= 1;
+    while (r2.pad_s < Ni) r2.pad_s <<= 1;
+    CompositeJob f2;
+    std::memset(&f2, 0, sizeof(f2));
+    if (fj) f2 = *fj;
+    const int64_t cr_blocks = (cj.R + RAYS_PER_WG - 1) / RAYS_PER_WG;
+    const int64_t f_blocks = (f2.R + RAYS_PER_WG - 1) / RAYS_PER_WG;
+    if (cr_blocks + f_blocks >= ((int64_t)1 << 31)) return NERF_AMD_EINVAL;
+    const size_t lds = (size_t)RAYS_PER_WG * (Nc + 2 * (Nc - 1) + r2.pad_c + r2.pad_s) * sizeof(float);
+    hipLaunchKernelGGL(mid_stage_kernel, dim3((unsigned)(cr_blocks + f_blocks)), dim3(64 * RAYS_PER_WG), lds, s, cj, r2, f2,
+                       (int)cr_blocks);
+    return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
 
 int launch_resample(const float *z_coarse, const float *weights, const float *u, const float *t_lin,
@@ -728,23 +751,6 @@ int launch_make_rays(int H, int W, const double *K4, const float *c2w, const flo
     g.sx = (float)(-1.0 / ((double)W / (2.0 * K4[0])));
     g.sy = (float)(-1.0 / ((double)H / (2.0 * K4[0])));
     hipLaunchKernelGGL(make_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, pix0, n, rays_out);
-    return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
-}
-
-int launch_composite_resample(const float *raw, int raw_ch, const float *z_coarse, const float *rays_d, int rays_d_stride,
-                              const float *noise, int64_t R, int Nc, int Ni, int white_bkgd, float *rgb0, float *disp0,
-                              float *acc0, float *weights, const float *u, const float *t_lin, float *z_fine, float *z_std,
-                              hipStream_t s) {
-    if (R <= 0) return NERF_AMD_OK;
-    if (raw_ch < 4 || Nc < 3 || Ni < 1 || Nc + Ni > 4096) return NERF_AMD_EINVAL;
-    int pad_c = 2, pad_s = 2;
-    while (pad_c < Nc) pad_c <<= 1;
-    while (pad_s < Ni) pad_s <<= 1;
-    const int64_t blocks = (R + RAYS_PER_WG - 1) / RAYS_PER_WG;
-    const size_t lds = (size_t)RAYS_PER_WG * (Nc + 2 * (Nc - 1) + pad_c + pad_s) * sizeof(float);
-    hipLaunchKernelGGL(composite_resample_kernel, dim3((unsigned)blocks), dim3(64 * RAYS_PER_WG), lds, s, raw, raw_ch,
-                       z_coarse, rays_d, rays_d_stride, noise, R, Nc, Ni, pad_c, pad_s, white_bkgd, rgb0, disp0, acc0, weights,
-                       u, t_lin, z_fine, z_std);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
 

@@ -14,6 +14,7 @@ edges of the hot path:
     DEBUG is set -- it never changes outputs and costs a device sync per key;
   * autograd reaches the models' parameters and the rays (standard model, bf16 mode).
 """
+import ctypes
 import os
 
 import numpy as np
@@ -158,25 +159,25 @@ class Renderer(torch.nn.Module):
             raise TypeError("%s must be a nerf_shared_amd.nerf.NeRF (got %s); load a reference model's "
                             "state_dict into one" % (name, type(m).__name__))
 
-    def _launch(self, rays, coarse_model, fine_model, outs, retraw, retweights, pytest, slot=0, z_pre=None):
-        """Enqueue render_rays for contiguous fp32 rays [R, 8|11]; writes into the
-        tensors of ``outs`` (rows [0, R)).  z_pre: coarse depths [R, N_samples] made beforehand (render_batch
-        computes them for all chunks in one launch)."""
-        R, dev = rays.shape[0], rays.device
-        Nc, Ni = int(self.N_samples), int(self.N_importance)
-        Nf = Nc + Ni
+    def _handles(self, dev, coarse_model, fine_model):
+        """Library handles (re-packed if the weights changed), render cfg and output width."""
         self._check_model(coarse_model, "coarse_model")
         if fine_model is not None:
             self._check_model(fine_model, "fine_model")
         hc = coarse_model._model_handle(dev)
-        hf = fine_model._model_handle(dev) if (fine_model is not None and Ni > 0) else None
+        hf = fine_model._model_handle(dev) if (fine_model is not None and int(self.N_importance) > 0) else None
         prec = coarse_model._precision_code()
         if hf is not None and fine_model._precision_code() != prec:
             prec = _lib.PREC_FP32
-        cfg = self._cfg(prec)
-        out_ch = lib.nerf_amd_model_out_ch(hc)
+        return hc, hf, self._cfg(prec), lib.nerf_amd_model_out_ch(hc)
 
-        # --- random draws, in the reference's order and shapes
+    def _chunk_io(self, rays, cfg, out_ch, outs, pytest, slot, z_pre=None):
+        """nerf_amd_render_io of one render_rays call on contiguous fp32 rays [R, 8|11] writing into the tensors
+        of ``outs`` (rows [0, R)): random draws in the reference's order and shapes, workspace `slot`.
+        z_pre: coarse depths [R, N_samples] made beforehand.  Returns (io, tensors to keep alive)."""
+        R, dev = rays.shape[0], rays.device
+        Nc, Ni = int(self.N_samples), int(self.N_importance)
+        Nf = Nc + Ni
         t_rand = noise0 = noise1 = u = None
         if self.perturb > 0. and z_pre is None:
             t_rand = _pytest_uniform([R, Nc], dev) if pytest else torch.rand([R, Nc], device=dev)
@@ -210,10 +211,37 @@ class Renderer(torch.nn.Module):
         nbytes = lib.nerf_amd_render_rays_workspace(cfg, R, out_ch)
         ws = _Workspace.get(dev, nbytes, slot)
         io.workspace, io.workspace_bytes = ws.data_ptr(), ws.numel()
+        return io, (rays, t_rand, noise0, noise1, u, z_pre, ws)
+
+    def _launch(self, rays, coarse_model, fine_model, outs, retraw, retweights, pytest, slot=0, z_pre=None):
+        """Enqueue render_rays for contiguous fp32 rays [R, 8|11]; writes into the
+        tensors of ``outs`` (rows [0, R))."""
+        dev = rays.device
+        hc, hf, cfg, out_ch = self._handles(dev, coarse_model, fine_model)
+        io, keep = self._chunk_io(rays, cfg, out_ch, outs, pytest, slot, z_pre)
         with torch.cuda.device(dev):
-            _lib.check(lib.nerf_amd_render_rays(cfg, hc, hf, io, R, _lib.stream_of(dev)), "nerf_amd_render_rays")
+            _lib.check(lib.nerf_amd_render_rays(cfg, hc, hf, io, rays.shape[0], _lib.stream_of(dev)), "nerf_amd_render_rays")
         # keep the draws alive until the stream has consumed them (caching allocator is stream-ordered)
-        return t_rand, noise0, noise1, u
+        return keep
+
+    def _launch_chunks(self, rays, starts, chunk, coarse_model, fine_model, full, z_all):
+        """render_batch's chunk loop as one library call (nerf_amd_render_chunks): per-chunk draws and output
+        rows exactly as _launch makes them, two workspaces used alternately."""
+        dev = rays.device
+        hc, hf, cfg, out_ch = self._handles(dev, coarse_model, fine_model)
+        n = len(starts)
+        ios = (_lib.RenderIO * n)()
+        counts = (ctypes.c_int64 * n)()
+        keep = []
+        for j, i in enumerate(starts):
+            part = {k: v[i:i + chunk] for k, v in full.items()}
+            r = rays[i:i + chunk]
+            ios[j], alive = self._chunk_io(r, cfg, out_ch, part, False, j % 2, None if z_all is None else z_all[i:i + chunk])
+            counts[j] = r.shape[0]
+            keep.append(alive)
+        with torch.cuda.device(dev):
+            _lib.check(lib.nerf_amd_render_chunks(cfg, hc, hf, ios, counts, n, _lib.stream_of(dev)), "nerf_amd_render_chunks")
+        return keep
 
     def _draws(self, R, dev, pytest):
         """Random draws of one render_rays call in the reference's order and shapes."""
@@ -325,6 +353,7 @@ class Renderer(torch.nn.Module):
                     print(f"! [Numerical Error] {k} contains nan or inf.")
         return ret
 
+    fuse_chunk_launches = True    # render_batch: one library call for all chunks (three dependent launches per chunk)
     overlap_chunks = False    # opt-in: two-stream chunk pipeline of render_batch (+~3 % at 4096-ray chunks)
 
     def render_batch(self, coarse_model, fine_model, rays_flat, chunk=1024 * 32, retraw=False):
@@ -361,6 +390,9 @@ class Renderer(torch.nn.Module):
                     _lib.check(lib.nerf_amd_coarse_z(rays.data_ptr(), rays.shape[1], _linspace01(Nc, dev).data_ptr(),
                                                      _lib.ptr(t_rand), N, Nc, int(bool(self.lindisp)), int(self.perturb > 0.),
                                                      z_all.data_ptr(), _lib.stream_of(dev)), "nerf_amd_coarse_z")
+            if len(starts) > 1 and self.fuse_chunk_launches:
+                self._launch_chunks(rays, starts, chunk, coarse_model, fine_model, full, z_all)
+                return full
             for i in starts:
                 part = {k: v[i:i + chunk] for k, v in full.items()}
                 self._launch(rays[i:i + chunk], coarse_model, fine_model, part, retraw, False, False,

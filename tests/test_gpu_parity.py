@@ -638,6 +638,26 @@ def test_staticcam_overlap_and_batch_poses(dev, tmp_path):
     rgb1 = r.render(H, W, K, coarse_gpu, fine_gpu, chunk=100, c2w=c2w, c2w_staticcam=c2w_s, retraw=False)[0]
     close(rgb2, rgb1, atol=0)
     # batch of poses -> frames on disk
+    # render_batch as one library call (nerf_amd_render_chunks: final compositing of chunk k-1 inside chunk k's
+    # compositing/resampling launch; 6 chunks here, the last one ragged) against one render_rays call per
+    # chunk: bit-identical, every output, deterministic and with random draws
+    assert render_utils.Renderer.fuse_chunk_launches
+    for rcfg, seed in ((cfg, None), (dict(cfg, perturb=1.0, raw_noise_std=1.0), 3)):
+        rr = render_utils.Renderer(**rcfg)
+        outs = []
+        for fused in (True, False):
+            render_utils.Renderer.fuse_chunk_launches = fused
+            try:
+                if seed is not None:
+                    torch.manual_seed(seed)
+                outs.append(rr.render(H, W, K, coarse_gpu, fine_gpu, chunk=100, c2w=c2w, retraw=True))
+            finally:
+                render_utils.Renderer.fuse_chunk_launches = True
+        for a, b in zip(outs[0][:3], outs[1][:3]):
+            assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
+        assert sorted(outs[0][3]) == sorted(outs[1][3])
+        for k in outs[0][3]:
+            assert torch.equal(torch.nan_to_num(outs[0][3][k]), torch.nan_to_num(outs[1][3][k])), k
     # batch of poses -> quantised on the GPU, PNG frames on disk (asynchronous and synchronous writers)
     from nerf_shared_amd import image_io, utils as amd_utils
     want8 = amd_utils.to8b(plain.cpu().numpy())                 # the reference's numpy to8b
