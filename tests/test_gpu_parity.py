@@ -642,7 +642,7 @@ def test_staticcam_overlap_and_batch_poses(dev, tmp_path):
     # compositing/resampling launch; 6 chunks here, the last one ragged) against one render_rays call per
     # chunk: bit-identical, every output, deterministic and with random draws
     assert render_utils.Renderer.fuse_chunk_launches
-    for rcfg, seed in ((cfg, None), (dict(cfg, perturb=1.0, raw_noise_std=1.0), 3)):
+    for rcfg, seed in ((cfg, None), (dict(cfg, perturb=1.0, raw_noise_std=1.0), 3), (dict(cfg, N_importance=0), None)):
         rr = render_utils.Renderer(**rcfg)
         outs = []
         for fused in (True, False):
