@@ -154,14 +154,16 @@ class _FieldTrainFn(torch.autograd.Function):
 
 # The packed device copy of a model's weights is refreshed when a parameter's (data_ptr, _version)
 # changes.  Optimizers that update through fused multi-tensor kernels (torch.optim.Adam(fused=True))
-# do not bump `_version`, so every optimizer step also marks all live models stale.  Writes through
+# do not bump `_version`, so every optimizer step also marks the models it updated stale.  Writes through
 # `param.data` are invisible to both: call `model.weights_changed()` after them.
 _LIVE_MODELS = weakref.WeakSet()
 
 
 def _after_optimizer_step(optimizer, args, kwargs):
+    stepped = {id(p) for g in optimizer.param_groups for p in g["params"]}
     for m in list(_LIVE_MODELS):
-        m._packed_key = None
+        if any(id(p) in stepped for p in m.parameters()):
+            m._packed_key = None
 
 
 from torch.optim import optimizer as _torch_optimizer  # noqa: E402

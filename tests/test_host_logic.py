@@ -257,11 +257,16 @@ def test_packed_weights_go_stale_after_optimizer_steps_and_copies_get_their_own_
     m = nerf.NeRF(D=8, W=256, output_ch=5, skips=[4], use_viewdirs=True)
     other = nerf.NeRF(D=8, W=256, output_ch=5, skips=[4], use_viewdirs=True)
     m._packed_key, other._packed_key = "packed", "packed"
-    lin = torch.nn.Linear(2, 2)                       # an unrelated optimizer: still invalidates (cheap, always safe)
-    opt = torch.optim.SGD(lin.parameters(), lr=0.1)
+    lin = torch.nn.Linear(2, 2)                       # an optimizer over unrelated parameters leaves the models alone
+    unrelated = torch.optim.SGD(lin.parameters(), lr=0.1)
     lin.weight.grad, lin.bias.grad = torch.zeros_like(lin.weight), torch.zeros_like(lin.bias)
+    unrelated.step()
+    assert m._packed_key == "packed" and other._packed_key == "packed"
+    opt = torch.optim.SGD(m.parameters(), lr=0.0)
+    for p_ in m.parameters():
+        p_.grad = torch.zeros_like(p_)
     opt.step()
-    assert m._packed_key is None and other._packed_key is None
+    assert m._packed_key is None and other._packed_key == "packed"
     m._packed_key = "packed"
     m.weights_changed()
     assert m._packed_key is None
@@ -269,7 +274,10 @@ def test_packed_weights_go_stale_after_optimizer_steps_and_copies_get_their_own_
     c = copy.deepcopy(m)
     assert c._handle is None and c._packed_key is None and m._handle == "library handle"
     c._packed_key = "packed"
-    opt.step()
+    copt = torch.optim.SGD(c.parameters(), lr=0.0)
+    for p_ in c.parameters():
+        p_.grad = torch.zeros_like(p_)
+    copt.step()
     assert c._packed_key is None                      # the copy is tracked too
     m._handle = None
     assert torch.equal(c.pts_linears[3].weight, m.pts_linears[3].weight)
