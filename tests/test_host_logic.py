@@ -172,6 +172,12 @@ for n in (10, 11, 4096):
         ok = ok and got is not None and torch.equal(got, full)
     else:
         ok = ok and got is None
+    # quantised colours (the image output stage gathers uint8 rows): same collective, 1-byte elements
+    full8 = (torch.arange(n * 3) %% 251).to(torch.uint8).reshape(n, 3)
+    got8 = nd.gather_rows(full8[lo:hi].clone(), n, 0)
+    ok = ok and ((got8 is not None and got8.dtype == torch.uint8 and torch.equal(got8, full8)) if rank == 0 else got8 is None)
+    # round-robin frame assignment of render_poses_sharded
+    ok = ok and list(range(rank, n, world)) == [i for i in range(n) if i %% world == rank]
 dist.barrier()
 dist.destroy_process_group()
 sys.exit(0 if ok else 1)
