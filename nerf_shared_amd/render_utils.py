@@ -529,7 +529,14 @@ class Renderer(torch.nn.Module):
                 import imageio
                 imageio.mimwrite(os.path.join(save_directory, 'video.mp4'), utils.to8b(np.stack(rgbs)), fps=30, quality=8)
             except ImportError:
-                print("render_from_batch_poses: imageio is not installed, video.mp4 skipped (frames are on disk)")
+                try:                         # no imageio/ffmpeg here: an animated GIF from the uint8 frames instead
+                    from PIL import Image
+                    imgs = [Image.fromarray(f) for f in frames]
+                    imgs[0].save(os.path.join(save_directory, 'video.gif'), save_all=True, append_images=imgs[1:],
+                                 duration=33, loop=0)
+                    print("render_from_batch_poses: imageio is not installed, wrote video.gif instead of video.mp4")
+                except ImportError:
+                    print("render_from_batch_poses: neither imageio nor Pillow is installed, video skipped (frames are on disk)")
         if tb_writer is not None:
             tb_writer.add_images('Test/Images', torch.tensor(utils.to8b(np.stack(rgbs))), dataformats="NHWC")
         return frames

@@ -669,6 +669,17 @@ def test_staticcam_overlap_and_batch_poses(dev, tmp_path):
         assert np.array_equal(out[1], want8)
         assert np.array_equal(image_io.read_image(str(d / "001.png")), want8)
         assert np.array_equal(image_io.decode_png(open(d / "001.png", "rb").read()), want8)
+    # b_combine_as_video without imageio: an animated GIF of the same frames
+    d = tmp_path / "video"
+    r.render_from_batch_poses(H, W, K, 4096, [c2w, c2w_s], coarse_gpu, fine_gpu, False, str(d), b_combine_as_video=True)
+    try:
+        import imageio  # noqa: F401
+        assert os.path.exists(d / "video.mp4")
+    except ImportError:
+        pytest.importorskip("PIL")
+        from PIL import Image
+        with Image.open(d / "video.gif") as g:
+            assert g.n_frames == 2 and g.size == (W, H)
 
 
 def test_to8b_matches_numpy_bit_for_bit(dev):
