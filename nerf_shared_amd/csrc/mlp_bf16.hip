@@ -89,11 +89,16 @@ __device__ __forceinline__ void encode(float x0, float x1, float x2, int h, bf16
     constexpr float INV2PI_LO = (float)(0.15915494309189535 - (double)INV2PI_HI);
     float x[3] = {x0, x1, x2};
     const float phase = h ? 0.25f : 0.0f;
+    // The reduction runs on |x| (v_fract of a negative number rounds, and that ulp would be doubled with every
+    // frequency); sin is odd, cos even, so the sin family gets x's sign bit back at the end.
     float ra[3], tl[3];
+    unsigned sgn[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        float th = x[c] * INV2PI_HI;
-        tl[c] = __builtin_fmaf(x[c], INV2PI_HI, -th) + x[c] * INV2PI_LO;
+        const float ax = __builtin_fabsf(x[c]);
+        sgn[c] = h ? 0u : (__builtin_bit_cast(unsigned, x[c]) & 0x80000000u);
+        float th = ax * INV2PI_HI;
+        tl[c] = __builtin_fmaf(ax, INV2PI_HI, -th) + ax * INV2PI_LO;
         ra[c] = __builtin_amdgcn_fractf(th);
     }
     float vals[8 * K];
@@ -103,7 +108,7 @@ __device__ __forceinline__ void encode(float x0, float x1, float x2, int h, bf16
     for (int f = 0; f < L; ++f) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            vals[3 * f + c] = __builtin_amdgcn_sinf(ra[c] + (tl[c] + phase));
+            vals[3 * f + c] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, __builtin_amdgcn_sinf(ra[c] + (tl[c] + phase))) ^ sgn[c]);
             ra[c] = __builtin_amdgcn_fractf(ra[c] * 2.0f);   // exact
             tl[c] *= 2.0f;                                   // exact
         }

@@ -117,11 +117,17 @@ __device__ __forceinline__ void encode16(float x0, float x1, float x2, int h, in
     const float x[3] = {x0, x1, x2};
     const float phase = h ? 0.25f : 0.0f;
     const float s0 = b ? 2.0f : 1.0f;
+    // The reduction runs on |x|: v_fract of a negative number is x - floor(x) *rounded*, and that ulp would be
+    // quadrupled with every step (3e-3 at 2^14, a bf16 quantum).  sin is odd and cos even, so the sin family
+    // (h == 0) gets x's sign bit back at the end.
     float ra[3], tl[3];
+    unsigned sgn[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float th = x[c] * INV2PI_HI;
-        tl[c] = (__builtin_fmaf(x[c], INV2PI_HI, -th) + x[c] * INV2PI_LO) * s0;
+        const float ax = __builtin_fabsf(x[c]);
+        sgn[c] = h ? 0u : (__builtin_bit_cast(unsigned, x[c]) & 0x80000000u);
+        const float th = ax * INV2PI_HI;
+        tl[c] = (__builtin_fmaf(ax, INV2PI_HI, -th) + ax * INV2PI_LO) * s0;
         ra[c] = __builtin_amdgcn_fractf(th * s0);
     }
     float vals[CAP];
@@ -131,7 +137,8 @@ __device__ __forceinline__ void encode16(float x0, float x1, float x2, int h, in
     for (int s = 0; s < NSTEP; ++s) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            if (3 * s + c < CAP) vals[3 * s + c] = __builtin_amdgcn_sinf(ra[c] + (tl[c] + phase));
+            if (3 * s + c < CAP)
+                vals[3 * s + c] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, __builtin_amdgcn_sinf(ra[c] + (tl[c] + phase))) ^ sgn[c]);
             ra[c] = __builtin_amdgcn_fractf(ra[c] * 4.0f);
             tl[c] *= 4.0f;
         }

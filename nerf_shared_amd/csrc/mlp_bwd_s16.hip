@@ -127,11 +127,16 @@ __device__ __forceinline__ void encode16_bwd(float x0, float x1, float x2, int h
     const float phase = (h ? 0.25f : 0.0f) + 0.25f;          // cos(u) = sin(u + 1/4 turn): derivative of the forward value
     const float s0 = b ? 2.0f : 1.0f;
     const int n_mine = b ? N_ODD : N_EVEN;
+    // reduction on |x| as in the forward (encode16): d/dx sin(2^f x) = 2^f cos(.) is even in x, d/dx cos(2^f x)
+    // = -2^f sin(.) is odd, so here it is the cos family (h == 1) that takes x's sign bit
     float ra[3], tl[3];
+    unsigned sgn[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float th = x[c] * INV2PI_HI;
-        tl[c] = (__builtin_fmaf(x[c], INV2PI_HI, -th) + x[c] * INV2PI_LO) * s0;
+        const float ax = __builtin_fabsf(x[c]);
+        sgn[c] = h ? (__builtin_bit_cast(unsigned, x[c]) & 0x80000000u) : 0u;
+        const float th = ax * INV2PI_HI;
+        tl[c] = (__builtin_fmaf(ax, INV2PI_HI, -th) + ax * INV2PI_LO) * s0;
         ra[c] = __builtin_amdgcn_fractf(th * s0);
     }
     float scale = s0;                                         // 2^f of the current step
@@ -140,7 +145,7 @@ __device__ __forceinline__ void encode16_bwd(float x0, float x1, float x2, int h
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             if (3 * s + c < CAP) {
-                const float dv = __builtin_amdgcn_sinf(ra[c] + (tl[c] + phase)) * scale;
+                const float dv = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, __builtin_amdgcn_sinf(ra[c] + (tl[c] + phase))) ^ sgn[c]) * scale;
                 gx[c] += (3 * s + c < n_mine) ? g[3 * s + c] * dv : 0.0f;
             }
             ra[c] = __builtin_amdgcn_fractf(ra[c] * 4.0f);
