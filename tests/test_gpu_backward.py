@@ -619,3 +619,64 @@ def test_ndc_rays_backward_and_ray_gradients_through_the_ndc_render(dev, monkeyp
     eo, ed = rel_err(o_g.grad, o_c.grad), rel_err(d_g.grad, d_c.grad)
     print("ndc render: rays_o grad err %.4f, rays_d grad err %.4f" % (eo, ed))
     assert float(o_c.grad.norm()) > 0 and eo < 8e-2 and ed < 8e-2
+
+
+@pytest.mark.parametrize("arch", [VD, VD15], ids=["multires10_4", "multires15_6"])
+def test_fused_kernel_encodings_match_the_reference_embedder(dev, arch):
+    """The positional encodings the fused bf16 kernel generates in registers (v_fract / v_sin_f32 on an exactly
+    reduced argument), read back from the training forward's saved activations (slot-major bf16 rows at the
+    start of its workspace), against bf16(Embedder.embed) of the reference arithmetic: equal bit for bit except
+    where a ~1e-6 difference crosses a bf16 rounding boundary -- at every frequency, for negative coordinates
+    too (reducing x instead of |x| made 2^14 x off by a bf16 quantum for x < 0)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pack_layout", os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                                                              "test_pack_layout.py"))
+    pl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pl)
+    Lx, Ld = arch["multires"], arch["multires_views"]
+    KE, KD = pl.gen16_ksteps(Lx), pl.gen16_ksteps(Ld)
+    rng = np.random.default_rng(31)
+    R, S = 97, 5                                            # 485 points: two tiles, the second ragged
+    pts = rng.uniform(-4, 4, size=(R, S, 3)).astype(np.float32)
+    pts[0, 0] = [0.0, -0.0, 7.75]
+    pts[1, 0] = [-7.9, 3.1415927, -1e-3]
+    vd = rng.normal(size=(R, 3)).astype(np.float32)
+    vd /= np.linalg.norm(vd, axis=-1, keepdims=True)
+    m, _ = _models(dev, 0, 1.0, arch)
+    out = m(torch.from_numpy(pts).to(dev), torch.from_numpy(vd).to(dev))
+    fn = out.grad_fn
+    while not hasattr(fn, "ws"):
+        fn = fn.next_functions[0][0]
+    ws = fn.ws.cpu().numpy()
+    P = R * S
+    P_pad = (P + 255) // 256 * 256
+
+    def rows(offset, K):
+        n = P_pad * 32 * K
+        bits = ws[offset:offset + 2 * n].view(np.uint16).reshape(P_pad, 32 * K)[:P]
+        return (bits.astype(np.uint32) << 16).view(np.float32)
+
+    def check(got, x, L, K, what):
+        want = O.embed(torch.from_numpy(x), L).to(torch.bfloat16).to(torch.float32).numpy()      # [P, 3 + 6L]
+        seen = np.zeros(want.shape[1], bool)
+        bad = total = 0
+        for ks in range(K):
+            for q in range(4):
+                for j in range(8):
+                    col = pl.gen16_col(ks, q, j, L)
+                    slot = got[:, 32 * ks + 8 * q + j]
+                    if col < 0:
+                        assert not slot.any(), (what, ks, q, j)
+                        continue
+                    seen[col] = True
+                    d = np.abs(slot - want[:, col])
+                    assert d.max() <= 2.0 ** -7, (what, col, float(d.max()))       # at most one bf16 ulp of a value <= 1..8
+                    bad += int((d != 0).sum())
+                    total += d.size
+        assert seen.all(), what
+        print("%s: %d of %d encoded values differ from bf16(reference) (%.3f %%)" % (what, bad, total, 100.0 * bad / total))
+        assert bad <= 0.001 * total, (what, bad, total)
+
+    off_d = (P_pad * 32 * KE * 2 + 255) // 256 * 256
+    check(rows(0, KE), pts.reshape(-1, 3), Lx, KE, "xyz L=%d" % Lx)
+    check(rows(off_d, KD), np.repeat(vd, S, axis=0), Ld, KD, "dirs L=%d" % Ld)
