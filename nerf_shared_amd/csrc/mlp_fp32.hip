@@ -8,14 +8,12 @@
 // chain) and the fallback for architectures the fused bf16 kernel does not
 // cover; it is still MFMA code, just at the fp32 rate (1/16 of bf16).
 //
-// One workgroup (4 waves) evaluates 32 points.  Activations live in LDS as
-// [feature row][32 points] fp32 in two ping-pong buffers whose rows are
+// The network is evaluated transposed (weights = A operand, points = B operand, v_mfma_f32_32x32x2_f32);
+// LDS rows are features:
 //   [0, input_ch)                    encoded xyz      (kept for the skip concat)
 //   [input_ch, input_ch+W)           hidden
 //   [input_ch+W, +input_ch_views)    encoded view dir (kept for the view concat)
-// so both torch.cat calls of the reference (nerf.py:117-118, :123) are just a
-// different first row.  The network is evaluated transposed (weights = A
-// operand, points = B operand); wave w computes output tiles w, w+4, ...
+// so both torch.cat calls of the reference (nerf.py:117-118, :123) are just a different first row.
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -54,30 +52,36 @@ int launch_embed(const float *x, int64_t n, int multires, float *out, hipStream_
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
 
-__global__ __launch_bounds__(256) void mlp_f32_kernel(MlpArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+// One workgroup (8 waves) evaluates 64 points = two 32-point column halves.  Activations live in ONE LDS
+// buffer [feature row][64 points] fp32 and layers update it in place: every wave first computes all of its
+// output tiles of a layer into registers (tile t belongs to wave t % 8; both column halves share the weight
+// fragment loaded from L2, which is what bounds this kernel), a barrier ends the reads, the tiles are
+// written over the layer's input rows, a second barrier publishes them.  The encoded xyz and view rows are
+// never overwritten, so both concats of the reference are a different first row.
+constexpr int F32_MAX_TILES_PER_WAVE = 4;            // n_out <= 8 * 4 * 32 = 1024
+
+__global__ __launch_bounds__(512) void mlp_f32_kernel(MlpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float act[];
     const int rows = a.lds_rows;
-    float *buf[2] = {lds, lds + rows * 32};
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pt = lane & 31, h = lane >> 5;
 
-    for (int i = tid; i < 2 * rows * 32; i += 256) lds[i] = 0.0f;
+    for (int i = tid; i < rows * 64; i += 512) act[i] = 0.0f;
     __syncthreads();
 
-    // ---- encode this tile's 32 points into both buffers
-    const int64_t p0 = (int64_t)blockIdx.x * 32;
-    for (int i = tid; i < (a.input_ch + a.input_ch_views) * 32; i += 256) {
-        const int row = i >> 5, q = i & 31;
+    // ---- encode this tile's 64 points
+    const int64_t p0 = (int64_t)blockIdx.x * 64;
+    const int n_in_rows = a.input_ch + a.input_ch_views;
+    for (int i = tid; i < n_in_rows * 64; i += 512) {
+        const int row = i >> 6, q = i & 63;
         int64_t p = p0 + q;
         if (p >= a.P) p = a.P - 1;
         const int64_t ray = (int64_t)((uint32_t)p / (uint32_t)a.S);
+        const int dst = row < a.input_ch ? row : a.input_ch + a.W + (row - a.input_ch);
         float v[3];
         float val;
         if (a.embedded) {
-            val = a.embedded[p * (a.input_ch + a.input_ch_views) + row];
-            const int dst = row < a.input_ch ? row : a.input_ch + a.W + (row - a.input_ch);
-            buf[0][dst * 32 + q] = val;
-            buf[1][dst * 32 + q] = val;
+            val = a.embedded[p * n_in_rows + row];
         } else if (row < a.input_ch) {
             if (a.pts) {
                 v[0] = a.pts[3 * p]; v[1] = a.pts[3 * p + 1]; v[2] = a.pts[3 * p + 2];
@@ -89,50 +93,60 @@ __global__ __launch_bounds__(256) void mlp_f32_kernel(MlpArgs a) {
                 v[2] = __fadd_rn(r[2], __fmul_rn(r[5], z));
             }
             val = embed_feature(v, row, a.i_embed);
-            buf[0][row * 32 + q] = val;
-            buf[1][row * 32 + q] = val;
         } else {
             const float *d = a.viewdirs + ray * a.vd_stride;
             v[0] = d[0]; v[1] = d[1]; v[2] = d[2];
             val = embed_feature(v, row - a.input_ch, a.i_embed);
-            const int dst = a.input_ch + a.W + (row - a.input_ch);
-            buf[0][dst * 32 + q] = val;
-            buf[1][dst * 32 + q] = val;
         }
+        act[dst * 64 + q] = val;
     }
     __syncthreads();
 
-    const int64_t p = p0 + pt;
-    const bool valid = p < a.P;
-
     for (int li = 0; li < a.n_layers; ++li) {
         const LayerF32 L = a.layers[li];
-        const float *in = buf[L.in_buf] + L.in_row * 32 + pt;
-        float *outb = buf[L.in_buf ^ 1];
+        const float *in = act + L.in_row * 64 + pt;
         const int tiles = (L.n_out + 31) >> 5, groups = (L.n_in + 7) >> 3;
-        for (int t = wave; t < tiles; t += 4) {
-            f32x16 acc;
+        f32x16 acc[F32_MAX_TILES_PER_WAVE][2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = a.bias_f32[L.bias_off + 32 * t + acc_row(r, h)];
-            const f32x4 *wf = reinterpret_cast<const f32x4 *>(a.stream_f32 + L.frag_off + (int64_t)t * groups * 256) + lane;
-#pragma unroll 4
-            for (int g = 0; g < groups; ++g) {
-                const f32x4 w = wf[(int64_t)g * 64];
-                const float *bp = in + (8 * g + h) * 32;
-                const float b0 = bp[0], b1 = bp[64], b2 = bp[128], b3 = bp[192];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], b0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1], b1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2], b2, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[3], b3, acc, 0, 0, 0);
+        for (int u = 0; u < F32_MAX_TILES_PER_WAVE; ++u) {
+            const int t = wave + 8 * u;
+            if (t < tiles) {                                   // wave-uniform
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float bias = a.bias_f32[L.bias_off + 32 * t + acc_row(r, h)];
+                    acc[u][0][r] = bias; acc[u][1][r] = bias;
+                }
+                const f32x4 *wf = reinterpret_cast<const f32x4 *>(a.stream_f32 + L.frag_off + (int64_t)t * groups * 256) + lane;
+#pragma unroll 2
+                for (int g = 0; g < groups; ++g) {
+                    const f32x4 w = wf[(int64_t)g * 64];
+                    const float *bp = in + (8 * g + h) * 64;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {              // rows 8g + h + 2k: the k-th pair of this 8-row group
+                        acc[u][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[k], bp[128 * k], acc[u][0], 0, 0, 0);
+                        acc[u][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[k], bp[128 * k + 32], acc[u][1], 0, 0, 0);
+                    }
+                }
             }
+        }
+        __syncthreads();                                       // every wave has read this layer's inputs
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = 32 * t + acc_row(r, h);
-                float v = acc[r];
-                if (L.relu) v = fmaxf(v, 0.0f);
-                if (row < L.n_out) {
-                    if (L.out_row >= 0) outb[(L.out_row + row) * 32 + pt] = v;
-                    else if (valid) a.out[(int64_t)a.out_ch * p + L.out_col + row] = v;
+        for (int u = 0; u < F32_MAX_TILES_PER_WAVE; ++u) {
+            const int t = wave + 8 * u;
+            if (t < tiles) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int64_t p = p0 + 32 * c + pt;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = 32 * t + acc_row(r, h);
+                        float v = acc[u][c][r];
+                        if (L.relu) v = fmaxf(v, 0.0f);
+                        if (row < L.n_out) {
+                            if (L.out_row >= 0) act[(L.out_row + row) * 64 + 32 * c + pt] = v;
+                            else if (p < a.P) a.out[(int64_t)a.out_ch * p + L.out_col + row] = v;
+                        }
+                    }
                 }
             }
         }
@@ -143,8 +157,9 @@ __global__ __launch_bounds__(256) void mlp_f32_kernel(MlpArgs a) {
 int launch_mlp_f32(const MlpArgs &a, hipStream_t s) {
     if (a.P <= 0) return NERF_AMD_OK;
     if (a.P >= (int64_t)1 << 31) return NERF_AMD_EINVAL;
-    const size_t lds = (size_t)2 * a.lds_rows * 32 * sizeof(float);
+    const size_t lds = (size_t)a.lds_rows * 64 * sizeof(float);
     if (lds > 160 * 1024) return NERF_AMD_EUNSUPPORTED;
+    if (a.W > 8 * F32_MAX_TILES_PER_WAVE * 32) return NERF_AMD_EUNSUPPORTED;
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_f32_kernel),
@@ -152,8 +167,8 @@ int launch_mlp_f32(const MlpArgs &a, hipStream_t s) {
             return NERF_AMD_EHIP;
         attr_lds = lds;
     }
-    const int64_t blocks = (a.P + 31) / 32;
-    hipLaunchKernelGGL(mlp_f32_kernel, dim3((unsigned)blocks), dim3(256), lds, s, a);
+    const int64_t blocks = (a.P + 63) / 64;
+    hipLaunchKernelGGL(mlp_f32_kernel, dim3((unsigned)blocks), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
 
