@@ -44,8 +44,13 @@ def main():
     ap.add_argument("--chunk", type=int, default=32768)
     ap.add_argument("--max-test-views", type=int, default=8)
     ap.add_argument("--write-demo-scene", action="store_true", help="write the analytic sphere scene to --datadir first")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--ckpt", default=None, help="reference-format .tar to start from (with --iters 0: render only)")
+    ap.add_argument("--render-path", type=int, default=0, help="also render this many poses of the scene's render path")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
+    torch.manual_seed(a.seed)
+    np.random.seed(a.seed)
 
     if a.write_demo_scene:
         from nerf_shared_amd import synth
@@ -74,12 +79,21 @@ def main():
     coarse, fine = utils.create_nerf_models(args, dev)
     renderer = utils.get_renderer(args, bds)
     optimizer = utils.get_optimizer(coarse, fine, args)
+    start = 0
+    if a.ckpt:
+        ck = torch.load(a.ckpt, map_location=dev)
+        coarse.load_state_dict(ck['coarse_model_state_dict'])
+        fine.load_state_dict(ck['fine_model_state_dict'])
+        if a.iters > 0:
+            optimizer.load_state_dict(ck['optimizer_state_dict'])
+        start = int(ck['global_step'])
+        print("loaded", a.ckpt, "at step", start)
     images_t, poses_t, rays_rgb, use_batching, N_rand, i_batch = utils.batch_training_data(args, poses, hwf, K, images, i_train)
     os.makedirs(a.out, exist_ok=True)
 
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(a.iters):
+    for i in range(start, start + a.iters):
         batch_rays, target, rays_rgb, i_batch = utils.sample_random_ray_batch(args, images_t, poses_t, rays_rgb, N_rand,
                                                                               use_batching, i_batch, i_train, hwf, K, 0, i)
         optimizer.zero_grad(set_to_none=True)
@@ -96,7 +110,7 @@ def main():
             print("iter %d  loss %.5f  psnr %.2f" % (i + 1, float(loss.detach()), float(utils.mse2psnr(utils.img2mse(rgb.detach(), target)))))
     torch.cuda.synchronize()
     train_s = time.perf_counter() - t0
-    ckpt = utils.save_checkpoints(args, coarse, fine, optimizer, a.iters, a.iters)
+    ckpt = utils.save_checkpoints(args, coarse, fine, optimizer, start + a.iters, start + a.iters) if a.iters > 0 else a.ckpt
 
     test_ids = [int(i) for i in np.atleast_1d(i_test)][:a.max_test_views]
     test_poses = [poses_t[i, :3, :4] for i in test_ids]
@@ -106,7 +120,12 @@ def main():
     psnr = [float(-10.0 * np.log10(np.mean((f.astype(np.float64) / 255.0 - g) ** 2))) for f, g in zip(frames, gt)]
     for k, f in enumerate(frames):
         image_io.write_png(os.path.join(a.out, "testset", "gt_%03d.png" % k), utils.to8b(gt[k]))
-    print(json.dumps({"iters": a.iters, "train_s": train_s, "it_per_s": a.iters / train_s, "checkpoint": ckpt,
+    n_path = 0
+    if a.render_path > 0:
+        rp = torch.as_tensor(np.asarray(render_poses), dtype=torch.float32)[:a.render_path, :3, :4]
+        n_path = len(renderer.render_from_batch_poses(H, W, K, a.chunk, list(rp), coarse, fine, False, os.path.join(a.out, "path"),
+                                                      b_combine_as_video=True))
+    print(json.dumps({"iters": a.iters, "train_s": train_s, "it_per_s": a.iters / max(train_s, 1e-9), "checkpoint": ckpt, "path_views": n_path,
                       "test_views": len(frames), "test_psnr_mean": float(np.mean(psnr)), "test_psnr": psnr}))
 
 
