@@ -22,7 +22,9 @@
  *    nerf_amd_last_error() returns a thread-local message.  No exception
  *    crosses the boundary.
  *  - Re-entrant; the only shared state is inside model handles, which must not
- *    be updated while a launch that uses them is being enqueued.
+ *    be updated while a launch that uses them is being enqueued.  What the
+ *    launchers cache (raised LDS limits, CU counts) is kept per device and
+ *    updated atomically (csrc/launch_util.h).
  */
 #ifndef NERF_AMD_H
 #define NERF_AMD_H
@@ -43,7 +45,8 @@ extern "C" {
 
 /* Arithmetic of the MLP (the only stage with a precision choice). */
 #define NERF_AMD_PREC_FP32 0       /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32): parity mode       */
-#define NERF_AMD_PREC_BF16 1       /* bf16 operands, fp32 accumulate (v_mfma_f32_32x32x16_bf16)   */
+#define NERF_AMD_PREC_BF16 1       /* bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16;   */
+                                   /* 32x32x16 for output_ch > 16 without a view branch)          */
 
 #define NERF_AMD_MAX_SKIPS 8
 

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
+#include "launch_util.h"
 #include "program.h"
 
 namespace na {
@@ -326,13 +327,8 @@ template <int OT, int IT, int WO, int WI>
 static int launch_dw(const DwArgs &a, const DwReduceArgs &ra, hipStream_t s) {
     constexpr int RSG = OT * 32 + 32, RSX = IT * 32 + 32;
     const size_t lds = 2 * 32 * (RSG + RSX);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(dw_kernel<OT, IT, WO, WI>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return NERF_AMD_EHIP;
-        attr_set = true;
-    }
+    static DynamicLdsOptIn opt_in;
+    if (opt_in.ensure(reinterpret_cast<const void *>(dw_kernel<OT, IT, WO, WI>), lds) != hipSuccess) return NERF_AMD_EHIP;
     // at least ~16 chunks (512 points) per workgroup so the partial tiles are worth their reduction
     const int64_t n_chunks = (a.P + 31) / 32;
     int64_t g = n_chunks / 16;

@@ -17,6 +17,11 @@ using namespace na;
 namespace {
 thread_local std::string g_err;
 
+std::string lds_msg(const char *what, size_t bytes) {
+    return std::string(what) + ": the per-ray scratch needs " + std::to_string(bytes) + " bytes of LDS per workgroup, the CU has " +
+           std::to_string(LDS_LIMIT_BYTES) + " (fewer samples per ray)";
+}
+
 int fail(int code, const std::string &msg) {
     g_err = msg;
     return code;
@@ -356,7 +361,8 @@ int nerf_amd_raw2outputs_backward(const float *raw, int32_t raw_ch, const float 
     int rc = launch_composite_bwd(raw, raw_ch, z_vals, rays_d, rays_d_stride, noise, R, S, white_bkgd, g_rgb_map,
                                   g_disp_map, g_acc_map, g_depth_map, g_weights, g_raw, g_rays_d,
                                   static_cast<hipStream_t>(stream));
-    return rc ? fail(rc, "composite backward launch failed (S must be <= 2048)") : NERF_AMD_OK;
+    if (rc == NERF_AMD_EINVAL && composite_bwd_lds_bytes(S) > LDS_LIMIT_BYTES) return fail(rc, lds_msg("raw2outputs_backward", composite_bwd_lds_bytes(S)));
+    return rc ? fail(rc, "composite backward launch failed") : NERF_AMD_OK;
 }
 
 int nerf_amd_sample_pdf(const float *bins, const float *weights, const float *u, const float *t_lin,
@@ -364,7 +370,8 @@ int nerf_amd_sample_pdf(const float *bins, const float *weights, const float *u,
     if (R < 0 || n_bins < 2 || n_samples < 0 || (R > 0 && (!bins || !weights || !samples || (!u && !t_lin))))
         return fail(NERF_AMD_EINVAL, "bad sample_pdf arguments");
     int rc = launch_sample_pdf(bins, weights, u, t_lin, R, n_bins, n_samples, samples, static_cast<hipStream_t>(stream));
-    return rc ? fail(rc, "sample_pdf launch failed (n_bins must be <= 4096)") : NERF_AMD_OK;
+    if (rc == NERF_AMD_EINVAL && sample_pdf_lds_bytes(n_bins) > LDS_LIMIT_BYTES) return fail(rc, lds_msg("sample_pdf", sample_pdf_lds_bytes(n_bins)));
+    return rc ? fail(rc, "sample_pdf launch failed") : NERF_AMD_OK;
 }
 
 int nerf_amd_coarse_z(const float *rays, int32_t ray_ch, const float *t_vals, const float *t_rand, int64_t R,
@@ -382,7 +389,9 @@ int nerf_amd_resample(const float *z_coarse, const float *weights, const float *
         return fail(NERF_AMD_EINVAL, "bad resample arguments");
     int rc = launch_resample(z_coarse, weights, u, t_lin, R, N_samples, N_importance, z_fine, z_std,
                              static_cast<hipStream_t>(stream));
-    return rc ? fail(rc, "resample launch failed (N_samples + N_importance must be <= 4096)") : NERF_AMD_OK;
+    if (rc == NERF_AMD_EINVAL && resample_lds_bytes(N_samples, N_importance, false) > LDS_LIMIT_BYTES)
+        return fail(rc, lds_msg("resample", resample_lds_bytes(N_samples, N_importance, false)));
+    return rc ? fail(rc, "resample launch failed") : NERF_AMD_OK;
 }
 
 int64_t nerf_amd_render_rays_workspace(const nerf_amd_render_cfg *cfg, int64_t R, int32_t out_ch) {
@@ -420,6 +429,8 @@ int plan_chunk(const nerf_amd_render_cfg *cfg, const nerf_amd_model *coarse, con
     const int Nc = cfg->N_samples, Ni = cfg->N_importance, Nf = Nc + Ni;
     if (Nc < 1 || Ni < 0) return fail(NERF_AMD_EINVAL, "bad sample counts");
     if (Ni > 0 && Nc < 3) return fail(NERF_AMD_EINVAL, "hierarchical sampling needs N_samples >= 3");
+    if (Ni > 0 && resample_lds_bytes(Nc, Ni, true) > LDS_LIMIT_BYTES)      // refuse before anything is launched
+        return fail(NERF_AMD_EINVAL, lds_msg("render_rays (compositing + resampling)", resample_lds_bytes(Nc, Ni, true)));
     if (!io->rays || (io->ray_ch != 8 && io->ray_ch != 11)) return fail(NERF_AMD_EINVAL, "rays must be [R,8] or [R,11]");
     if (!io->t_vals) return fail(NERF_AMD_EINVAL, "t_vals missing");
     if (cfg->perturb && !io->t_rand && !io->z_coarse) return fail(NERF_AMD_EINVAL, "perturb set but t_rand missing");
@@ -519,7 +530,9 @@ int stage_mid(const ChunkPlan &p, const ChunkPlan *prev, hipStream_t s) {
     CompositeJob fj;
     if (prev) fj = final_job(*prev);
     int rc = launch_mid_stage(cj, rj, prev ? &fj : nullptr, s);
-    return rc ? fail(rc, "composite/resample launch failed (N_samples + N_importance must be <= 4096)") : NERF_AMD_OK;
+    if (rc == NERF_AMD_EINVAL && resample_lds_bytes(p.Nc, p.Ni, true) > LDS_LIMIT_BYTES)
+        return fail(rc, lds_msg("render_rays (compositing + resampling)", resample_lds_bytes(p.Nc, p.Ni, true)));
+    return rc ? fail(rc, "composite/resample launch failed") : NERF_AMD_OK;
 }
 }  // namespace
 

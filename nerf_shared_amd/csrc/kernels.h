@@ -106,6 +106,11 @@ int launch_sample_pdf(const float *bins, const float *weights, const float *u, c
                       int64_t R, int n_bins, int n_samples, float *samples, hipStream_t s);
 int launch_resample(const float *z_coarse, const float *weights, const float *u, const float *t_lin,
                     int64_t R, int Nc, int Ni, float *z_fine, float *z_std, hipStream_t s);
+// dynamic LDS the per-ray kernels ask for (4 rays per workgroup); launches beyond LDS_LIMIT_BYTES are refused
+constexpr size_t LDS_LIMIT_BYTES = 160 * 1024;
+size_t composite_bwd_lds_bytes(int S);
+size_t sample_pdf_lds_bytes(int n_bins);
+size_t resample_lds_bytes(int Nc, int Ni, bool with_composite);
 // one compositing job (raw2outputs over R rays of S samples) and the resampling that may follow it
 struct CompositeJob {
     const float *raw; int raw_ch; const float *z; const float *rays_d; int rays_d_stride; const float *noise;

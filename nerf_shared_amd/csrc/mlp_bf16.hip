@@ -24,6 +24,7 @@
 #include <utility>
 
 #include "kernels.h"
+#include "launch_util.h"
 #include "pipeline.h"
 #include "program.h"
 
@@ -250,13 +251,8 @@ static int launch_wg(const MlpArgs &a, int n_frags_used, int n_tiles, hipStream_
     using Lay = Layout<LX, LD, VD>;
     if (n_frags_used != Lay::F_END || n_tiles != Lay::N_TILES) return NERF_AMD_EINVAL;
     const size_t lds = C::RING_BYTES + (size_t)Lay::N_TILES * 32 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_bf16_kernel<LX, LD, VD, C>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return NERF_AMD_EHIP;
-        attr_set = true;
-    }
+    static DynamicLdsOptIn opt_in;
+    if (opt_in.ensure(reinterpret_cast<const void *>(mlp_bf16_kernel<LX, LD, VD, C>), lds) != hipSuccess) return NERF_AMD_EHIP;
     const int64_t groups = (a.P + WG_POINTS - 1) / WG_POINTS;
     if (groups <= 0) return NERF_AMD_OK;
     if (a.P >= (int64_t)1 << 31) return NERF_AMD_EINVAL;

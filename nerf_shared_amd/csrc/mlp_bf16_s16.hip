@@ -16,6 +16,7 @@
 #include <utility>
 
 #include "kernels.h"
+#include "launch_util.h"
 #include "pipeline.h"
 #include "program.h"
 
@@ -383,23 +384,14 @@ static int launch_wg16(const MlpArgs &a, int n_frags_used, int n_tiles, hipStrea
     using Lay = Layout16<LX, LD, VD>;
     if (n_frags_used != Lay::F_END || n_tiles != Lay::N_TILES) return NERF_AMD_EINVAL;
     const size_t lds = C::RING_BYTES + (size_t)Lay::N_TILES * 16 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_bf16_s16_kernel<LX, LD, VD, C, SAVE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return NERF_AMD_EHIP;
-        attr_set = true;
-    }
+    static DynamicLdsOptIn opt_in;         // per kernel instantiation, tracks every device (launch_util.h)
+    if (opt_in.ensure(reinterpret_cast<const void *>(mlp_bf16_s16_kernel<LX, LD, VD, C, SAVE>), lds) != hipSuccess)
+        return NERF_AMD_EHIP;
     int64_t groups = (a.P + WG_POINTS - 1) / WG_POINTS;
     if (groups <= 0) return NERF_AMD_OK;
     if (a.P >= (int64_t)1 << 31) return NERF_AMD_EINVAL;
     if (g_variant != 31) {                 // one workgroup per CU walks the tiles (+1 %: no per-tile dispatch); 31 = A/B off
-        static int n_cu = 0;
-        if (!n_cu) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-        }
+        const int n_cu = device_cu_count();
         if (groups > n_cu) groups = n_cu;
     }
     hipLaunchKernelGGL((mlp_bf16_s16_kernel<LX, LD, VD, C, SAVE>), dim3((unsigned)groups), dim3(WG_THREADS), lds, s, a);

@@ -18,6 +18,7 @@
 #include <utility>
 
 #include "kernels.h"
+#include "launch_util.h"
 #include "pipeline.h"
 #include "program.h"
 
@@ -350,13 +351,8 @@ static int launch_bwd(const MlpArgs &a, int n_frags_used, hipStream_t s) {
     if (a.P <= 0) return NERF_AMD_OK;
     if (a.P >= (int64_t)1 << 31) return NERF_AMD_EINVAL;
     const size_t lds = C::RING_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_bwd_s16_kernel<LX, LD, C>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return NERF_AMD_EHIP;
-        attr_set = true;
-    }
+    static DynamicLdsOptIn opt_in;
+    if (opt_in.ensure(reinterpret_cast<const void *>(mlp_bwd_s16_kernel<LX, LD, C>), lds) != hipSuccess) return NERF_AMD_EHIP;
     const int64_t groups = (a.P + 255) / 256;
     hipLaunchKernelGGL((mlp_bwd_s16_kernel<LX, LD, C>), dim3((unsigned)groups), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;

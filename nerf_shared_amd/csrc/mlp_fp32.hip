@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
+#include "launch_util.h"
 #include "program.h"
 
 namespace na {
@@ -160,13 +161,8 @@ int launch_mlp_f32(const MlpArgs &a, hipStream_t s) {
     const size_t lds = (size_t)a.lds_rows * 64 * sizeof(float);
     if (lds > 160 * 1024) return NERF_AMD_EUNSUPPORTED;
     if (a.W > 8 * F32_MAX_TILES_PER_WAVE * 32) return NERF_AMD_EUNSUPPORTED;
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_f32_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return NERF_AMD_EHIP;
-        attr_lds = lds;
-    }
+    static DynamicLdsOptIn opt_in;         // the size depends on the model: raise the limit to the CU's 160 KiB once per device
+    if (opt_in.ensure(reinterpret_cast<const void *>(mlp_f32_kernel), 160 * 1024) != hipSuccess) return NERF_AMD_EHIP;
     const int64_t blocks = (a.P + 63) / 64;
     hipLaunchKernelGGL(mlp_f32_kernel, dim3((unsigned)blocks), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;

@@ -12,10 +12,30 @@
 #include <math.h>
 
 #include "kernels.h"
+#include "launch_util.h"
 
 namespace na {
 
 constexpr int RAYS_PER_WG = 4;   // one wave per ray, 4 waves per workgroup
+
+// Dynamic LDS of the per-ray kernels grows with the sample counts: reject what the CU cannot hold
+// (EINVAL, before any launch) and raise the kernel's limit above the 64-KiB default when needed.
+constexpr size_t LDS_PER_CU = 160 * 1024;
+static int pow2_at_least(int n) {
+    int p = 2;
+    while (p < n) p <<= 1;
+    return p;
+}
+size_t composite_bwd_lds_bytes(int S) { return (size_t)RAYS_PER_WG * 3 * S * sizeof(float); }
+size_t sample_pdf_lds_bytes(int n_bins) { return (size_t)RAYS_PER_WG * 2 * n_bins * sizeof(float); }
+size_t resample_lds_bytes(int Nc, int Ni, bool with_composite) {
+    return (size_t)RAYS_PER_WG * ((with_composite ? Nc : 0) + 2 * (size_t)(Nc - 1) + pow2_at_least(Nc) + pow2_at_least(Ni)) * sizeof(float);
+}
+static int reserve_lds(DynamicLdsOptIn &opt_in, const void *kernel, size_t bytes) {
+    if (bytes > LDS_PER_CU) return NERF_AMD_EINVAL;
+    if (bytes > 64 * 1024 && opt_in.ensure(kernel, LDS_PER_CU) != hipSuccess) return NERF_AMD_EHIP;
+    return NERF_AMD_OK;
+}
 
 // Each ray's scratch lives in LDS that only its own wave touches, so ordering LDS
 // traffic inside the wave is all that is needed: wait for this wave's LDS
@@ -295,9 +315,11 @@ int launch_composite_bwd(const float *raw, int raw_ch, const float *z, const flo
                          const float *g_acc, const float *g_depth, const float *g_weights, float *g_raw, float *g_rays_d,
                          hipStream_t s) {
     if (R <= 0) return NERF_AMD_OK;
-    if (S < 1 || S > 2048 || raw_ch < 4) return NERF_AMD_EINVAL;
+    if (S < 1 || raw_ch < 4) return NERF_AMD_EINVAL;
     const int64_t blocks = (R + RAYS_PER_WG - 1) / RAYS_PER_WG;
-    const size_t lds = (size_t)RAYS_PER_WG * 3 * S * sizeof(float);
+    const size_t lds = composite_bwd_lds_bytes(S);
+    static DynamicLdsOptIn opt_in;
+    if (int rc = reserve_lds(opt_in, reinterpret_cast<const void *>(composite_bwd_kernel), lds)) return rc;
     hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)blocks), dim3(64 * RAYS_PER_WG), lds, s, raw, raw_ch, z,
                        rays_d, rays_d_stride, noise, R, S, white_bkgd, g_rgb, g_disp, g_acc, g_depth, g_weights, g_raw,
                        g_rays_d);
@@ -367,9 +389,11 @@ __global__ __launch_bounds__(64 * RAYS_PER_WG) void sample_pdf_kernel(const floa
 int launch_sample_pdf(const float *bins, const float *weights, const float *u, const float *t_lin,
                       int64_t R, int n_bins, int n_samples, float *samples, hipStream_t s) {
     if (R <= 0 || n_samples <= 0) return NERF_AMD_OK;
-    if (n_bins < 2 || n_bins > 4096) return NERF_AMD_EINVAL;
+    if (n_bins < 2) return NERF_AMD_EINVAL;
     const int64_t blocks = (R + RAYS_PER_WG - 1) / RAYS_PER_WG;
-    const size_t lds = (size_t)RAYS_PER_WG * 2 * n_bins * sizeof(float);
+    const size_t lds = sample_pdf_lds_bytes(n_bins);
+    static DynamicLdsOptIn opt_in;
+    if (int rc = reserve_lds(opt_in, reinterpret_cast<const void *>(sample_pdf_kernel), lds)) return rc;
     hipLaunchKernelGGL(sample_pdf_kernel, dim3((unsigned)blocks), dim3(64 * RAYS_PER_WG), lds, s, bins, weights, u,
                        t_lin, R, n_bins, n_samples, samples);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
@@ -517,18 +541,18 @@ __global__ __launch_bounds__(64 * RAYS_PER_WG) void mid_stage_kernel(CompositeJo
 int launch_mid_stage(const CompositeJob &cj, const ResampleJob &rj, const CompositeJob *fj, hipStream_t s) {
     if (cj.R <= 0) return NERF_AMD_EINVAL;
     const int Nc = cj.S, Ni = rj.Ni;
-    if (cj.raw_ch < 4 || Nc < 3 || Ni < 1 || Nc + Ni > 4096) return NERF_AMD_EINVAL;
+    if (cj.raw_ch < 4 || Nc < 3 || Ni < 1) return NERF_AMD_EINVAL;
     ResampleJob r2 = rj;
-    r2.pad_c = 2; r2.pad_s = 2;
-    while (r2.pad_c < Nc) r2.pad_c <<= 1;
-    while (r2.pad_s < Ni) r2.pad_s <<= 1;
+    r2.pad_c = pow2_at_least(Nc); r2.pad_s = pow2_at_least(Ni);
     CompositeJob f2;
     std::memset(&f2, 0, sizeof(f2));
     if (fj) f2 = *fj;
     const int64_t cr_blocks = (cj.R + RAYS_PER_WG - 1) / RAYS_PER_WG;
     const int64_t f_blocks = (f2.R + RAYS_PER_WG - 1) / RAYS_PER_WG;
     if (cr_blocks + f_blocks >= ((int64_t)1 << 31)) return NERF_AMD_EINVAL;
-    const size_t lds = (size_t)RAYS_PER_WG * (Nc + 2 * (Nc - 1) + r2.pad_c + r2.pad_s) * sizeof(float);
+    const size_t lds = resample_lds_bytes(Nc, Ni, true);
+    static DynamicLdsOptIn opt_in;
+    if (int rc = reserve_lds(opt_in, reinterpret_cast<const void *>(mid_stage_kernel), lds)) return rc;
     hipLaunchKernelGGL(mid_stage_kernel, dim3((unsigned)(cr_blocks + f_blocks)), dim3(64 * RAYS_PER_WG), lds, s, cj, r2, f2,
                        (int)cr_blocks);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
@@ -537,12 +561,12 @@ int launch_mid_stage(const CompositeJob &cj, const ResampleJob &rj, const Compos
 int launch_resample(const float *z_coarse, const float *weights, const float *u, const float *t_lin,
                     int64_t R, int Nc, int Ni, float *z_fine, float *z_std, hipStream_t s) {
     if (R <= 0) return NERF_AMD_OK;
-    if (Nc < 3 || Ni < 1 || Nc + Ni > 4096) return NERF_AMD_EINVAL;
-    int pad_c = 2, pad_s = 2;
-    while (pad_c < Nc) pad_c <<= 1;
-    while (pad_s < Ni) pad_s <<= 1;
+    if (Nc < 3 || Ni < 1) return NERF_AMD_EINVAL;
+    const int pad_c = pow2_at_least(Nc), pad_s = pow2_at_least(Ni);
     const int64_t blocks = (R + RAYS_PER_WG - 1) / RAYS_PER_WG;
-    const size_t lds = (size_t)RAYS_PER_WG * (2 * (Nc - 1) + pad_c + pad_s) * sizeof(float);
+    const size_t lds = resample_lds_bytes(Nc, Ni, false);
+    static DynamicLdsOptIn opt_in;
+    if (int rc = reserve_lds(opt_in, reinterpret_cast<const void *>(resample_kernel), lds)) return rc;
     hipLaunchKernelGGL(resample_kernel, dim3((unsigned)blocks), dim3(64 * RAYS_PER_WG), lds, s, z_coarse, weights, u,
                        t_lin, R, Nc, Ni, pad_c, pad_s, z_fine, z_std);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;

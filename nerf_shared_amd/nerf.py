@@ -6,10 +6,11 @@ Signatures, attribute names and state_dict keys follow the reference
 (`coarse_model_state_dict` / `fine_model_state_dict`, utils.py:450-455) loads
 with ``load_state_dict`` unchanged.
 
-Inference runs the forward-only kernels.  With gradients enabled, the standard model
-(D=8, W=256, skips=[4], viewdirs, multires 10/4 or 15/6, bf16) runs the training kernels and
-loss.backward() reaches its parameters, the points / view directions and the rays
-(SURVEY.md section 8f rank 1).
+Inference (torch.no_grad(), or nothing requires grad) runs the forward-only kernels.  With
+gradients enabled, the standard model (D=8, W=256, skips=[4], viewdirs, multires 10/4 or 15/6,
+bf16) runs the training kernels and loss.backward() reaches its parameters, the points / view
+directions and the rays.  Any other model raises NerfAmdError when
+gradients are requested: outputs never silently come back without autograd history.
 """
 import ctypes
 import weakref
@@ -115,12 +116,20 @@ class _FieldTrainFn(torch.autograd.Function):
                                                         _lib.stream_of(dev)), "nerf_amd_field_forward_train")
         ctx.model, ctx.ws, ctx.R, ctx.S = model, ws, n_rays, n_samples
         ctx.inputs = (pts, viewdirs, rays, z_vals)
+        ctx.pack_key = model._packed_key          # the weights this forward ran on (backward must see the same pack)
         return raw
 
     @staticmethod
     def backward(ctx, g_raw):
         model, ws, R, S = ctx.model, ctx.ws, ctx.R, ctx.S
         pts, viewdirs, rays, z_vals = ctx.inputs
+        if ws is None:
+            raise _lib.NerfAmdError("backward through this field evaluation ran already and released its saved "
+                                    "activations; a second backward (retain_graph=True) is not supported")
+        if model._packed_key is None or model._packed_key != ctx.pack_key:
+            raise _lib.NerfAmdError("the model's parameters changed between this forward and its backward "
+                                    "(optimizer step, load_state_dict or weights_changed()): the gradients would be "
+                                    "taken against the wrong weights; run backward before updating the parameters")
         dev = ws.device
         g = g_raw.contiguous().float()
         mods = model._linears()
@@ -272,21 +281,25 @@ class NeRF(nn.Module):
         return out
 
     def _wants_grad(self, device, *inputs):
-        """True when autograd should flow into the parameters (or the given inputs) and the training
-        kernels apply.  Otherwise (no_grad, nothing requires grad, or an architecture / precision
-        the training kernels do not cover) the forward-only kernels run and outputs carry no history."""
+        """True when autograd has to flow into the parameters (or the given inputs): gradients are
+        enabled and something requires them.  The training kernels cover the standard model in bf16
+        mode; for anything else this raises -- outputs never silently lose their autograd history
+        (the reference's loss.backward(), main.py:103, would train nothing).  Inference on such a
+        model runs under torch.no_grad() (as render_utils.py:302 does) or after requires_grad_(False)."""
         if not torch.is_grad_enabled() or not (any(p.requires_grad for p in self._train_params())
                                                or any(t is not None and t.requires_grad for t in inputs)):
             return False
-        ok = (self.precision or _default_precision) == "bf16" and \
-            bool(lib.nerf_amd_model_supports_training(self._model_handle(device)))
-        if not ok and not getattr(self, "_warned_no_grad", False):
-            import warnings
-            warnings.warn("nerf_shared_amd: gradients were requested but the training kernels cover only "
-                          "NeRF(D=8, W=256, skips=[4], use_viewdirs=True, multires=10, multires_views=4) in bf16 mode; "
-                          "this model runs forward-only and its outputs carry no autograd history")
-            self._warned_no_grad = True
-        return ok
+        prec = self.precision or _default_precision
+        if prec != "bf16" or not lib.nerf_amd_model_supports_training(self._model_handle(device)):
+            raise _lib.NerfAmdError(
+                "gradients were requested (grad mode is on and a parameter or input requires grad) but the HIP "
+                "training kernels cover NeRF(D=8, W=256, skips=[4], use_viewdirs=True) with multires/multires_views "
+                "10/4 or 15/6 in precision 'bf16'; this model is %s(D=%d, W=%d, skips=%s, use_viewdirs=%s, multires=%d, "
+                "multires_views=%d) in precision '%s'.  For inference wrap the call in torch.no_grad() or call "
+                "model.requires_grad_(False); there is no PyTorch fallback"
+                % (type(self).__name__, self.D, self.W, list(self.skips), self.use_viewdirs, self.multires,
+                   self.multires_views, prec))
+        return True
 
     def forward_rays(self, rays, z_vals):
         """raw [R, S, 4] of rays [R, 11] at depths z_vals [R, S] (pts = o + d z formed in the kernel);

@@ -7,9 +7,11 @@ edges of the hot path:
   * temporaries are allocated on ``ray_batch.device`` (the reference uses the
     process-wide default device, main.py:150-152);
   * random draws use torch's generator for that device in the reference's order
-    and shapes (t_rand, coarse noise, u, fine noise), so a seeded run matches a
-    seeded reference run on the same device; ``pytest=True`` reproduces the
-    reference's seeded numpy draws bit for bit;
+    and shapes -- per render_rays call, i.e. per chunk of render_batch: t_rand,
+    coarse noise, u, fine noise (render_utils.py:121,264, utils.py:86) -- so a
+    seeded multi-chunk render equals seeded per-chunk render_rays calls in every
+    mode of render_batch; ``pytest=True`` reproduces the reference's seeded numpy
+    draws bit for bit;
   * the NaN/Inf scan of every output (render_utils.py:170-172) only runs when
     DEBUG is set -- it never changes outputs and costs a device sync per key;
   * autograd reaches the models' parameters and the rays (standard model, bf16 mode).
@@ -29,27 +31,23 @@ DEBUG = False
 _KEYS_MAIN = ('rgb_map', 'disp_map', 'acc_map')
 
 
-class _Workspace:
-    """Grow-only scratch buffers per (device, slot): raw/z/weights of the two passes.
-    Slot 0 belongs to the caller's stream, slots 1.. to the chunk-overlap streams."""
-    _bufs = {}
-    _streams = {}
+def _workspace(device, nbytes):
+    """Scratch for one render_rays call (raw / z / weights of the two passes), allocated per call on the
+    stream that is current: torch's caching allocator recycles the block and keeps its reuse ordered
+    on that stream, so renders enqueued on different streams never share scratch."""
+    return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
 
-    @classmethod
-    def get(cls, device, nbytes, slot=0):
-        buf = cls._bufs.get((device, slot))
-        if buf is None or buf.numel() < nbytes:
-            buf = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
-            cls._bufs[(device, slot)] = buf
-        return buf
 
-    @classmethod
-    def side_streams(cls, device, n=2):
-        s = cls._streams.get(device)
-        if s is None:
-            s = [torch.cuda.Stream(device=device) for _ in range(n)]
-            cls._streams[device] = s
-        return s
+_side_streams = {}
+
+
+def _chunk_streams(device, n=2):
+    """The two side streams of the opt-in chunk-overlap mode of render_batch."""
+    s = _side_streams.get(device)
+    if s is None:
+        s = [torch.cuda.Stream(device=device) for _ in range(n)]
+        _side_streams[device] = s
+    return s
 
 
 _linspace_cache = {}
@@ -171,16 +169,21 @@ class Renderer(torch.nn.Module):
             prec = _lib.PREC_FP32
         return hc, hf, self._cfg(prec), lib.nerf_amd_model_out_ch(hc)
 
-    def _chunk_io(self, rays, cfg, out_ch, outs, pytest, slot, z_pre=None):
+    def _chunk_io(self, rays, cfg, out_ch, outs, pytest, ws=None, z_pre=None, t_rand_out=None):
         """nerf_amd_render_io of one render_rays call on contiguous fp32 rays [R, 8|11] writing into the tensors
-        of ``outs`` (rows [0, R)): random draws in the reference's order and shapes, workspace `slot`.
-        z_pre: coarse depths [R, N_samples] made beforehand.  Returns (io, tensors to keep alive)."""
+        of ``outs`` (rows [0, R)): random draws in the reference's order and shapes (t_rand, noise0, u, noise1).
+        ws: workspace to use (default: a fresh one).  z_pre: this chunk's rows of a coarse-depth buffer that one
+        launch fills for all chunks afterwards; the jitter draws it needs go into t_rand_out (same rows).
+        Returns (io, tensors to keep alive)."""
         R, dev = rays.shape[0], rays.device
         Nc, Ni = int(self.N_samples), int(self.N_importance)
         Nf = Nc + Ni
         t_rand = noise0 = noise1 = u = None
-        if self.perturb > 0. and z_pre is None:
-            t_rand = _pytest_uniform([R, Nc], dev) if pytest else torch.rand([R, Nc], device=dev)
+        if self.perturb > 0.:
+            if t_rand_out is not None:
+                t_rand_out.uniform_()        # the same draw as torch.rand([R, Nc]): rand() is empty().uniform_(0, 1)
+            else:
+                t_rand = _pytest_uniform([R, Nc], dev) if pytest else torch.rand([R, Nc], device=dev)
         if self.raw_noise_std > 0.:
             noise0 = (_pytest_uniform([R, Nc], dev) if pytest else torch.randn([R, Nc], device=dev)) * self.raw_noise_std
         t_lin = None
@@ -209,37 +212,47 @@ class Renderer(torch.nn.Module):
         for k in ('rgb_map', 'disp_map', 'acc_map', 'rgb0', 'disp0', 'acc0', 'z_std', 'raw', 'weights', 'z_vals'):
             setattr(io, k, _lib.ptr(outs.get(k)))
         nbytes = lib.nerf_amd_render_rays_workspace(cfg, R, out_ch)
-        ws = _Workspace.get(dev, nbytes, slot)
+        if ws is None or ws.numel() < nbytes:
+            ws = _workspace(dev, nbytes)
         io.workspace, io.workspace_bytes = ws.data_ptr(), ws.numel()
         return io, (rays, t_rand, noise0, noise1, u, z_pre, ws)
 
-    def _launch(self, rays, coarse_model, fine_model, outs, retraw, retweights, pytest, slot=0, z_pre=None):
+    def _launch(self, rays, coarse_model, fine_model, outs, retraw, retweights, pytest):
         """Enqueue render_rays for contiguous fp32 rays [R, 8|11]; writes into the
         tensors of ``outs`` (rows [0, R))."""
         dev = rays.device
         hc, hf, cfg, out_ch = self._handles(dev, coarse_model, fine_model)
-        io, keep = self._chunk_io(rays, cfg, out_ch, outs, pytest, slot, z_pre)
+        io, keep = self._chunk_io(rays, cfg, out_ch, outs, pytest)
         with torch.cuda.device(dev):
             _lib.check(lib.nerf_amd_render_rays(cfg, hc, hf, io, rays.shape[0], _lib.stream_of(dev)), "nerf_amd_render_rays")
         # keep the draws alive until the stream has consumed them (caching allocator is stream-ordered)
         return keep
 
-    def _launch_chunks(self, rays, starts, chunk, coarse_model, fine_model, full, z_all):
-        """render_batch's chunk loop as one library call (nerf_amd_render_chunks): per-chunk draws and output
-        rows exactly as _launch makes them, two workspaces used alternately."""
+    def _launch_chunks(self, rays, starts, chunk, coarse_model, fine_model, full):
+        """render_batch's chunk loop as one library call (nerf_amd_render_chunks): per-chunk draws (in the
+        reference's per-chunk order) and output rows exactly as _launch makes them, two workspaces used
+        alternately, and the coarse depths of all chunks from one launch in front."""
         dev = rays.device
         hc, hf, cfg, out_ch = self._handles(dev, coarse_model, fine_model)
-        n = len(starts)
+        n, N, Nc = len(starts), rays.shape[0], int(self.N_samples)
         ios = (_lib.RenderIO * n)()
         counts = (ctypes.c_int64 * n)()
         keep = []
+        z_all = torch.empty(N, Nc, device=dev, dtype=torch.float32)
+        t_all = torch.empty(N, Nc, device=dev, dtype=torch.float32) if self.perturb > 0. else None
+        nbytes = lib.nerf_amd_render_rays_workspace(cfg, min(chunk, N), out_ch)
+        wss = [_workspace(dev, nbytes), _workspace(dev, nbytes)]
         for j, i in enumerate(starts):
             part = {k: v[i:i + chunk] for k, v in full.items()}
             r = rays[i:i + chunk]
-            ios[j], alive = self._chunk_io(r, cfg, out_ch, part, False, j % 2, None if z_all is None else z_all[i:i + chunk])
+            ios[j], alive = self._chunk_io(r, cfg, out_ch, part, False, wss[j % 2], z_all[i:i + chunk],
+                                           None if t_all is None else t_all[i:i + chunk])
             counts[j] = r.shape[0]
             keep.append(alive)
         with torch.cuda.device(dev):
+            _lib.check(lib.nerf_amd_coarse_z(rays.data_ptr(), rays.shape[1], _linspace01(Nc, dev).data_ptr(),
+                                             _lib.ptr(t_all), N, Nc, int(bool(self.lindisp)), int(self.perturb > 0.),
+                                             z_all.data_ptr(), _lib.stream_of(dev)), "nerf_amd_coarse_z")
             _lib.check(lib.nerf_amd_render_chunks(cfg, hc, hf, ios, counts, n, _lib.stream_of(dev)), "nerf_amd_render_chunks")
         return keep
 
@@ -362,7 +375,8 @@ class Renderer(torch.nn.Module):
         without the copy).  With ``Renderer.overlap_chunks = True`` consecutive chunks
         alternate between two HIP streams (each with its own workspace) so the small
         per-ray kernels and launch/drain gaps of one chunk hide under the field kernel
-        of the other; results do not depend on it.  Off by default: the gain is ~3 % and
+        of the other; results do not depend on it (random draws come from the device's one
+        generator in chunk order in every mode).  Off by default: the gain is ~3 % and
         concurrent kernels blur per-kernel timings."""
         _lib.require_device(rays_flat, "rays_flat")
         rays = rays_flat.detach().contiguous().float()
@@ -381,22 +395,12 @@ class Renderer(torch.nn.Module):
                     parts.setdefault(k, []).append(v)
             return {k: torch.cat(v, 0) for k, v in parts.items()}
         if not (self.overlap_chunks and len(starts) > 1):
-            z_all = None
-            if len(starts) > 1:          # coarse depths of every chunk in one launch instead of one per chunk
-                Nc = int(self.N_samples)
-                t_rand = torch.rand([N, Nc], device=dev) if self.perturb > 0. else None
-                z_all = torch.empty(N, Nc, device=dev, dtype=torch.float32)
-                with torch.cuda.device(dev):
-                    _lib.check(lib.nerf_amd_coarse_z(rays.data_ptr(), rays.shape[1], _linspace01(Nc, dev).data_ptr(),
-                                                     _lib.ptr(t_rand), N, Nc, int(bool(self.lindisp)), int(self.perturb > 0.),
-                                                     z_all.data_ptr(), _lib.stream_of(dev)), "nerf_amd_coarse_z")
             if len(starts) > 1 and self.fuse_chunk_launches:
-                self._launch_chunks(rays, starts, chunk, coarse_model, fine_model, full, z_all)
+                self._launch_chunks(rays, starts, chunk, coarse_model, fine_model, full)
                 return full
             for i in starts:
                 part = {k: v[i:i + chunk] for k, v in full.items()}
-                self._launch(rays[i:i + chunk], coarse_model, fine_model, part, retraw, False, False,
-                             z_pre=None if z_all is None else z_all[i:i + chunk])
+                self._launch(rays[i:i + chunk], coarse_model, fine_model, part, retraw, False, False)
             return full
         # pack parameters and build the cached linspaces on the caller's stream first, then fan out
         _linspace01(int(self.N_samples), dev)
@@ -408,16 +412,17 @@ class Renderer(torch.nn.Module):
         cur = torch.cuda.current_stream(dev)
         ready = torch.cuda.Event()
         ready.record(cur)
-        side = _Workspace.side_streams(dev)
+        side = _chunk_streams(dev)
         for s in side:
             s.wait_event(ready)
         for n, i in enumerate(starts):
-            slot = n % len(side)
-            with torch.cuda.stream(side[slot]):
+            with torch.cuda.stream(side[n % len(side)]):      # draws and scratch are made on the chunk's own stream
                 part = {k: v[i:i + chunk] for k, v in full.items()}
-                self._launch(rays[i:i + chunk], coarse_model, fine_model, part, retraw, False, False, slot=slot + 1)
+                self._launch(rays[i:i + chunk], coarse_model, fine_model, part, retraw, False, False)
         for s in side:
             cur.wait_stream(s)
+        for v in full.values():
+            v.record_stream(side[0]); v.record_stream(side[1])
         return full
 
     def render(self, H, W, K, coarse_model, fine_model, chunk=1024 * 32, rays=None, retraw=True,

@@ -200,41 +200,33 @@ def sample_pdf(bins, weights, N_samples, det=False, pytest=False):
 
 
 # ---------------------------------------------------------------- factories (utils.py:119-161)
+_FIELD_SKIPS = [4]          # the reference hard-codes the skip layer (utils.py:122)
+
+
 def create_nerf_models(args, device=None):
-    """coarse (+ fine when N_importance > 0) NeRF from an args namespace (utils.py:119-139)."""
+    """(coarse_model, fine_model) for an args namespace, what utils.py:119-139 builds: one field, or two when
+    N_importance > 0 (then both emit 5 channels); the fine field takes its depth / width from
+    netdepth_fine / netwidth_fine.  fine_model is None without importance sampling."""
     from . import nerf
     device = device or _default_device()
-    output_ch = 5 if args.N_importance > 0 else 4
-    skips = [4]
-    coarse_model = nerf.NeRF(D=args.netdepth, W=args.netwidth, output_ch=output_ch, skips=skips,
-                             use_viewdirs=args.use_viewdirs, multires=args.multires,
-                             multires_views=args.multires_views, i_embed=args.i_embed).to(device)
-    fine_model = None
-    if args.N_importance > 0:
-        fine_model = nerf.NeRF(D=args.netdepth_fine, W=args.netwidth_fine, output_ch=output_ch, skips=skips,
-                               use_viewdirs=args.use_viewdirs, multires=args.multires,
-                               multires_views=args.multires_views, i_embed=args.i_embed).to(device)
-    return coarse_model, fine_model
+    two_pass = args.N_importance > 0
+    shared = dict(output_ch=5 if two_pass else 4, skips=list(_FIELD_SKIPS), use_viewdirs=args.use_viewdirs,
+                  multires=args.multires, multires_views=args.multires_views, i_embed=args.i_embed)
+    sizes = [(args.netdepth, args.netwidth)] + ([(args.netdepth_fine, args.netwidth_fine)] if two_pass else [])
+    fields = [nerf.NeRF(D=depth, W=width, **shared).to(device) for depth, width in sizes]
+    return fields[0], (fields[1] if two_pass else None)
 
 
 def get_renderer(args, bds_dict):
-    """Renderer from an args namespace + {'near':..., 'far':...} (utils.py:141-161)."""
+    """Renderer for an args namespace and the scene's {'near', 'far'} (utils.py:141-161).  NDC rays are used
+    for forward-facing LLFF scenes only, and not when args.no_ndc asks for world-space sampling."""
     from . import render_utils
-    render_kwargs = {
-        'perturb': args.perturb,
-        'N_importance': args.N_importance,
-        'N_samples': args.N_samples,
-        'use_viewdirs': args.use_viewdirs,
-        'white_bkgd': args.white_bkgd,
-        'raw_noise_std': args.raw_noise_std,
-        'ndc': True,
-        'lindisp': args.lindisp,
-    }
-    if args.dataset_type != 'llff' or args.no_ndc:
+    ndc = args.dataset_type == 'llff' and not args.no_ndc
+    if not ndc:
         print('Not ndc!')
-        render_kwargs['ndc'] = False
-    render_kwargs.update(bds_dict)
-    return render_utils.Renderer(**render_kwargs)
+    return render_utils.Renderer(perturb=args.perturb, N_importance=args.N_importance, N_samples=args.N_samples,
+                                 use_viewdirs=args.use_viewdirs, white_bkgd=args.white_bkgd,
+                                 raw_noise_std=args.raw_noise_std, ndc=ndc, lindisp=args.lindisp, **bds_dict)
 
 
 # ---------------------------------------------------------------- optimizer + checkpoints (utils.py:163-214, 444-456)
@@ -290,48 +282,51 @@ def load_checkpoint(coarse_model, fine_model, optimizer, args, b_load_ckpnt_as_t
 
 
 # ---------------------------------------------------------------- datasets (utils.py:216-313)
+def _scene_llff(args):
+    """LLFF scene -> images, poses [N,3,4], render_poses, hwf, splits, (near, far)  (utils.py:220-252)."""
+    from . import load_llff
+    images, poses, bds, render_poses, i_test = load_llff.load_llff_data(
+        args.datadir, args.factor, recenter=True, bd_factor=.75, spherify=args.spherify)
+    hwf, poses = poses[0, :3, -1], poses[:, :3, :4]
+    print('Loaded llff', images.shape, render_poses.shape, hwf, args.datadir)
+    held_out = list(i_test) if isinstance(i_test, (list, tuple, np.ndarray)) else [i_test]
+    if args.llffhold > 0:
+        print('Auto LLFF holdout,', args.llffhold)
+        held_out = np.arange(images.shape[0])[::args.llffhold]
+    i_train = np.array([i for i in range(int(images.shape[0])) if i not in held_out])
+    # world-space depth range from the scene bounds, or the unit NDC range
+    near_far = (np.ndarray.min(bds) * .9, np.ndarray.max(bds) * 1.) if args.no_ndc else (0., 1.)
+    print('NEAR FAR', *near_far)
+    return images, poses, render_poses, hwf, (i_train, held_out, held_out), near_far
+
+
+def _scene_blender(args):
+    """NeRF-synthetic scene; RGBA is composited over white or the alpha dropped  (utils.py:254-266)."""
+    from . import load_blender
+    images, poses, render_poses, hwf, i_split, near, far = load_blender.load_blender_data(
+        args.datadir, args.half_res, args.testskip)
+    print('Loaded blender', images.shape, render_poses.shape, hwf, args.datadir)
+    rgb, alpha = images[..., :3], images[..., -1:]
+    images = rgb * alpha + (1. - alpha) if args.white_bkgd else rgb
+    return images, poses, render_poses, hwf, tuple(i_split), (near, far)
+
+
+_SCENE_READERS = {'llff': _scene_llff, 'blender': _scene_blender}
+
+
 def load_datasets(args):
     """Scene on disk -> (images, poses, render_poses, [H, W, focal], (i_train, i_val, i_test), K,
     {'near', 'far'}) for dataset_type 'blender' and 'llff' (utils.py:216-313).  The LINEMOD and
     deepvoxels loaders of the reference are not part of this build."""
-    from . import load_blender, load_llff
-    if args.dataset_type == 'llff':
-        images, poses, bds, render_poses, i_test = load_llff.load_llff_data(
-            args.datadir, args.factor, recenter=True, bd_factor=.75, spherify=args.spherify)
-        hwf = poses[0, :3, -1]
-        poses = poses[:, :3, :4]
-        print('Loaded llff', images.shape, render_poses.shape, hwf, args.datadir)
-        if not isinstance(i_test, list):
-            i_test = [i_test]
-        if args.llffhold > 0:
-            print('Auto LLFF holdout,', args.llffhold)
-            i_test = np.arange(images.shape[0])[::args.llffhold]
-        i_val = i_test
-        i_train = np.array([i for i in np.arange(int(images.shape[0])) if (i not in i_test and i not in i_val)])
-        if args.no_ndc:
-            near, far = np.ndarray.min(bds) * .9, np.ndarray.max(bds) * 1.
-        else:
-            near, far = 0., 1.
-        print('NEAR FAR', near, far)
-    elif args.dataset_type == 'blender':
-        images, poses, render_poses, hwf, i_split, near, far = load_blender.load_blender_data(
-            args.datadir, args.half_res, args.testskip)
-        print('Loaded blender', images.shape, render_poses.shape, hwf, args.datadir)
-        i_train, i_val, i_test = i_split
-        if args.white_bkgd:
-            images = images[..., :3] * images[..., -1:] + (1. - images[..., -1:])
-        else:
-            images = images[..., :3]
-    else:
-        raise NotImplementedError("dataset_type %r: this build reads 'blender' and 'llff' scenes" % (args.dataset_type,))
-
-    H, W, focal = hwf
-    H, W = int(H), int(W)
-    hwf = [H, W, focal]
+    reader = _SCENE_READERS.get(args.dataset_type)
+    if reader is None:
+        raise NotImplementedError("dataset_type %r: this build reads %s scenes" % (args.dataset_type, sorted(_SCENE_READERS)))
+    images, poses, render_poses, hwf, (i_train, i_val, i_test), (near, far) = reader(args)
+    H, W, focal = int(hwf[0]), int(hwf[1]), hwf[2]
     K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
     if getattr(args, 'render_test', False):
         render_poses = np.array(poses[i_test])
-    return images, poses, render_poses, hwf, (i_train, i_val, i_test), K, {'near': near, 'far': far}
+    return images, poses, render_poses, [H, W, focal], (i_train, i_val, i_test), K, {'near': near, 'far': far}
 
 
 # ---------------------------------------------------------------- training ray batches (utils.py:360-442)

@@ -607,7 +607,13 @@ def test_sharded_render_two_ranks_matches_single(dev, tmp_path):
     port = str(29600 + os.getpid() % 2000)
     frames = tmp_path / "frames"
     procs = [subprocess.Popen([sys.executable, str(script), str(rk), "2", port, str(frames)]) for rk in range(2)]
-    codes = [p.wait(timeout=170) for p in procs]
+    try:
+        codes = [p.wait(timeout=170) for p in procs]
+    finally:
+        for p in procs:                       # never leave a worker holding the GPU behind a failed test
+            if p.poll() is None:
+                p.kill()
+                p.wait()
     assert codes == [0, 0]
 
 

@@ -152,6 +152,25 @@ def test_load_blender_data(tmp_path, half_res):
     same(render_poses[0].numpy(), G["ps_out"][0]); same(render_poses[1].numpy(), G["ps_out"][1])
 
 
+def test_halve_area_hand_computed_fixture():
+    """half_res (load_blender.py:86-94) resizes with cv2.INTER_AREA, which for an exact factor of 2 is the mean
+    of every 2x2 block.  cv2 is absent offline, so this stage is UNPINNED against cv2 itself; what is pinned
+    is the arithmetic, on a hand-computed fixture whose block means are exact in fp32."""
+    img = (np.arange(16, dtype=np.float32).reshape(4, 4) / 16.0)[..., None] * np.array([1.0, 2.0, 0.5, 1.0], np.float32)
+    # rows 0-1: blocks {0,1,4,5} -> 2.5 and {2,3,6,7} -> 4.5; rows 2-3: {8,9,12,13} -> 10.5 and {10,11,14,15} -> 12.5
+    want = (np.array([[2.5, 4.5], [10.5, 12.5]], np.float32) / 16.0)[..., None] * np.array([1.0, 2.0, 0.5, 1.0], np.float32)
+    got = load_blender.halve_area(img)
+    assert got.dtype == np.float32 and got.shape == (2, 2, 4)
+    assert np.array_equal(got, want)
+    # 8-bit pixels over 255 (what the loader feeds it): within one fp32 ulp of the exact rational mean
+    px = np.array([[[255, 0, 17, 255], [254, 1, 18, 0]], [[3, 2, 19, 255], [0, 255, 20, 1]]], np.uint8)
+    got = load_blender.halve_area((px / 255.).astype(np.float32))
+    exact = px.astype(np.float64).sum((0, 1)) / (4 * 255.0)                 # [512, 258, 74, 511] / 1020
+    assert np.abs(got[0, 0].astype(np.float64) - exact).max() <= np.spacing(np.float32(0.5))
+    # an odd edge is cropped (stock NeRF-synthetic frames are 800x800; cv2 would use a fractional footprint there)
+    assert load_blender.halve_area(np.ones((5, 7, 4), np.float32)).shape == (2, 3, 4)
+
+
 def test_load_datasets_blender_and_llff(tmp_path):
     b, l = tmp_path / "b", tmp_path / "l"
     os.makedirs(b); os.makedirs(l)

@@ -80,13 +80,10 @@ def main():
     renderer = utils.get_renderer(args, bds)
     optimizer = utils.get_optimizer(coarse, fine, args)
     start = 0
-    if a.ckpt:
-        ck = torch.load(a.ckpt, map_location=dev)
-        coarse.load_state_dict(ck['coarse_model_state_dict'])
-        fine.load_state_dict(ck['fine_model_state_dict'])
-        if a.iters > 0:
-            optimizer.load_state_dict(ck['optimizer_state_dict'])
-        start = int(ck['global_step'])
+    if a.ckpt:          # resume / render-only: the package's own reader (handles fine_model None, reference .tar keys)
+        args.ft_path, args.no_reload = a.ckpt, False
+        start = int(utils.load_checkpoint(coarse, fine, optimizer if a.iters > 0 else None, args,
+                                          b_load_ckpnt_as_trainable=True))
         print("loaded", a.ckpt, "at step", start)
     images_t, poses_t, rays_rgb, use_batching, N_rand, i_batch = utils.batch_training_data(args, poses, hwf, K, images, i_train)
     os.makedirs(a.out, exist_ok=True)
