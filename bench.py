@@ -1,30 +1,43 @@
 #!/usr/bin/env python3
 """bench.py -- rays/sec of the render hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c1|c2|c3|c4|c5] [--precision bf16|fp32]
 
-One "step" = one pass of Renderer.render_batch over a resident [rays, 11] batch:
-Lego half-res geometry (400x400 = 160 000 rays per GPU), 64 coarse + 128 fine
-samples, 8x256 viewdirs MLP x 2 (coarse + fine, random-init seeds 0/10),
-4096-ray chunks, perturb=0, white background (BASELINE.json configs[1]).
-Rays are generated into HBM before the timed region; outputs stay in HBM.
+One "step" = one call of Renderer.render(H, W, K, coarse, fine, chunk, c2w=pose, retraw=False)
+(reference render_utils.py:176-238: rays from the pose, batch assembly, the chunk loop, both field
+passes, compositing, resampling), end to end, everything resident in HBM: the models' packed
+weights before the timed region, the maps after it.  Random-init 8x256 viewdirs fields (seeds 0/10),
+synthetic Lego camera, perturb=1 (stratified jitter + random sample_pdf draws,
+the reference's own default and what SURVEY.md section 8d prescribes for throughput runs).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): weak scaling.
-The view is 400 x (400 N) pixels; rank r renders flat pixel range r of it and the
-finished [rays, 5] rows are gathered to rank 0 inside the timed step (the one real
-exchange of the path).
+N = 1 (the default, what BENCH_rNN records): BASELINE.json configs[1], the configuration the metric
+is quoted on -- Lego half-res 400x400 = 160 000 rays, 64 coarse + 128 fine samples, 4096-ray chunks.
+The line also carries sub-records measured in the same process after the main timed region:
+  perturb0  the same workload with perturb=0 (the deterministic parity configuration)
+  fp32      the same workload on the exact-fp32 kernel (rays/s, TFLOP/s against the 157.3 TFLOP/s fp32 MFMA peak)
+  c5_n1     the multi-GPU workload (below) on this one GPU: the N=1 point of the scaling curve
+
+N > 1 (torch.distributed.run, one rank per GPU, RCCL): BASELINE.json configs[4] = C5, STRONG scaling.
+A step is one 800x800 frame (640 000 rays, 64+128, chunk 32768) of a fixed list of 200 poses on the
+camera circle (synth.circle_poses(200)); rank r renders flat pixel range r of every frame and the finished
+[rays, 5] rows are gathered to rank 0 -- the gather of frame k runs on a side stream under the render of
+frame k+1 (nerf_shared_amd.dist.OverlappedGather); all gathers are complete when the clock stops.
+Sub-record frames_round_robin: the same K frames dealt whole to the ranks (rank r renders frames
+r, r+N, ...; no data-path collective, the frames stay where they were rendered).
 
 The JSON line also carries
-  roofline     -- the fused bf16 field kernel (fine-pass launches dominate):
-                  algorithmic FLOP (1 186 816 per point) / device time
-                  from hipEvents recorded around every launch on its stream
-                  (nerf_amd_profile_*), against the 2.5 PFLOP/s dense bf16 MFMA peak.
-  cpu_baseline -- the CPU oracle (torch-CPU restatement of the reference, "port")
-                  timed on this box's host cores on a bounded sample of the same
-                  workload (one 4096-ray batch, 64+128), rank 0, N=1 only.
+  roofline     -- the field-MLP kernel: algorithmic FLOP (1 186 816 per point) / device
+                  time from hipEvents recorded around every launch on its stream (nerf_amd_profile_*),
+                  against the 2.5 PFLOP/s dense bf16 MFMA peak.  `traffic` (HBM bytes per launch from
+                  rocprofv3 --pmc passes) is reported only from a profiles/ summary made from THIS build
+                  of the kernels (csrc hash match), else null.
+  cpu_baseline -- the CPU oracle (torch-CPU restatement of the reference, "port") on this box's host cores:
+                  all cores granted to the process and 1 thread, on bounded samples (N = 1 only).
 """
 import argparse
 import ctypes
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -36,90 +49,139 @@ os.environ.setdefault("NERF_AMD_QUIET", "1")
 
 FLOP_PER_POINT = 1186816            # 2 x 593 408 MAC, viewdirs 8x256 MLP
 PEAK_BF16_TFLOPS = 2500.0           # dense bf16 MFMA peak, MI355X_MICROARCH.md
-H, W_PER_GPU, CHUNK = 400, 400, 4096
-N_SAMPLES, N_IMPORTANCE = 64, 128
+PEAK_FP32_TFLOPS = 157.3            # fp32 MFMA peak
 ARCH = dict(D=8, W=256, output_ch=5, skips=[4], use_viewdirs=True, multires=10, multires_views=4)
-RCFG = dict(perturb=0.0, N_importance=N_IMPORTANCE, N_samples=N_SAMPLES, use_viewdirs=True, white_bkgd=True,
-            raw_noise_std=0.0, ndc=False, lindisp=False, near=2.0, far=6.0)
-NDC_FOCAL = None
+N_POSES_C5 = 200
 
-# BASELINE.json configs; c2 is the one the metric is quoted on (the default, and what the driver runs).
+# BASELINE.json configs; c2 is the one the metric is quoted on (the default, and what the driver runs at N=1),
+# c5 the multi-GPU one (the default at N>1).
 WORKLOADS = {
     "c1": dict(name="lego_halfres_400x400_64c_coarse_only_chunk32768", H=400, W=400, chunk=32768, Nc=64, Ni=0),
     "c2": dict(name="lego_halfres_400x400_64c+128f_viewdirs_8x256_chunk4096", H=400, W=400, chunk=4096, Nc=64, Ni=128),
     "c3": dict(name="lego_fullres_800x800_64c+128f_viewdirs_8x256_chunk32768", H=800, W=800, chunk=32768, Nc=64, Ni=128),
     "c4": dict(name="fern_llff_378x504_ndc_64c+64f_viewdirs_8x256_chunk32768", H=378, W=504, chunk=32768, Nc=64, Ni=64,
-               ndc=True, near=0.0, far=1.0, white_bkgd=False, focal=408.0),
+               ndc=True, near=0.0, far=1.0, white_bkgd=False, focal=408.0, raw_noise_std=1.0),
+    "c5": dict(name="lego_fullres_800x800_64c+128f_200_pose_testset_chunk32768", H=800, W=800, chunk=32768, Nc=64, Ni=128,
+               poses=N_POSES_C5),
 }
 
 
-def select_workload(key):
-    global H, W_PER_GPU, CHUNK, N_SAMPLES, N_IMPORTANCE, RCFG, NDC_FOCAL
-    w = WORKLOADS[key]
-    H, W_PER_GPU, CHUNK, N_SAMPLES, N_IMPORTANCE = w["H"], w["W"], w["chunk"], w["Nc"], w["Ni"]
-    RCFG = dict(RCFG, N_samples=w["Nc"], N_importance=w["Ni"], ndc=w.get("ndc", False), near=w.get("near", 2.0),
-                far=w.get("far", 6.0), white_bkgd=w.get("white_bkgd", True))
-    NDC_FOCAL = w.get("focal")
-    return w["name"]
+def renderer_cfg(w, perturb):
+    return dict(perturb=perturb, N_importance=w["Ni"], N_samples=w["Nc"], use_viewdirs=True,
+                white_bkgd=w.get("white_bkgd", True), raw_noise_std=w.get("raw_noise_std", 0.0) if perturb else 0.0,
+                ndc=w.get("ndc", False), lindisp=False, near=w.get("near", 2.0), far=w.get("far", 6.0))
 
 
-def cpu_baseline(torch, synth):
-    """Oracle on host cores: one 4096-ray 64+128 batch, 1 warm-up + best of 2."""
-    from oracle import nerf_oracle as O
+def camera(w, synth):
+    """(K, [poses]) of a workload: the Lego test pose, the Fern-like forward-facing pose, or the 200-pose circle."""
     import numpy as np
-    # the GPU box reports every host core but grants a 16-core share per GPU
-    threads = min(len(os.sched_getaffinity(0)), 16)
-    torch.set_num_threads(threads)
-    K = synth.lego_intrinsics(H, W_PER_GPU)
-    ro, rd = synth.rays_np(H, W_PER_GPU, K, synth.LEGO_C2W, np.arange(80000, 80000 + CHUNK))
-    batch = torch.from_numpy(synth.ray_batch_np(ro, rd, 2.0, 6.0, True))
-    models = []
-    for seed in (0, 10):
-        sd = synth.make_state_dict(seed, 1.0, **{**ARCH, "skips": (4,)})
-        models.append((O.state_dict_to_torch(sd), O.Arch(**ARCH)))
-    cfg = O.RenderCfg(**RCFG)
-    best = float("inf")
-    with torch.no_grad():
-        for i in range(3):
-            t0 = time.perf_counter()
-            O.render_rays(cfg, batch, models[0], models[1])
-            dt = time.perf_counter() - t0
-            if i > 0:
-                best = min(best, dt)
-    return {"value": CHUNK / best, "unit": "rays/s", "cores": threads, "kind": "port",
-            "sample": "one %d-ray batch, 64+128 samples, torch-CPU oracle fp32, best of 2 after warm-up (%.2f s)" % (CHUNK, best)}
+    K = synth.lego_intrinsics(w["H"], w["W"])
+    poses = [synth.LEGO_C2W]
+    if w.get("focal"):      # forward-facing LLFF-style camera (SURVEY.md section 8d, config C4)
+        K[0][0] = K[1][1] = w["focal"]
+        poses = [np.array([[1, 0, 0, 0.05], [0, 1, 0, -0.02], [0, 0, 1, 0.1]], np.float32)]
+    if w.get("poses"):
+        poses = synth.circle_poses(w["poses"])
+    return K, poses
 
 
-def measured_traffic(kernel_tag, chunk_points):
-    """HBM bytes per launch of the field kernel from the committed rocprofv3 --pmc passes
-    (profiles/r01_pmc_summary_*.json, made by tools/pmc_summary.py: FETCH_SIZE x2 + WRITE_SIZE per
-    MI355X_MICROARCH.md), averaged over the coarse and fine launch shapes like `achieved`.
-    PMC counters cannot be read from inside the timed run; None if no summary is present."""
-    import glob
-    best = None
-    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_summary_*.json"))):
+def csrc_hash():
+    """Identity of the kernel sources a profile was made from (profiles/*pmc_summary*.json carry it)."""
+    h = hashlib.sha256()
+    root = os.path.join(REPO, "nerf_shared_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h")) +
+                       glob.glob(os.path.join(root, "*.cpp")) + [os.path.join(root, "Makefile")]):
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(kernel_tag):
+    """HBM bytes per launch of the dominant kernel from committed rocprofv3 --pmc passes
+    (tools/pmc_summary.py: FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md), only if that summary was
+    made from the kernels this process runs (same csrc hash).  PMC counters cannot be read inside the
+    timed run.  Returns (bytes, file) or None."""
+    want = csrc_hash()
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_summary*.json")), reverse=True):
         try:
             with open(path) as f:
                 d = json.load(f)
         except (OSError, ValueError):
             continue
+        if d.get("_meta", {}).get("csrc_hash") != want:
+            continue
         for name, grids in d.items():
-            if kernel_tag not in name:
+            if name == "_meta" or kernel_tag not in name:
                 continue
-            vals = []
-            for pts in chunk_points:
-                g = grids.get(str((pts // 256) * 512))
-                if g and "hbm_bytes_per_launch" in g:
-                    vals.append(g["hbm_bytes_per_launch"]["total"])
-            if len(vals) == len(chunk_points):
-                best = (sum(vals) / len(vals), os.path.basename(path))
-                continue
-            # one workgroup per CU walks the tiles: coarse and fine launches share the grid (256 CUs x 512
-            # threads) and the summary's mean per launch already averages the two shapes
-            g = grids.get(str(256 * 512))
-            if g and "hbm_bytes_per_launch" in g and all(pts >= 256 * 256 for pts in chunk_points):
-                best = (g["hbm_bytes_per_launch"]["total"], os.path.basename(path))
-    return best
+            tot = n = 0
+            for g in grids.values():
+                if "hbm_bytes_per_launch" in g:
+                    k = g["FETCH_SIZE"]["launches"]
+                    tot += g["hbm_bytes_per_launch"]["total"] * k
+                    n += k
+            if n:
+                return tot / n, os.path.basename(path)
+    return None
+
+
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(torch, synth, w):
+    """The oracle on host cores (rank 0, N=1).  C2: one 4096-ray 64+128 batch on all granted cores (1 warm-up +
+    best of 2) and a 512-ray batch on 1 thread; C1: the full 400x400 coarse-only view, chunk 32768, wall clock
+    (BASELINE.md "CPU-baseline plan").  Bounded to roughly 20-40 s."""
+    from oracle import nerf_oracle as O
+    import numpy as np
+    # the GPU box reports every host core but grants a 16-core share per GPU
+    threads = min(len(os.sched_getaffinity(0)), 16)
+    K, poses = camera(w, synth)
+    H, W = w["H"], w["W"]
+    models = []
+    for seed in (0, 10):
+        sd = synth.make_state_dict(seed, 1.0, **{**ARCH, "skips": (4,)})
+        models.append((O.state_dict_to_torch(sd), O.Arch(**ARCH)))
+    cfg = O.RenderCfg(**renderer_cfg(w, 0.0))
+    fine = models[1] if w["Ni"] > 0 else None
+    out = {"unit": "rays/s", "kind": "port", "cpu_model": cpu_model_name(), "host_cores_visible": os.cpu_count()}
+    with torch.no_grad():
+        if w["Ni"] == 0:          # C1: one whole coarse-only view
+            torch.set_num_threads(threads)
+            t0 = time.perf_counter()
+            O.render(cfg, H, W, K, models[0], None, chunk=w["chunk"], c2w=torch.from_numpy(poses[0]), retraw=False)
+            dt = time.perf_counter() - t0
+            out.update(value=H * W / dt, cores=threads,
+                       sample="one full %dx%d coarse-only view (64 samples), chunk %d, torch-CPU oracle fp32, wall clock %.2f s"
+                              % (H, W, w["chunk"], dt))
+            return out
+
+        def timed(n_rays, n_threads, reps):
+            torch.set_num_threads(n_threads)
+            ro, rd = synth.rays_np(H, W, K, poses[0], np.arange(H * W // 2, H * W // 2 + n_rays))
+            batch = torch.from_numpy(synth.ray_batch_np(ro, rd, cfg.near, cfg.far, True))
+            best = float("inf")
+            for i in range(reps + 1):
+                t0 = time.perf_counter()
+                O.render_rays(cfg, batch, models[0], fine)
+                if i > 0:
+                    best = min(best, time.perf_counter() - t0)
+            return n_rays / best, best
+        v, best = timed(w["chunk"] if w["chunk"] <= 4096 else 4096, threads, 2)
+        out.update(value=v, cores=threads,
+                   sample="one 4096-ray batch, %d+%d samples, torch-CPU oracle fp32, best of 2 after warm-up (%.2f s)" % (w["Nc"], w["Ni"], best))
+        v1, best1 = timed(512, 1, 1)
+        out["single_thread"] = {"value": v1, "cores": 1,
+                                "sample": "one 512-ray batch, same workload, 1 torch thread, after warm-up (%.2f s)" % best1}
+        torch.set_num_threads(threads)
+    return out
 
 
 def main():
@@ -129,19 +191,19 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-subrecords", action="store_true")
+    ap.add_argument("--perturb", type=float, default=1.0)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     args = ap.parse_args()
-    workload_name = select_workload(args.workload)
+    from nerf_shared_amd import render_utils as _ru
     if os.environ.get("NERF_AMD_OVERLAP_CHUNKS") == "1":      # A/B knob: two-stream chunk pipeline of render_batch
-        from nerf_shared_amd import render_utils as _ru
         _ru.Renderer.overlap_chunks = True
     if os.environ.get("NERF_AMD_FUSE_CHUNKS") == "0":         # A/B knob: one render_rays call per chunk
-        from nerf_shared_amd import render_utils as _ru
         _ru.Renderer.fuse_chunk_launches = False
 
     import torch
     import torch.distributed as dist
-    from nerf_shared_amd import _lib, dist as nd, nerf, render_utils, synth, utils
+    from nerf_shared_amd import _lib, dist as nd, nerf, render_utils, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -151,6 +213,8 @@ def main():
                          % (args.gpus, args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device; there is no CPU path")
+    key = args.workload or ("c5" if world > 1 else "c2")
+    w = WORKLOADS[key]
     # NERF_AMD_DIST_BACKEND=gloo rehearses the N>1 path with several ranks on one GPU (no RCCL)
     backend = os.environ.get("NERF_AMD_DIST_BACKEND", "nccl")
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())
@@ -164,93 +228,123 @@ def main():
         m = nerf.NeRF(**ARCH)
         m.load_state_dict(synth.torch_state_dict(seed, 1.0, **{**ARCH, "skips": (4,)}))
         m.precision = args.precision
-        models.append(m.to(dev))
-    renderer = render_utils.Renderer(**RCFG)
-
-    Wimg = W_PER_GPU * world
-    K = synth.lego_intrinsics(H, W_PER_GPU)
-    pose = synth.LEGO_C2W
-    if NDC_FOCAL:      # forward-facing LLFF-style camera
-        K[0][0] = K[1][1] = NDC_FOCAL
-        K[1][2] = 0.5 * H
-        import numpy as np
-        pose = np.array([[1, 0, 0, 0.05], [0, 1, 0, -0.02], [0, 0, 1, 0.1]], np.float32)
-    K[0][2] = 0.5 * Wimg
-    n_total = H * Wimg
-    lo, hi = nd.shard_range(n_total, rank, world)
-    rays = utils.make_ray_batch(H, Wimg, K, pose, RCFG["near"], RCFG["far"], True, RCFG["ndc"], device=dev,
-                                pix0=lo, n=hi - lo)
-    torch.cuda.synchronize()
-
-    def step():
-        ret = renderer.render_batch(models[0], models[1], rays, CHUNK, False)
-        if world > 1:
-            return nd.gather_rows(nd.pack_maps(ret), n_total, 0)
-        return ret
+        models.append(m.to(dev).requires_grad_(False))
+    fine_model = models[1]
+    torch.manual_seed(1234 + rank)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
-        if world > 1:      # communicator set-up must not land in the timed region, whatever --warmup is
-            nd.gather_rows(torch.zeros(hi - lo, 5, device=dev), n_total, 0)
-        for _ in range(args.warmup):
-            step()
-        fence()
-        _lib.lib.nerf_amd_profile_enable(1)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        fence()
-        dt = time.perf_counter() - t0
-        _lib.lib.nerf_amd_profile_enable(0)
+    def collect_profile():
+        launches, ms, pts = (ctypes.c_int64 * 2)(), (ctypes.c_double * 2)(), (ctypes.c_double * 2)()
+        _lib.lib.nerf_amd_profile_collect(launches, ms, pts)
+        return [(int(launches[c]), float(ms[c]), float(pts[c])) for c in range(2)]
 
-    launches = (ctypes.c_int64 * 2)()
-    ms = (ctypes.c_double * 2)()
-    pts = (ctypes.c_double * 2)()
-    _lib.lib.nerf_amd_profile_collect(launches, ms, pts)
+    def run(wk, perturb, steps, warmup, precision=None, mode="pixel_ranges", profile=False):
+        """Time `steps` steps of workload wk.  Returns (seconds [max over ranks], rays per step, profile)."""
+        for m in models:
+            m.precision = precision or args.precision
+        renderer = render_utils.Renderer(**renderer_cfg(wk, perturb))
+        K, poses = camera(wk, synth)
+        H, W, chunk = wk["H"], wk["W"], wk["chunk"]
+        poses_t = [torch.from_numpy(p) for p in poses]
+        fm = fine_model if wk["Ni"] > 0 else None
+
+        def frames(first, count):
+            if world == 1:
+                for k in range(first, first + count):
+                    renderer.render(H, W, K, models[0], fm, chunk=chunk, c2w=poses_t[k % len(poses_t)], retraw=False)
+            elif mode == "pixel_ranges":
+                nd.render_poses_gathered(renderer, H, W, K, chunk, [poses_t[k % len(poses_t)] for k in range(first, first + count)],
+                                         models[0], fm, on_frame=lambda i, rgb, disp, acc: None)
+            else:       # whole frames round-robin: rank r renders frames r, r + world, ...
+                for k in range(first + rank, first + count, world):
+                    renderer.render(H, W, K, models[0], fm, chunk=chunk, c2w=poses_t[k % len(poses_t)], retraw=False)
+
+        with torch.no_grad():
+            if world > 1:      # communicator set-up must not land in the timed region, whatever --warmup is
+                nd.gather_rows(torch.zeros(nd.shard_sizes(H * W, world)[rank], 5, device=dev), H * W, 0)
+            frames(0, warmup)
+            fence()
+            if profile:
+                collect_profile()
+                _lib.lib.nerf_amd_profile_enable(1)
+            t0 = time.perf_counter()
+            frames(warmup, steps)
+            fence()
+            dt = time.perf_counter() - t0
+            prof = None
+            if profile:
+                _lib.lib.nerf_amd_profile_enable(0)
+                prof = collect_profile()
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), H * W, prof
+
+    dt, rays_per_step, prof = run(w, args.perturb, args.steps, args.warmup, profile=True)
     cls = 1 if args.precision == "bf16" else 0
+    launches, kern_ms, kern_pts = prof[cls]
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    sub = {}
+    if not args.no_subrecords:
+        if world == 1 and key == "c2":
+            d0, n0, _ = run(w, 0.0, max(2, args.steps // 4), 1)
+            sub["perturb0"] = {"value": n0 * max(2, args.steps // 4) / d0, "unit": "rays/s",
+                               "ms_per_step": d0 / max(2, args.steps // 4) * 1e3, "steps": max(2, args.steps // 4)}
+            if args.precision == "bf16":
+                d32, n32, p32 = run(w, args.perturb, 2, 1, precision="fp32", profile=True)
+                l32, ms32, pts32 = p32[0]
+                sub["fp32"] = {"value": n32 * 2 / d32, "unit": "rays/s", "ms_per_step": d32 / 2 * 1e3, "steps": 2, "dtype": "f32",
+                               "roofline": {"bound": "mfma", "achieved": pts32 * FLOP_PER_POINT / (ms32 / 1e3) / 1e12 if ms32 else 0.0,
+                                            "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                                            "frac": (pts32 * FLOP_PER_POINT / (ms32 / 1e3) / 1e12 / PEAK_FP32_TFLOPS) if ms32 else 0.0,
+                                            "kernel": "mlp_f32_kernel", "launches": l32, "avg_launch_ms": ms32 / l32 if l32 else None}}
+            n5 = max(3, args.steps // 4)
+            d5, r5, _ = run(WORKLOADS["c5"], args.perturb, n5, 1)
+            sub["c5_n1"] = {"value": r5 * n5 / d5, "unit": "rays/s", "ms_per_step": d5 / n5 * 1e3, "steps": n5,
+                            "workload": WORKLOADS["c5"]["name"],
+                            "note": "the N>1 workload on one GPU: the N=1 point of the strong-scaling curve"}
+        if world > 1:
+            drr, rrr, _ = run(w, args.perturb, args.steps, min(args.warmup, 1), mode="frames_round_robin")
+            sub["frames_round_robin"] = {"value": rrr * args.steps / drr, "unit": "rays/s", "ms_per_step": drr / args.steps * 1e3,
+                                         "steps": args.steps,
+                                         "note": "whole frames dealt round-robin, no data-path collective, frames stay on their rank"}
 
     if rank == 0:
-        rays_per_step = n_total
         value = rays_per_step * args.steps / dt
-        kern_s = ms[cls] / 1e3
-        achieved = (pts[cls] * FLOP_PER_POINT / kern_s / 1e12) if kern_s > 0 else 0.0
-        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3
-        traffic = (measured_traffic("mlp_bf16_s16_kernel", [CHUNK * N_SAMPLES, CHUNK * (N_SAMPLES + N_IMPORTANCE)])
-                   if cls == 1 and args.workload == "c2" else None)
+        kern_s = kern_ms / 1e3
+        achieved = (kern_pts * FLOP_PER_POINT / kern_s / 1e12) if kern_s > 0 else 0.0
+        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_FP32_TFLOPS
+        kernel = "mlp_bf16_s16_kernel" if cls == 1 else "mlp_f32_kernel"
+        traffic = measured_traffic(kernel) if key == "c2" else None
+        chunk_rays = min(w["chunk"], rays_per_step)
         out = {
             "metric": "rays_per_sec", "value": value, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": workload_name,
-                       "rays_per_step": rays_per_step, "rays_per_gpu_per_step": H * W_PER_GPU, "chunk": CHUNK,
-                       "N_samples": N_SAMPLES, "N_importance": N_IMPORTANCE, "weights": "random-init seeds 0/10",
-                       "parallelism": "ray-range shards x%d, one gather of [rays,5] to rank 0 per step" % world
+            "config": {"workload": w["name"], "entry": "Renderer.render(c2w=pose, retraw=False)",
+                       "rays_per_step": rays_per_step, "chunk": w["chunk"], "perturb": args.perturb,
+                       "N_samples": w["Nc"], "N_importance": w["Ni"], "weights": "random-init seeds 0/10",
+                       "parallelism": ("flat pixel-range shards x%d of every frame, gather of [rays,5] rows to rank 0 "
+                                       "overlapped with the next frame (strong scaling over a fixed %d-pose list)" % (world, N_POSES_C5))
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic[0] if traffic else None,
                          "traffic_unit": "bytes per launch (HBM, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)",
                          "traffic_source": ("profiles/" + traffic[1]) if traffic else None,
-                         "traffic_note": "measured traffic = algorithmic bytes + one L2 fill of the 1.2 MB bf16 weight stream per XCD "
-                                         "(8 x 1.2 MB; FETCH_SIZE counts L2 misses, including those the MALL serves); "
-                                         "the kernel is MFMA-bound, 21.6 MB per 0.43 ms launch is 50 GB/s",
-                         "algorithmic_bytes_per_launch": CHUNK * 44 + (CHUNK * (2 * N_SAMPLES + N_IMPORTANCE) // 2) * 20,
-                         "kernel": "mlp_bf16_s16_kernel" if cls == 1 else "mlp_f32_kernel",
-                         "launches": int(launches[cls]),
-                         "avg_launch_ms": (ms[cls] / launches[cls]) if launches[cls] else None,
-                         "flop_per_point": FLOP_PER_POINT, "points": pts[cls], "rank": 0},
+                         "csrc_hash": csrc_hash(),
+                         "algorithmic_bytes_per_launch": chunk_rays * 44 + (chunk_rays * (2 * w["Nc"] + w["Ni"]) // (2 if w["Ni"] else 1)) * 20,
+                         "kernel": kernel, "launches": launches,
+                         "avg_launch_ms": (kern_ms / launches) if launches else None,
+                         "flop_per_point": FLOP_PER_POINT, "points": kern_pts, "rank": 0},
         }
-        if world == 1 and not args.no_cpu_baseline and args.workload == "c2":
-            out["cpu_baseline"] = cpu_baseline(torch, synth)
+        out.update(sub)
+        if world == 1 and not args.no_cpu_baseline and key in ("c1", "c2"):
+            out["cpu_baseline"] = cpu_baseline(torch, synth, w)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -23,33 +23,105 @@ def shard_sizes(n, world):
     return [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
 
 
-def gather_rows(local, n_total, dst=0, group=None):
-    """Gather row-shards (split by shard_range) of a [n_local, C] tensor to `dst`.
-    Returns the [n_total, C] tensor on dst, None elsewhere.  One collective."""
+def _start_gather(local, n_total, dst, group, async_op):
+    """Issue the one collective of gather_rows.  Returns (work or None, finish) where finish() -> the
+    [n_total, C] tensor on dst (None elsewhere) once the collective is complete."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    if world == 1:
-        return local
     sizes = shard_sizes(n_total, world)
     assert local.shape[0] == sizes[rank], (local.shape, sizes, rank)
     C = local.shape[1]
-    if local.is_cuda and dist.get_backend(group) == "gloo":
-        # rehearsal path (several ranks sharing one GPU, no RCCL): stage through the host
-        out = gather_rows(local.cpu(), n_total, dst, group)
-        return out.to(local.device) if out is not None else None
     if max(sizes) == min(sizes):
         out = torch.empty(n_total, C, device=local.device, dtype=local.dtype) if rank == dst else None
-        dist.gather(local.contiguous(), list(out.split(sizes[0])) if rank == dst else None, dst=dst, group=group)
-        return out
+        work = dist.gather(local.contiguous(), list(out.split(sizes[0])) if rank == dst else None, dst=dst, group=group,
+                           async_op=async_op)
+        return work, (lambda: out)
     # ragged shards: pad to the largest, gather, trim
     m = max(sizes)
     pad = torch.zeros(m, C, device=local.device, dtype=local.dtype)
     pad[:local.shape[0]] = local
     bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-    dist.gather(pad, bufs, dst=dst, group=group)
-    if rank != dst:
-        return None
-    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], 0)
+    work = dist.gather(pad, bufs, dst=dst, group=group, async_op=async_op)
+    return work, (lambda: torch.cat([b[:s] for b, s in zip(bufs, sizes)], 0) if rank == dst else None)
+
+
+def gather_rows(local, n_total, dst=0, group=None):
+    """Gather row-shards (split by shard_range) of a [n_local, C] tensor to `dst`.
+    Returns the [n_total, C] tensor on dst, None elsewhere.  One collective."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return local
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal path (several ranks sharing one GPU, no RCCL): stage through the host
+        out = gather_rows(local.cpu(), n_total, dst, group)
+        return out.to(local.device) if out is not None else None
+    _, finish = _start_gather(local, n_total, dst, group, False)
+    return finish()
+
+
+class OverlappedGather:
+    """The per-frame gather of SURVEY.md section 8e, taken off the render's critical path: ``submit(rows)``
+    issues the gather of frame k's finished rows on a side stream (RCCL) / as an asynchronous operation
+    (gloo on CPU tensors) and returns at once, so the caller enqueues the render of frame k+1 while the rows
+    of frame k cross xGMI; ``collect()`` hands the gathered frames back in submission order (None on ranks
+    other than `dst`).  At most `depth` gathers are kept in flight (the oldest is completed first).
+
+    Stream contract on the GPU: the side stream waits for an event recorded on the caller's stream at
+    submit (the rows are complete), the rows are kept alive and marked as used by the side stream, and
+    collect() makes the caller's current stream wait for the gathers it returns."""
+
+    def __init__(self, n_total, dst=0, group=None, depth=2):
+        self.n_total, self.dst, self.group, self.depth = n_total, dst, group, max(1, int(depth))
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._pending = []        # (finish, work, done_event, keepalive) in submission order
+        self._ready = []
+        self._side = None
+        self.submitted = 0
+
+    def _complete_oldest(self):
+        finish, work, done, _keep = self._pending.pop(0)
+        if done is not None:                       # GPU: the caller's stream waits for the side stream's gather
+            torch.cuda.current_stream().wait_event(done)
+        elif work is not None:
+            work.wait()
+        res = finish()
+        if res is not None and res.is_cuda:        # allocated under the side stream, consumed on the caller's
+            res.record_stream(torch.cuda.current_stream(res.device))
+        self._ready.append(res)
+
+    def submit(self, rows):
+        self.submitted += 1
+        if self.world == 1:
+            self._ready.append(rows)
+            return
+        while len(self._pending) >= self.depth:
+            self._complete_oldest()
+        if rows.is_cuda and dist.get_backend(self.group) == "gloo":     # rehearsal only: synchronous, through the host
+            self._ready.append(gather_rows(rows, self.n_total, self.dst, self.group))
+            return
+        if rows.is_cuda:
+            if self._side is None:
+                self._side = torch.cuda.Stream(rows.device)
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(rows.device))
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ready)
+                work, finish = _start_gather(rows, self.n_total, self.dst, self.group, True)
+                work.wait()                        # stream-level: the side stream waits for the collective, the host does not
+                done = torch.cuda.Event()
+                done.record(self._side)
+            rows.record_stream(self._side)
+            self._pending.append((finish, work, done, rows))
+        else:
+            work, finish = _start_gather(rows, self.n_total, self.dst, self.group, True)
+            self._pending.append((finish, work, None, rows))
+
+    def collect(self):
+        """All frames submitted so far, oldest first (completes what is still in flight)."""
+        while self._pending:
+            self._complete_oldest()
+        out, self._ready = self._ready, []
+        return out
 
 
 def pack_maps(ret):
@@ -89,6 +161,47 @@ def render_image_sharded(renderer, H, W, K, c2w, coarse_model, fine_model, chunk
     if full is None:
         return None
     return full[:, 0:3].reshape(H, W, 3), full[:, 3].reshape(H, W), full[:, 4].reshape(H, W)
+
+
+def render_poses_gathered(renderer, H, W, K, chunk, batch_c2w, coarse_model, fine_model, group=None, depth=2,
+                          on_frame=None):
+    """The C5 workload (BASELINE.json configs[4]; the pose loop of render_utils.py:293-319 over the ranks of one
+    node): every pose is rendered by all ranks together -- rank r takes flat pixel range r of the frame and
+    generates its own rays from (K, c2w) -- and the finished [n, 5] rows (rgb, disp, acc) are gathered to
+    rank 0 with the gather of frame k overlapped with the render of frame k+1 (OverlappedGather).
+    Returns the frames as [(rgb [H,W,3], disp [H,W], acc [H,W]), ...] on rank 0 (or hands each to
+    on_frame(i, rgb, disp, acc) and returns the count), None / count elsewhere."""
+    from . import utils
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_range(H * W, rank, world)
+    dev = next(coarse_model.parameters()).device
+    gatherer = OverlappedGather(H * W, 0, group, depth)
+    frames, n_done = [], 0
+
+    def drain(rows_list):
+        nonlocal n_done
+        for full in rows_list:
+            if full is not None:
+                img = (full[:, 0:3].reshape(H, W, 3), full[:, 3].reshape(H, W), full[:, 4].reshape(H, W))
+                if on_frame is not None:
+                    on_frame(n_done, *img)
+                else:
+                    frames.append(img)
+            n_done += 1
+
+    for c2w in batch_c2w:
+        batch = utils.make_ray_batch(H, W, K, c2w, renderer.near, renderer.far, renderer.use_viewdirs, renderer.ndc,
+                                     device=dev, pix0=lo, n=hi - lo)
+        ret = renderer.render_batch(coarse_model, fine_model, batch, chunk, False)
+        gatherer.submit(pack_maps(ret))
+        if len(gatherer._ready) >= 4:              # hand finished frames on without waiting for the ones in flight
+            ready, gatherer._ready = gatherer._ready, []
+            drain(ready)
+    drain(gatherer.collect())
+    if on_frame is not None:
+        return n_done
+    return frames if rank == 0 else None
 
 
 def render_poses_sharded(renderer, H, W, K, chunk, batch_c2w, coarse_model, fine_model, save_directory,

@@ -1,0 +1,132 @@
+"""Full-frame GPU parity (-m gpu) at the BASELINE.json sizes the crop-sized goldens do not reach:
+
+  C3  Lego 800x800, 64+128, view directions, chunk 32768, through Renderer.render(c2w=)
+  C4  Fern-like 378x504, NDC rays, 64+64, chunk 32768, through Renderer.render(c2w=)
+
+A whole frame is rendered through render(c2w=) (render_utils.py:176-238: get_rays, view directions,
+NDC warp, batch assembly, the chunk loop with its ragged last chunk, the reshape) in both precisions.
+The oracle cannot render 640 000 rays in test time, so a strided subset of the frame's rays is
+compared against it:
+  * fp32 mode, coarse maps (rgb0 / disp0 / acc0): the oracle end to end on the subset     -> tight
+  * fp32 mode, fine pass: staged -- render_rays on the subset reproduces the frame's values bit for bit
+    (chunk invariance) and returns z_vals / raw; the oracle's fine field + compositing on those
+    z_vals                                                                                 -> tight
+  * the G8 referee crop is cut OUT OF the full frame and compared with the reference's image (golden)
+  * bf16 mode: PSNR of the subset against the oracle's fp32 maps, gated a few dB under the measured value
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+os.environ.setdefault("NERF_AMD_QUIET", "1")
+
+pytestmark = pytest.mark.gpu
+
+from nerf_shared_amd import synth  # noqa: E402
+from oracle import nerf_oracle as O  # noqa: E402
+from test_gpu_parity import BASE, G5_TOL, VD, amd, close, cpu_model, gpu_model, oracle_batch, psnr, report  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "-m gpu tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+# bf16 PSNR gates (dB) on the strided subset, a few dB under the measured values
+FRAME_BF16_GATES = {"c3": 30.0, "c4": 30.0}
+
+
+def frame_check(dev, name, cfg, H, W, K, c2w, seeds, chunk, stride):
+    _, render_utils, _ = amd()
+    sc, sf, sharpen = seeds
+    N = H * W
+    idx = np.arange(stride // 2, N, stride)
+    batch = oracle_batch(cfg, H, W, K, c2w, idx)                         # the oracle's own ray math on the subset
+    coarse_cpu, fine_cpu = cpu_model(sc, sharpen, **VD), cpu_model(sf, sharpen, **VD)
+    r = render_utils.Renderer(**cfg)
+    c2w_t = torch.from_numpy(np.asarray(c2w, np.float32))
+    measured = {"rays": int(N), "subset": int(idx.size), "chunks": -(-N // chunk)}
+    frames = {}
+    for prec in ("fp32", "bf16"):
+        c, f = gpu_model(dev, sc, sharpen, prec, **VD), gpu_model(dev, sf, sharpen, prec, **VD)
+        rgb, disp, acc, extras = r.render(H, W, K, c, f, chunk=chunk, c2w=c2w_t, retraw=False)
+        assert rgb.shape == (H, W, 3) and disp.shape == (H, W) and acc.shape == (H, W)
+        assert sorted(extras) == ["acc0", "disp0", "rgb0", "z_std"] and extras["rgb0"].shape == (H, W, 3)
+        flat = {"rgb_map": rgb.reshape(N, 3), "disp_map": disp.reshape(N), "acc_map": acc.reshape(N),
+                "rgb0": extras["rgb0"].reshape(N, 3), "disp0": extras["disp0"].reshape(N), "acc0": extras["acc0"].reshape(N),
+                "z_std": extras["z_std"].reshape(N)}
+        frames[prec] = flat
+        sub = {k: v[torch.from_numpy(idx).to(dev)].cpu() for k, v in flat.items()}
+        # render_rays on the subset's rays = the frame's values at those pixels, bit for bit (ray generation in the
+        # frame kernel vs the oracle's ray math may differ by an ulp, so feed the frame's own rays)
+        from nerf_shared_amd import utils as amd_utils
+        own = amd_utils.make_ray_batch(H, W, K, c2w_t, cfg["near"], cfg["far"], True, cfg["ndc"], device=dev)[torch.from_numpy(idx).to(dev)].contiguous()
+        if prec == "fp32":
+            close(own[:, :6], batch[:, :6], atol=2e-6, rtol=2e-6)                   # ray math of the frame kernel vs the oracle
+            close(own[:, 8:], batch[:, 8:], atol=2e-6, rtol=2e-6)
+        part = {k: v.cpu() for k, v in r.render_rays(own, c, f, retraw=True, retweights=True).items()}
+        for k in sub:
+            assert torch.equal(torch.nan_to_num(part[k]), torch.nan_to_num(sub[k])), (prec, k)
+        own_cpu = own.cpu()
+        if prec == "fp32":
+            # coarse maps: oracle end to end on the same rays -> tight
+            ref0 = O.render_rays(O.RenderCfg(**dict(cfg, N_importance=0)), own_cpu, coarse_cpu, None)
+            for k0, k in (("rgb_map", "rgb0"), ("disp_map", "disp0"), ("acc_map", "acc0")):
+                close(sub[k], ref0[k0], atol=G5_TOL[k], rtol=2e-4)
+            # fine pass, staged on the GPU's own z_vals -> tight
+            z = part["z_vals"]
+            assert bool((z[:, 1:] >= z[:, :-1]).all())
+            pts = own_cpu[:, None, 0:3] + own_cpu[:, None, 3:6] * z[..., None]
+            raw = O.nerf_forward(fine_cpu[0], fine_cpu[1], pts, own_cpu[:, 8:11])
+            close(part["raw"], raw, atol=2e-4, rtol=2e-4)
+            rgb_o, disp_o, acc_o, w_o, _ = O.raw2outputs(part["raw"], z, own_cpu[:, 3:6], cfg["white_bkgd"], None)
+            close(sub["rgb_map"], rgb_o, atol=1e-5, rtol=1e-5)
+            close(sub["acc_map"], acc_o, atol=1e-5, rtol=1e-5)
+            close(sub["disp_map"], disp_o, atol=1e-5, rtol=1e-4)
+            measured["fp32_raw_max"] = float((part["raw"] - raw).abs().max())
+            measured["subset_rgb_var"] = float(sub["rgb_map"].var())
+            measured["subset_acc_mean"] = float(sub["acc_map"].mean())
+            ref_full = O.render_rays(O.RenderCfg(**cfg), own_cpu, coarse_cpu, fine_cpu)       # end-to-end oracle maps (PSNR referee)
+            measured["fp32_psnr_vs_oracle"] = psnr(sub["rgb_map"], ref_full["rgb_map"])
+            frames["oracle_subset"] = ref_full
+        else:
+            measured["bf16_psnr_vs_oracle"] = psnr(sub["rgb_map"], frames["oracle_subset"]["rgb_map"])
+            measured["bf16_psnr_rgb0_vs_oracle"] = psnr(sub["rgb0"], frames["oracle_subset"]["rgb0"])
+            measured["bf16_psnr_vs_fp32_frame"] = psnr(flat["rgb_map"], frames["fp32"]["rgb_map"])
+    return measured, frames
+
+
+def test_c3_full_frame_800x800(dev, golden):
+    """BASELINE configs[2]: Lego full_res 800x800 coarse+fine with viewdirs, chunk 32768 (19 full chunks + one
+    of 17 472 rays), fixed test pose."""
+    H = W = 800
+    K = synth.lego_intrinsics(H, W)
+    measured, frames = frame_check(dev, "c3", dict(BASE), H, W, K, synth.LEGO_C2W, (1, 19, 3.0), 32768, 1237)
+    # the G8 referee crop, cut out of the full frame (fp32 against the reference's image; bf16 gated on PSNR)
+    g = golden("g8_psnr_crop")
+    pix = torch.from_numpy(g["pixel_index"]).to(dev)
+    for prec, gate in (("fp32", 50.0), ("bf16", 30.0)):
+        crop = frames[prec]["rgb_map"][pix]
+        measured["crop_%s_psnr_vs_reference" % prec] = psnr(crop, g["rgb_c19"])
+        assert measured["crop_%s_psnr_vs_reference" % prec] > gate, measured
+    close(frames["fp32"]["rgb0"][pix], g["rgb0_c19"], atol=2e-4)
+    report("frame_c3", measured)
+    assert measured["subset_rgb_var"] > 1e-2                                # the frame has content
+    assert measured["fp32_psnr_vs_oracle"] > 60.0, measured
+    assert measured["bf16_psnr_vs_oracle"] > FRAME_BF16_GATES["c3"], measured
+
+
+def test_c4_full_frame_fern_ndc(dev):
+    """BASELINE configs[3]: Fern-like LLFF frame, 378x504, NDC rays, near/far 0/1, 64+64, black background,
+    chunk 32768 (5 full chunks + one of 26 672 rays); deterministic draws (perturb 0, no noise) for parity."""
+    H, W, focal = 378, 504, 408.0
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+    c2w = np.array([[1, 0, 0, 0.05], [0, 1, 0, -0.02], [0, 0, 1, 0.1]], np.float32)
+    cfg = dict(BASE, ndc=True, near=0.0, far=1.0, N_importance=64, white_bkgd=False)
+    measured, frames = frame_check(dev, "c4", cfg, H, W, K, c2w, (1, 12, 3.0), 32768, 373)
+    report("frame_c4", measured)
+    assert measured["fp32_psnr_vs_oracle"] > 60.0, measured
+    assert measured["bf16_psnr_vs_oracle"] > FRAME_BF16_GATES["c4"], measured

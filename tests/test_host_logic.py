@@ -178,6 +178,23 @@ for n in (10, 11, 4096):
     ok = ok and ((got8 is not None and got8.dtype == torch.uint8 and torch.equal(got8, full8)) if rank == 0 else got8 is None)
     # round-robin frame assignment of render_poses_sharded
     ok = ok and list(range(rank, n, world)) == [i for i in range(n) if i %% world == rank]
+# the overlapped per-frame gather: frames come back in submission order with the right rows, whatever the
+# depth of the in-flight window, for even and ragged shards; submit() does not complete the gather itself
+for n, depth in ((12, 1), (12, 2), (11, 2), (4097, 3)):
+    lo, hi = nd.shard_range(n, rank, world)
+    g = nd.OverlappedGather(n, 0, None, depth)
+    frames = [torch.arange(n * 5, dtype=torch.float32).reshape(n, 5) * (k + 1) + k for k in range(7)]
+    got = []
+    for k, full in enumerate(frames):
+        g.submit(full[lo:hi].clone())
+        ok = ok and len(g._pending) <= depth and len(g._pending) >= 1
+        if k == 3:
+            got += g.collect()                     # a mid-sequence collect drains what is in flight, in order
+            ok = ok and len(g._pending) == 0
+    got += g.collect()
+    ok = ok and len(got) == 7 and g.submitted == 7
+    for k, (a, b) in enumerate(zip(got, frames)):
+        ok = ok and ((a is not None and torch.equal(a, b)) if rank == 0 else a is None)
 dist.barrier()
 dist.destroy_process_group()
 sys.exit(0 if ok else 1)
@@ -189,7 +206,13 @@ def test_gather_rows_gloo_world2(tmp_path):
     script.write_text(_WORKER % {"repo": REPO})
     port = str(29500 + os.getpid() % 2000)
     procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", port]) for r in range(2)]
-    codes = [p.wait(timeout=180) for p in procs]
+    try:
+        codes = [p.wait(timeout=180) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
     assert codes == [0, 0]
 
 

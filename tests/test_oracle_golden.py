@@ -111,6 +111,11 @@ G5_CASES = {
     "novd_s1": (dict(use_viewdirs=False), NOVD, (2, 12, 3.0), False),
     "fern_s1": (dict(N_importance=64, ndc=True, near=0.0, far=1.0, white_bkgd=False,
                      raw_noise_std=1.0, perturb=1.0), VD, (1, 11, 3.0), True),
+    # fine fields with content (seed 11's fine pass is empty space)
+    "det_c19": (dict(), VD, (1, 19, 3.0), False),
+    "perturb_c12": (dict(perturb=1.0), VD, (1, 12, 3.0), True),
+    "fern_c12": (dict(N_importance=64, ndc=True, near=0.0, far=1.0, white_bkgd=False,
+                      raw_noise_std=1.0, perturb=1.0), VD, (1, 12, 3.0), True),
 }
 G5_BASE = dict(perturb=0.0, N_importance=128, N_samples=64, use_viewdirs=True, white_bkgd=True,
                raw_noise_std=0.0, ndc=False, lindisp=False, near=2.0, far=6.0)
@@ -191,9 +196,13 @@ def test_g8_psnr_crop(golden):
     ro, rd = synth.rays_np(H, W, K, synth.LEGO_C2W, g["pixel_index"])
     rays = torch.from_numpy(np.stack([ro, rd], 0))
     cfg = O.RenderCfg(**G5_BASE)
-    coarse, fine = model(1, 3.0, **VD), model(11, 3.0, **VD)
-    rgb, disp, acc, extras = O.render(cfg, H, W, K, coarse, fine, chunk=4096, rays=rays, retraw=False)
-    close(rgb, g["rgb_s1"], 2e-6)
-    close(extras["rgb0"], g["rgb0_s1"], 2e-6)
-    psnr = float(O.mse2psnr(O.img2mse(rgb, torch.from_numpy(g["rgb_s1"])) + 1e-20))
-    assert psnr > 100.0
+    coarse = model(1, 3.0, **VD)
+    for tag, fine_seed in (("s1", 11), ("c19", 19), ("c12", 12)):
+        rgb, disp, acc, extras = O.render(cfg, H, W, K, coarse, model(fine_seed, 3.0, **VD), chunk=4096, rays=rays, retraw=False)
+        close(rgb, g["rgb_" + tag], 2e-6)
+        close(acc, g["acc_" + tag], 2e-6)
+        close(extras["rgb0"], g["rgb0_" + tag], 2e-6)
+        psnr = float(O.mse2psnr(O.img2mse(rgb, torch.from_numpy(g["rgb_" + tag])) + 1e-20))
+        assert psnr > 100.0
+    # the referee legs have content: a constant image would make any PSNR gate vacuous
+    assert g["rgb_c19"].var() > 1e-2 and g["rgb_c12"].var() > 1e-2 and g["acc_c12"].var() > 1e-2

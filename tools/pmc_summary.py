@@ -35,6 +35,11 @@ def main(src, dst):
                 rd = c["FETCH_SIZE"]["mean_per_launch"] * 1024 * 2
                 wr = c["WRITE_SIZE"]["mean_per_launch"] * 1024
                 c["hbm_bytes_per_launch"] = {"read_corrected_x2": rd, "write": wr, "total": rd + wr}
+    # which build of the kernels these counters belong to: bench.py reports `roofline.traffic` from this file only
+    # while the kernel sources still hash to the same value
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import csrc_hash
+    out["_meta"] = {"csrc_hash": csrc_hash(), "source": "rocprofv3 --pmc passes under " + src}
     with open(dst, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print("wrote", dst)
