@@ -10,7 +10,8 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint16, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnerf_amd.so")
+# NERF_AMD_LIB selects another build of the same library (diagnostic builds such as -DNERF_AMD_STAMPS)
+LIB_PATH = os.environ.get("NERF_AMD_LIB") or os.path.join(_HERE, "libnerf_amd.so")
 
 ABI_VERSION = 2
 PREC_FP32, PREC_BF16 = 0, 1

@@ -54,6 +54,9 @@ struct MlpArgs {
     float *g_pts;                  // [P, 3]  dL/dpts (explicit-points mode), overwritten; or NULL
     float *g_rays;                 // [R, 6]  dL/d(origin, direction) accumulated with atomics (rays mode); or NULL
     float *g_vd;                   // [R, 3]  dL/d(view direction) accumulated with atomics; or NULL
+#ifdef NERF_AMD_STAMPS
+    unsigned long long *stamps;    // diagnostic build: [workgroups][waves][4] cycle sums (mlp_bf16_s16.hip)
+#endif
 };
 
 // Rows of the training arrays: P rounded up to whole 256-point workgroups.

@@ -22,7 +22,28 @@
 
 namespace na {
 
+#ifdef NERF_AMD_STAMPS
+// Diagnostic build only (cdna_hip_programming.md section 7, in-kernel stamps): per wave, the shader cycles spent
+// in the three segments of a tile -- [loop top .. first weight block published], [.. last MFMA issued],
+// [.. end-of-tile drain] -- summed over the wave's tiles into a buffer nothing else reads.
+unsigned long long *g_stamp_buf = nullptr;
+#define STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define STAMP(var)
+#endif
+
 #define MFMA16(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, b_, c_, 0, 0, 0)
+
+// Scheduling pipeline of one k-step (OPT & 4): NR LDS reads (the read-ahead of the fragments LA ahead), then NM
+// MFMAs.  Without it the machine scheduler sinks half of the fragment reads to just in front of their first MFMA
+// (tools/isa_readahead.py), which exposes the full LDS latency every two MFMAs.
+template <class C, int NR, int NM>
+__device__ __forceinline__ void sched_step() {
+    if constexpr ((C::OPT & 4) != 0) {
+        __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);   // DS read
+        __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);   // MFMA
+    }
+}
 
 // Pair of 16-row output tiles T, T+1 over K1 k-steps of x1 and K2 of x2.
 // Activation fragment of k-step k, column tile c is x[2*k + c].  acc[u][c]: tile u, column tile c.
@@ -41,6 +62,7 @@ __device__ __forceinline__ void tile_pair(C &c, const bf16x8 *x1, const bf16x8 *
         acc[0][1] = MFMA16(w0, x1[2 * k + 1], acc[0][1]);
         acc[1][0] = MFMA16(w1, x1[2 * k], acc[1][0]);
         acc[1][1] = MFMA16(w1, x1[2 * k + 1], acc[1][1]);
+        sched_step<C, 2, 4>();
     });
     static_for<K2>([&](auto k_) {
         constexpr int k = k_, n = F0 + 2 * K1 + 2 * k;
@@ -50,6 +72,7 @@ __device__ __forceinline__ void tile_pair(C &c, const bf16x8 *x1, const bf16x8 *
         acc[0][1] = MFMA16(w0, x2[2 * k + 1], acc[0][1]);
         acc[1][0] = MFMA16(w1, x2[2 * k], acc[1][0]);
         acc[1][1] = MFMA16(w1, x2[2 * k + 1], acc[1][1]);
+        sched_step<C, 2, 4>();
     });
 }
 
@@ -63,6 +86,7 @@ __device__ __forceinline__ void tile_single(C &c, const bf16x8 *x1, f32x4 (&acc)
         const bf16x8 w0 = take<n, NB, NFRAGS>(c);
         acc[0] = MFMA16(w0, x1[2 * k], acc[0]);
         acc[1] = MFMA16(w0, x1[2 * k + 1], acc[1]);
+        sched_step<C, 1, 2>();
     });
 }
 
@@ -236,6 +260,10 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16_kernel(MlpArgs 
     const int q = lane >> 4;
     C c;
     c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    c.lag = c.wave >= C::WAVES / 2;
+    if constexpr ((C::OPT & 16) != 0) {      // static priority for the second-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+        if (c.lag) __builtin_amdgcn_s_setprio(1);
+    }
     c.gstream = reinterpret_cast<const char *>(a.stream_s16) + lane * 16;
     c.ring_lane = smem + lane * 16;
     c.ring_u32 = (uint32_t)(uintptr_t)smem;
@@ -248,6 +276,7 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16_kernel(MlpArgs 
     const int64_t n_point_tiles = (a.P + WG_POINTS - 1) / WG_POINTS;
 #pragma unroll 1
     for (int64_t tile = blockIdx.x; tile < n_point_tiles; tile += gridDim.x) {
+    STAMP(t0);
     // opaque per-iteration copy of the stream pointer: otherwise the 148 DMA source addresses of the body are
     // loop-invariant, get hoisted in front of the loop and cost ~300 VGPRs
     asm volatile("" : "+v"(c.gstream));
@@ -316,6 +345,7 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16_kernel(MlpArgs 
         block_sync<-1, NB>(c);                                 // publishes block 0
         static_for<C::LA>([&](auto i_) { constexpr int i = i_; c.q[i] = ring_frag<i>(c); });
     }
+    STAMP(t1);
     // training forward: every layer's output also goes to HBM for the backward pass.  (These stores
     // sit in the same vmcnt queue as the ring DMA, so the counted waits are conservative right after a
     // layer's burst; measured, a store ledger like the backward kernel's gains nothing here -- the
@@ -373,8 +403,16 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16_kernel(MlpArgs 
             }
         });
     }
+    STAMP(t2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // no LDS-DMA may outlive the tile (or the workgroup)
     __syncthreads();                                           // every wave is done with the ring before it is refilled
+#ifdef NERF_AMD_STAMPS
+    if (a.stamps && lane == 0) {
+        const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+        unsigned long long *o = a.stamps + ((size_t)blockIdx.x * C::WAVES + c.wave) * 4;
+        o[0] += t1 - t0; o[1] += t2 - t1; o[2] += t3 - t2; o[3] += 1;
+    }
+#endif
     }
 }
 
@@ -394,17 +432,28 @@ static int launch_wg16(const MlpArgs &a, int n_frags_used, int n_tiles, hipStrea
         const int n_cu = device_cu_count();
         if (groups > n_cu) groups = n_cu;
     }
+#ifdef NERF_AMD_STAMPS
+    MlpArgs a2 = a;
+    a2.stamps = g_stamp_buf;
+    hipLaunchKernelGGL((mlp_bf16_s16_kernel<LX, LD, VD, C, SAVE>), dim3((unsigned)groups), dim3(WG_THREADS), lds, s, a2);
+    return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
+#endif
     hipLaunchKernelGGL((mlp_bf16_s16_kernel<LX, LD, VD, C, SAVE>), dim3((unsigned)groups), dim3(WG_THREADS), lds, s, a);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
 
-using Cfg16 = Ctx<8, 16, 4, 8, 2>;
+// 64-KiB ring of 16-fragment blocks, mid-block sync, 4-deep read-ahead pinned in front of the MFMAs it runs ahead of
+// (OPT 4), DMA issue of the two SIMD partners half a block apart (OPT 8).  tools/mlp_ab.py, 4096 x 192 points:
+// 0.606 ms against 0.630 for the round-1 shape Ctx<8, 16, 4, 8, 2> on the same device.
+using Cfg16 = Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 8>;
+using Cfg16R1 = Ctx<8, 16, 4, 8, 2>;          // round-1 shape (A/B: nerf_amd_set_tuning(0, 40))
 
 int launch_mlp_bf16_s16(const MlpArgs &a, int multires, int multires_views, int use_viewdirs,
                         int n_frags_used, int n_tiles, hipStream_t s) {
 #ifdef NERF_AMD_EXPERIMENTS
     if (use_viewdirs && multires == 10 && multires_views == 4) {
         switch (g_variant) {
+#ifdef NERF_AMD_EXPERIMENTS_OLD
             case 20: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 2, 0, 1, 1>>(a, n_frags_used, n_tiles, s);   // fp32 ReLU
             case 21: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 4>>(a, n_frags_used, n_tiles, s);            // 4-deep read-ahead
             case 22: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 4, 4>>(a, n_frags_used, n_tiles, s);            // sync 4 fragments in
@@ -415,10 +464,21 @@ int launch_mlp_bf16_s16(const MlpArgs &a, int multires, int multires_views, int 
             case 26: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 2, 1>>(a, n_frags_used, n_tiles, s);         // no syncs, no DMA
             case 27: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 2, 2>>(a, n_frags_used, n_tiles, s);         // no LDS fragment reads
             case 28: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 2, 3>>(a, n_frags_used, n_tiles, s);         // neither
+            case 29: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 2, 0, 1, 2>>(a, n_frags_used, n_tiles, s);   // stagger: waves 4-7 half a block late
+            case 30: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 2, 0, 1, 4>>(a, n_frags_used, n_tiles, s);   // pinned read-ahead (sched groups), LA 2
+#endif
+            case 32: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 4, 0, 1, 4>>(a, n_frags_used, n_tiles, s);   // pinned read-ahead, LA 4
+            case 34: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 8>>(a, n_frags_used, n_tiles, s);   // + split DMA issue
+            case 35: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 16>>(a, n_frags_used, n_tiles, s);  // + setprio 1 for waves 4-7
+            case 36: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 8 + 16>>(a, n_frags_used, n_tiles, s);
+            case 37: return launch_wg16<10, 4, true, Ctx<8, 32, 3, 16, 4, 0, 1, 4 + 8>>(a, n_frags_used, n_tiles, s);   // 32-fragment blocks, 96-KiB ring
+            case 38: return launch_wg16<10, 4, true, Ctx<8, 32, 4, 16, 4, 0, 1, 4 + 8>>(a, n_frags_used, n_tiles, s);   // 32-fragment blocks, 128-KiB ring
+            case 39: return launch_wg16<10, 4, true, Ctx<8, 16, 5, 8, 4, 0, 1, 4 + 8>>(a, n_frags_used, n_tiles, s);    // 5-slot ring
             default: break;
         }
     }
 #endif
+    if (use_viewdirs && multires == 10 && multires_views == 4 && g_variant == 40) return launch_wg16<10, 4, true, Cfg16R1>(a, n_frags_used, n_tiles, s);
     if (use_viewdirs) {
         if (multires == 10 && multires_views == 4) return launch_wg16<10, 4, true, Cfg16>(a, n_frags_used, n_tiles, s);
         if (multires == 15 && multires_views == 6) return launch_wg16<15, 6, true, Cfg16>(a, n_frags_used, n_tiles, s);
@@ -428,6 +488,10 @@ int launch_mlp_bf16_s16(const MlpArgs &a, int multires, int multires_views, int 
     }
     return NERF_AMD_EUNSUPPORTED;
 }
+
+#ifdef NERF_AMD_STAMPS
+extern "C" void nerf_amd_debug_set_stamp_buffer(void *p) { g_stamp_buf = static_cast<unsigned long long *>(p); }
+#endif
 
 int launch_mlp_bf16_s16_save(const MlpArgs &a, int multires, int multires_views, int n_frags_used, int n_tiles, hipStream_t s) {
     if (multires == 10 && multires_views == 4) return launch_wg16<10, 4, true, Cfg16, true>(a, n_frags_used, n_tiles, s);

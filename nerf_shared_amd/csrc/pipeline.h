@@ -35,6 +35,12 @@ __device__ __forceinline__ void static_for(F &&f) {
 //          (NP = 2 halves the LDS read traffic; needs one wave per SIMD for its registers)
 //   OPT    code-generation options for A/B runs: 1 = ReLU on fp32 registers (one integer max per
 //          value) instead of one packed 16-bit max per converted pair
+//          2 = STAGGER: waves WAVES/2.. (the SIMD partners of waves 0..WAVES/2-1) take every block sync half
+//          a block later in their program -- at fragment 0 of block b+1 instead of fragment PHASE of block b --
+//          so the two waves of a SIMD run half a block apart instead of in lockstep: one converts / reads
+//          LDS / parks at the barrier while the other has the matrix pipe (MI355X_MICROARCH.md, "Two waves per
+//          SIMD", item 9).  Same barrier count, same DMA schedule; legal because the late half, at
+//          fragment 0 of block b+1, has finished every read of block b-1... see maybe_sync.
 //   LEDGER a compile-time count of the compiler-issued global stores that sit in program order
 //          before each fragment (training kernels).  Those stores share the in-order vmcnt queue
 //          with the ring DMA; the counted waits add the stores known to be younger than the block
@@ -60,6 +66,7 @@ struct Ctx {
     uint32_t ring_u32;       // LDS byte address of the ring
     const float *bias_half;  // LDS bias table + (lane>>5)*16
     int wave;
+    int lag;                 // STAGGER: 1 for the waves that sync half a block late (wave-uniform)
 };
 
 // LDS-DMA of this wave's share of stream block BB into its ring slot.
@@ -112,7 +119,30 @@ __device__ __forceinline__ void block_sync(const C &c) {
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(cnt) : "memory");
         __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (B + C::NS - 1 < NB) issue_block<B + C::NS - 1>(c);
+    if constexpr (B + C::NS - 1 < NB) {
+        if constexpr ((C::OPT & 8) != 0) {     // SPLIT_DMA: the late half issues its pieces half a block later (late_issue)
+            if (!c.lag) issue_block<B + C::NS - 1>(c);
+        } else {
+            issue_block<B + C::NS - 1>(c);
+        }
+    }
+}
+
+// OPT & 8 (SPLIT_DMA): waves WAVES/2.. issue their DMA pieces of block b+NS-1 half a block after sync S_b instead of
+// right behind its barrier, so the two waves of a SIMD are never both inside the (slow, ~100 cycles per piece)
+// LDS-DMA issue path at the same time.  The pieces are still issued between S_b and S_b+1 in every wave's program
+// order, so the counted vmcnt waits are unchanged.
+template <int n, int NB, class C>
+__device__ __forceinline__ void late_issue(const C &c) {
+    if constexpr ((C::OPT & 8) != 0 && C::PHASE > 0) {
+        constexpr int half = (C::PHASE + C::BF / 2) % C::BF;
+        if constexpr (n % C::BF == half) {
+            constexpr int B = (n - C::PHASE - C::BF / 2) / C::BF;     // the sync half a block ago
+            if constexpr (B >= -1 && B + C::NS - 1 < NB && (n - C::PHASE - C::BF / 2) >= -C::BF) {
+                if (c.lag) issue_block<B + C::NS - 1>(c);
+            }
+        }
+    }
 }
 
 template <int NB, class C>
@@ -126,15 +156,32 @@ __device__ __forceinline__ bf16x8 ring_frag(const C &c) {
     return *reinterpret_cast<const bf16x8 *>(c.ring_lane + ((n % (C::NS * C::BF)) << 10));
 }
 
+// Sync S_b publishes block b+1 and refills the slot of block b-1 with block b+NS-1.  The early waves reach it
+// PHASE fragments into block b.  With STAGGER the late waves reach the same barrier at fragment PHASE of block
+// b too -- in wall time -- but their program is half a block behind: for them it sits at fragment
+// PHASE - BF/2 of block b.  Legal: a late wave at that point has consumed every fragment of block b-1 (reads
+// run LA <= BF/2 - ... fragments ahead and are waited for before their MFMA), and it needs block b+1 only
+// BF/2 fragments later than the early waves do.
 template <int n, int NB, class C>
 __device__ __forceinline__ void maybe_sync(const C &c) {
-    if constexpr (n % C::BF == C::PHASE && (n / C::BF + C::LOOKAHEAD) < NB) block_sync<n / C::BF, NB>(c);
+    if constexpr ((C::OPT & 2) != 0) {
+        static_assert(C::PHASE == C::BF / 2 && C::LA <= C::PHASE, "stagger is written for a mid-block sync");
+        if constexpr (n % C::BF == C::PHASE && (n / C::BF + 1) < NB) {
+            if (!c.lag) block_sync<n / C::BF, NB>(c);
+        }
+        if constexpr (n % C::BF == 0 && (n / C::BF + 1) < NB) {
+            if (c.lag) block_sync<n / C::BF, NB>(c);
+        }
+    } else {
+        if constexpr (n % C::BF == C::PHASE && (n / C::BF + C::LOOKAHEAD) < NB) block_sync<n / C::BF, NB>(c);
+    }
 }
 
 // Fragment n of the stream, in consumption order (syncs included).
 template <int n, int NB, int NFRAGS, class C>
 __device__ __forceinline__ bf16x8 take(C &c) {
     maybe_sync<n, NB>(c);
+    late_issue<n, NB>(c);
     if constexpr (C::ABL & 2) {
         bf16x8 f = c.q[0];
         asm volatile("" : "+v"(f));     // opaque: keeps one MFMA per fragment without an LDS read
