@@ -47,8 +47,14 @@ __device__ __forceinline__ void sched_step() {
 
 // Pair of 16-row output tiles T, T+1 over K1 k-steps of x1 and K2 of x2.
 // Activation fragment of k-step k, column tile c is x[2*k + c].  acc[u][c]: tile u, column tile c.
-template <int F0, int T, int K1, int K2, int NB, int NFRAGS, class C>
-__device__ __forceinline__ void tile_pair(C &c, const bf16x8 *x1, const bf16x8 *x2, f32x4 (&acc)[2][2]) {
+struct NoHook {
+    template <class P, class K> __device__ __forceinline__ void operator()(P, K) const {}
+};
+
+// hook(p, k): called after the MFMAs of k-step k (0 .. K1+K2-1) of the pair; the pipelined kernel hangs the next
+// tile's coordinate loads and positional encoding on it, a piece at a time.
+template <int F0, int T, int K1, int K2, int NB, int NFRAGS, class C, class P = std::integral_constant<int, 0>, class H = NoHook>
+__device__ __forceinline__ void tile_pair(C &c, const bf16x8 *x1, const bf16x8 *x2, f32x4 (&acc)[2][2], P p_ = P{}, H &&hook = H{}) {
     {
         const f32x4 b0 = *reinterpret_cast<const f32x4 *>(c.bias_half + T * 16);
         const f32x4 b1 = *reinterpret_cast<const f32x4 *>(c.bias_half + (T + 1) * 16);
@@ -63,6 +69,7 @@ __device__ __forceinline__ void tile_pair(C &c, const bf16x8 *x1, const bf16x8 *
         acc[1][0] = MFMA16(w1, x1[2 * k], acc[1][0]);
         acc[1][1] = MFMA16(w1, x1[2 * k + 1], acc[1][1]);
         sched_step<C, 2, 4>();
+        hook(p_, std::integral_constant<int, k>{});
     });
     static_for<K2>([&](auto k_) {
         constexpr int k = k_, n = F0 + 2 * K1 + 2 * k;
@@ -73,6 +80,7 @@ __device__ __forceinline__ void tile_pair(C &c, const bf16x8 *x1, const bf16x8 *
         acc[1][0] = MFMA16(w1, x2[2 * k], acc[1][0]);
         acc[1][1] = MFMA16(w1, x2[2 * k + 1], acc[1][1]);
         sched_step<C, 2, 4>();
+        hook(p_, std::integral_constant<int, K1 + k>{});
     });
 }
 
@@ -119,12 +127,12 @@ __device__ __forceinline__ bf16x8 pack_pair(const f32x4 &even, const f32x4 &odd)
 }
 
 // A hidden layer of NPAIR tile pairs -> y[2 * NPAIR] (k-step p, column tile c at y[2p + c]).
-template <int F0, int T0, int NPAIR, int K1, int K2, bool RELU, int NB, int NFRAGS, class C>
-__device__ __forceinline__ void layer16(C &c, const bf16x8 *x1, const bf16x8 *x2, bf16x8 *y) {
+template <int F0, int T0, int NPAIR, int K1, int K2, bool RELU, int NB, int NFRAGS, class C, class H = NoHook>
+__device__ __forceinline__ void layer16(C &c, const bf16x8 *x1, const bf16x8 *x2, bf16x8 *y, H &&hook = H{}) {
     static_for<NPAIR>([&](auto p_) {
         constexpr int p = p_;
         f32x4 acc[2][2];
-        tile_pair<F0 + p * 2 * (K1 + K2), T0 + 2 * p, K1, K2, NB, NFRAGS>(c, x1, x2, acc);
+        tile_pair<F0 + p * 2 * (K1 + K2), T0 + 2 * p, K1, K2, NB, NFRAGS>(c, x1, x2, acc, p_, hook);
         y[2 * p] = pack_pair<RELU, !(C::OPT & 1)>(acc[0][0], acc[1][0]);
         y[2 * p + 1] = pack_pair<RELU, !(C::OPT & 1)>(acc[0][1], acc[1][1]);
     });
@@ -133,53 +141,73 @@ __device__ __forceinline__ void layer16(C &c, const bf16x8 *x1, const bf16x8 *x2
 // Positional encoding into FRAG_GEN16 layout (program.h: gen16_col).  h = sin/cos family,
 // b = frequency parity of this lane quarter.  th + tl = x / (2 pi) as an exact fp32 pair;
 // multiplying by 4 and v_fract are exact, v_sin_f32 takes revolutions.
-template <int L, int K, int STRIDE>
-__device__ __forceinline__ void encode16(float x0, float x1, float x2, int h, int b, bf16x8 *out) {
-    constexpr float INV2PI_HI = 0.15915494f;
-    constexpr float INV2PI_LO = (float)(0.15915494309189535 - (double)INV2PI_HI);
-    constexpr int NSTEP = (L + 1) / 2, CAP = 8 * K;
-    constexpr int N_EVEN = gen16_ntrig(L, 0), N_ODD = gen16_ntrig(L, 1);
-    const float x[3] = {x0, x1, x2};
-    const float phase = h ? 0.25f : 0.0f;
-    const float s0 = b ? 2.0f : 1.0f;
-    // The reduction runs on |x|: v_fract of a negative number is x - floor(x) *rounded*, and that ulp would be
-    // quadrupled with every step (3e-3 at 2^14, a bf16 quantum).  sin is odd and cos even, so the sin family
-    // (h == 0) gets x's sign bit back at the end.
-    float ra[3], tl[3];
+// The work comes in pieces -- begin, NSTEP x step, finish -- so the pipelined kernel can spread the encoding of its
+// NEXT tile over the k-steps of the current one; encode16 runs them back to back.
+template <int L, int K>
+struct Enc16 {
+    static constexpr int NSTEP = (L + 1) / 2, CAP = 8 * K;
+    static constexpr int N_EVEN = gen16_ntrig(L, 0), N_ODD = gen16_ntrig(L, 1);
+    static constexpr int N_COMMON = N_ODD < N_EVEN ? N_ODD : N_EVEN;     // slots that hold a trig value in every lane quarter
+    static constexpr int N_TAIL = (N_EVEN > N_ODD ? N_EVEN : N_ODD) - N_COMMON;
+    float x[3], ra[3], tl[3], phase;
     unsigned sgn[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float ax = __builtin_fabsf(x[c]);
-        sgn[c] = h ? 0u : (__builtin_bit_cast(unsigned, x[c]) & 0x80000000u);
-        const float th = ax * INV2PI_HI;
-        tl[c] = (__builtin_fmaf(ax, INV2PI_HI, -th) + ax * INV2PI_LO) * s0;
-        ra[c] = __builtin_amdgcn_fractf(th * s0);
-    }
-    float vals[CAP];
-#pragma unroll
-    for (int i = 0; i < CAP; ++i) vals[i] = 0.0f;
-#pragma unroll
-    for (int s = 0; s < NSTEP; ++s) {
+    float tail[N_TAIL > 0 ? N_TAIL : 1];      // trig values of the slots that are raw coordinates in the other parity
+
+    __device__ __forceinline__ void begin(float x0, float x1, float x2, int h, int b) {
+        constexpr float INV2PI_HI = 0.15915494f;
+        constexpr float INV2PI_LO = (float)(0.15915494309189535 - (double)INV2PI_HI);
+        x[0] = x0; x[1] = x1; x[2] = x2;
+        phase = h ? 0.25f : 0.0f;
+        const float s0 = b ? 2.0f : 1.0f;
+        // The reduction runs on |x|: v_fract of a negative number is x - floor(x) *rounded*, and that ulp would be
+        // quadrupled with every step (3e-3 at 2^14, a bf16 quantum).  sin is odd and cos even, so the sin family
+        // (h == 0) gets x's sign bit back at the end.
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            if (3 * s + c < CAP)
-                vals[3 * s + c] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, __builtin_amdgcn_sinf(ra[c] + (tl[c] + phase))) ^ sgn[c]);
+            const float ax = __builtin_fabsf(x[c]);
+            sgn[c] = h ? 0u : (__builtin_bit_cast(unsigned, x[c]) & 0x80000000u);
+            const float th = ax * INV2PI_HI;
+            tl[c] = (__builtin_fmaf(ax, INV2PI_HI, -th) + ax * INV2PI_LO) * s0;
+            ra[c] = __builtin_amdgcn_fractf(th * s0);
+        }
+    }
+    // step S: the three trig values of slots 3S .. 3S+2, converted to bf16 and placed at once (a slot i lives in
+    // out[(i / 8) * STRIDE][i % 8]) unless the slot's content depends on the lane's frequency parity (finish)
+    template <int S, int STRIDE>
+    __device__ __forceinline__ void step(bf16x8 *out) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            constexpr int dummy = 0; (void)dummy;
+            const int i = 3 * S + c;
+            if (i < CAP) {
+                const float v = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, __builtin_amdgcn_sinf(ra[c] + (tl[c] + phase))) ^ sgn[c]);
+                if (i < N_COMMON) out[(i / 8) * STRIDE][i % 8] = (__bf16)v;
+                else if (i - N_COMMON < N_TAIL) tail[i - N_COMMON] = v;
+            }
             ra[c] = __builtin_amdgcn_fractf(ra[c] * 4.0f);
             tl[c] *= 4.0f;
         }
     }
-    // slots past a group's trig count hold raw coordinates (or nothing)
-    auto coord = [&](int mc) { return mc == 0 ? x0 : mc == 1 ? x1 : mc == 2 ? x2 : 0.0f; };
+    template <int STRIDE>
+    __device__ __forceinline__ void finish(int h, int b, bf16x8 *out) {
+        // slots past a group's trig count hold raw coordinates (or nothing)
+        auto coord = [&](int mc) { return mc == 0 ? x[0] : mc == 1 ? x[1] : mc == 2 ? x[2] : 0.0f; };
 #pragma unroll
-    for (int i = (N_ODD < N_EVEN ? N_ODD : N_EVEN); i < CAP; ++i) {
-        const float v_even = i < N_EVEN ? vals[i] : (h ? coord(gen16_misc(L, 1, 0, i - N_EVEN)) : coord(gen16_misc(L, 0, 0, i - N_EVEN)));
-        const float v_odd = i < N_ODD ? vals[i] : (h ? coord(gen16_misc(L, 1, 1, i - N_ODD)) : coord(gen16_misc(L, 0, 1, i - N_ODD)));
-        vals[i] = b ? v_odd : v_even;
+        for (int i = N_COMMON; i < CAP; ++i) {
+            const float t = (i - N_COMMON < N_TAIL) ? tail[i - N_COMMON < N_TAIL ? i - N_COMMON : 0] : 0.0f;
+            const float v_even = i < N_EVEN ? t : (h ? coord(gen16_misc(L, 1, 0, i - N_EVEN)) : coord(gen16_misc(L, 0, 0, i - N_EVEN)));
+            const float v_odd = i < N_ODD ? t : (h ? coord(gen16_misc(L, 1, 1, i - N_ODD)) : coord(gen16_misc(L, 0, 1, i - N_ODD)));
+            out[(i / 8) * STRIDE][i % 8] = (__bf16)(b ? v_odd : v_even);
+        }
     }
-#pragma unroll
-    for (int k = 0; k < K; ++k)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) out[k * STRIDE][j] = (__bf16)vals[8 * k + j];
+};
+
+template <int L, int K, int STRIDE>
+__device__ __forceinline__ void encode16(float x0, float x1, float x2, int h, int b, bf16x8 *out) {
+    Enc16<L, K> e;
+    e.begin(x0, x1, x2, h, b);
+    static_for<Enc16<L, K>::NSTEP>([&](auto s_) { e.template step<s_, STRIDE>(out); });
+    e.template finish<STRIDE>(h, b, out);
 }
 
 // Save NK k-steps of fragments (y[2*ks + cc]) as slot-major bf16 rows of ROW elements.  Unconditional:
@@ -260,7 +288,7 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16_kernel(MlpArgs 
     const int q = lane >> 4;
     C c;
     c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    c.lag = c.wave >= C::WAVES / 2;
+    c.lag = __builtin_amdgcn_readfirstlane(c.wave >= C::WAVES / 2 ? 1 : 0);   // an SGPR: the DMA asm branches on it
     if constexpr ((C::OPT & 16) != 0) {      // static priority for the second-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
         if (c.lag) __builtin_amdgcn_s_setprio(1);
     }
@@ -416,6 +444,254 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16_kernel(MlpArgs 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// The pipelined form of the kernel above (inference; the training forward keeps the simple one).  Same
+// arithmetic, same fragment order, bit-identical outputs; what changes is what happens BETWEEN two tiles of
+// a workgroup.  tools/tile_stamps.py measured the simple kernel's tile at 105 k cycles of which 4.9 k are the
+// tile start (coordinate loads, positional encoding, the first weight block's DMA latency) and 0.4 k the
+// end-of-tile drain, with the matrix pipe idle throughout.  Here
+//   * the weight stream is CONTINUOUS (pipeline.h, OPT 32): the next tile's first two blocks are fetched
+//     under the current tile's last two and no DMA is drained at a tile boundary;
+//   * the next tile's coordinates are loaded and its encodings generated a piece at a time on the k-steps
+//     of layers 6 and 7 (the xyz encoding is dead after the skip layer, so it is overwritten in place; the
+//     view-direction encoding is double-buffered), i.e. in the VALU slots the MFMAs leave free.
+// ---------------------------------------------------------------------------------------------------------
+template <int LX, int LD, bool VD, class C>
+__global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16p_kernel(MlpArgs a) {
+    static_assert((C::OPT & 32) != 0 && C::PHASE > 0, "the pipelined kernel needs the continuous ring");
+    constexpr int WG_THREADS = C::WAVES * 64, WG_POINTS = C::WAVES * 32;
+    using Lay = Layout16<LX, LD, VD>;
+    constexpr int KE = Lay::KE, KD = Lay::KD, NF = Lay::F_END, NB = (NF + C::BF - 1) / C::BF;
+    constexpr int SHIFT = NB % C::NS;                      // ring slots the block numbering advances per tile
+    using EncX = Enc16<LX, KE>;
+    using EncD = Enc16<(VD ? LD : 1), (VD ? KD : 1)>;
+    // Pieces of the next tile's preparation, one per hook slot.  A 256-wide layer's pair is one ring block (16 fragments,
+    // k-steps 0..7) with its block sync in front of k-step 4, and has two slots: 2p after k-step 0 (half a block behind
+    // the previous sync) and 2p+1 after k-step 4 (right behind its own sync).  Global loads go right behind a sync: they
+    // sit in the same in-order vmcnt queue as the ring DMA, so the NEXT sync's counted wait also waits for them (it is
+    // only stricter than it needs to be), a whole block later; their first use comes after that sync.
+    //   layers 6 + 7 (32 slots): the NEXT tile's two points one after the other -- loads, point, NSX encoding steps --
+    //     so only one point's raw coordinates and encoder state are live at a time (registers are what limits this);
+    //   feature layer (16 slots, view-branch models): THIS tile's view directions -- loads, then 2 x NSD steps -- which
+    //     nothing needs before the views layer that follows.
+    constexpr int NSX = EncX::NSTEP, NSD = VD ? EncD::NSTEP : 0;
+    constexpr int PT_SLOTS = 4 + NSX + ((4 + NSX) & 1);           // load (odd slot), two slots later the point, then the steps; even length
+    constexpr int SLOT_LOAD = 1, SLOT_PTS = 3, SLOT_ENC = 4;       // relative to a point's first slot
+    static_assert(C::BF == 16 && C::PHASE == 8, "hook slots are laid out for a sync in front of k-step 4");
+    static_assert(2 * PT_SLOTS <= 32 && 3 + 2 * NSD <= 16, "the encodings must fit on the hooks they are given");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *bias_lds = reinterpret_cast<float *>(smem + C::RING_BYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int q = lane >> 4;
+    const int64_t n_point_tiles = (a.P + WG_POINTS - 1) / WG_POINTS;
+    int64_t tile = blockIdx.x;
+    if (tile >= n_point_tiles) return;                     // whole workgroups only (the launcher never over-provisions)
+    C c;
+    c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    c.lag = __builtin_amdgcn_readfirstlane(c.wave >= C::WAVES / 2 ? 1 : 0);   // an SGPR: the DMA asm branches on it
+    c.gstream = reinterpret_cast<const char *>(a.stream_s16) + lane * 16;
+    c.gstream_next = c.gstream;
+    c.ring_lane = smem + lane * 16;
+    c.ring_u32 = (uint32_t)(uintptr_t)smem;
+#pragma unroll
+    for (int i = 0; i < C::NS; ++i) {
+        c.slot_u32[i] = c.ring_u32 + i * C::BLOCK_BYTES;
+        c.slot_lane[i] = c.slot_u32[i] + lane * 16;
+    }
+    c.bias_half = bias_lds + q * 4;          // this lane's 4 rows of every 16-row tile
+    for (int i = tid; i < Lay::N_TILES * 16; i += WG_THREADS) bias_lds[i] = a.bias_s16[i];
+
+    // ---- coordinates of a tile: this lane's two points (column tile cc, column lane&15)
+    float ld[7], dvn[2][3];                  // raw loads of ONE point of the next tile: o(3) d(3) z | explicit point(3); this tile's view directions
+    float xsn[3];
+    const int32_t P32 = (int32_t)a.P;        // P < 2^31 (checked at launch)
+    const int32_t lane_pt = c.wave * 32 + (lane & 15);
+    auto point_index = [&](int64_t t, int cc) { return (int32_t)t * WG_POINTS + lane_pt + cc * 16; };
+    auto issue_loads = [&](int64_t t, int cc) {
+        const int32_t p = point_index(t, cc);
+        const int64_t pc = p < P32 ? p : P32 - 1;
+        if (a.pts) {
+            ld[0] = a.pts[3 * pc + 0]; ld[1] = a.pts[3 * pc + 1]; ld[2] = a.pts[3 * pc + 2];
+        } else {
+            const float *r = a.rays + (int64_t)((uint32_t)pc / (uint32_t)a.S) * a.ray_stride;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) ld[k] = r[k];
+            ld[6] = a.z_vals[pc];
+        }
+    };
+    // the view directions of the CURRENT tile's points: loaded and encoded on the hooks of its feature layer (Dv is not
+    // needed before the views layer), so nothing of it is live while the next tile is prepared
+    auto issue_dir_loads = [&]() {
+        if constexpr (VD) {
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const int32_t p = point_index(tile, cc);
+                const int64_t pc = p < P32 ? p : P32 - 1;
+                const float *d = a.viewdirs + (int64_t)((uint32_t)pc / (uint32_t)a.S) * a.vd_stride;
+                dvn[cc][0] = d[0]; dvn[cc][1] = d[1]; dvn[cc][2] = d[2];
+            }
+        }
+    };
+    auto make_point = [&]() {
+        if (a.pts) {
+            xsn[0] = ld[0]; xsn[1] = ld[1]; xsn[2] = ld[2];
+        } else {                                             // pts = o + d z, rounded like the reference's two ops
+            xsn[0] = __fadd_rn(ld[0], __fmul_rn(ld[3], ld[6]));
+            xsn[1] = __fadd_rn(ld[1], __fmul_rn(ld[4], ld[6]));
+            xsn[2] = __fadd_rn(ld[2], __fmul_rn(ld[5], ld[6]));
+        }
+    };
+
+    bf16x8 E[KE * 2];
+    bf16x8 Dv[(VD ? KD : 1) * 2];
+    static_for<2>([&](auto cc_) {            // the first tile's points: nothing to hide the loads and the encoding under
+        constexpr int cc = cc_;
+        issue_loads(tile, cc);
+        make_point();
+        encode16<LX, KE, 2>(xsn[0], xsn[1], xsn[2], q >> 1, q & 1, E + cc);
+    });
+    pipeline_prologue<NB>(c);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // bias table stores, before the first barrier publishes them
+
+    EncX ex;
+    EncD ed;
+    auto prepare = [&](auto slot_) {         // slot 0..31 of layers 6 + 7
+        constexpr int slot = slot_, cc = slot / PT_SLOTS, r = slot % PT_SLOTS;
+        if constexpr (cc < 2) {
+            if constexpr (r == SLOT_LOAD) {
+                issue_loads(c.has_next ? tile + gridDim.x : tile, cc);      // nothing follows: reload this tile (never used)
+            } else if constexpr (r == SLOT_PTS) {
+                make_point();
+            } else if constexpr (r >= SLOT_ENC && r < SLOT_ENC + NSX) {
+                constexpr int st = r - SLOT_ENC;
+                if constexpr (st == 0) ex.begin(xsn[0], xsn[1], xsn[2], q >> 1, q & 1);
+                ex.template step<st, 2>(E + cc);                                               // E is dead after the skip layer
+                if constexpr (st == NSX - 1) ex.template finish<2>(q >> 1, q & 1, E + cc);
+            }
+        }
+    };
+    auto hook_feat = [&](auto p_, auto k_) {
+        constexpr int p = p_, k = k_;
+        if constexpr (VD && (k == 0 || k == 4)) {
+            constexpr int slot = 2 * p + (k == 4);
+            if constexpr (slot == 1) issue_dir_loads();
+            if constexpr (slot >= 3 && slot < 3 + 2 * NSD) {
+                constexpr int cc = (slot - 3) / NSD, st = (slot - 3) % NSD;
+                if constexpr (st == 0) ed.begin(dvn[cc][0], dvn[cc][1], dvn[cc][2], q >> 1, q & 1);
+                ed.template step<st, 2>(Dv + cc);
+                if constexpr (st == NSD - 1) ed.template finish<2>(q >> 1, q & 1, Dv + cc);
+            }
+        }
+    };
+    auto hook6 = [&](auto p_, auto k_) {
+        constexpr int p = p_, k = k_;
+        if constexpr (k == 0 || k == 4) prepare(std::integral_constant<int, 2 * p + (k == 4)>{});
+    };
+    auto hook7 = [&](auto p_, auto k_) {
+        constexpr int p = p_, k = k_;
+        if constexpr (k == 0 || k == 4) prepare(std::integral_constant<int, 16 + 2 * p + (k == 4)>{});
+    };
+
+#ifdef NERF_AMD_STAMPS
+    unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll 1
+    for (;;) {
+#ifdef NERF_AMD_STAMPS
+    if (a.stamps && lane == 0) {             // diagnostic build: cycles per loop iteration (= per tile) of this wave
+        const unsigned long long t_now = __builtin_amdgcn_s_memtime();
+        unsigned long long *o = a.stamps + ((size_t)blockIdx.x * C::WAVES + c.wave) * 4;
+        o[1] += t_now - t_prev; o[3] += 1;
+        t_prev = t_now;
+    }
+#endif
+    c.has_next = tile + gridDim.x < n_point_tiles;
+    // opaque per-iteration copies of the stream pointers: otherwise the DMA source addresses of the body are
+    // loop-invariant, get hoisted in front of the loop and cost ~300 VGPRs
+    asm volatile("" : "+v"(c.gstream));
+    c.gstream_next = c.gstream;              // one model per launch: the next tile streams the same weights
+
+    block_sync<-1, NB>(c);                                 // publishes block 0
+    static_for<C::LA>([&](auto i_) { constexpr int i = i_; c.q[i] = ring_frag<i>(c); });
+
+    bf16x8 A[16], B[16];
+    layer16<Lay::F_L0, 0, 8, KE, 0, true, NB, NF>(c, E, E, A);
+    layer16<Lay::F_L1 + 0 * 128, 16, 8, 8, 0, true, NB, NF>(c, A, A, B);
+    layer16<Lay::F_L1 + 1 * 128, 32, 8, 8, 0, true, NB, NF>(c, B, B, A);
+    layer16<Lay::F_L1 + 2 * 128, 48, 8, 8, 0, true, NB, NF>(c, A, A, B);
+    layer16<Lay::F_L1 + 3 * 128, 64, 8, 8, 0, true, NB, NF>(c, B, B, A);
+    layer16<Lay::F_L5, 80, 8, KE, 8, true, NB, NF>(c, E, A, B);            // skip: [input_pts | h]
+    layer16<Lay::F_L6, 96, 8, 8, 0, true, NB, NF>(c, B, B, A, hook6);      // + next tile: loads, points, encoding ...
+    layer16<Lay::F_L6 + 128, 112, 8, 8, 0, true, NB, NF>(c, A, A, B, hook7);   // ... h7 in B
+
+    if constexpr (VD) {
+        layer16<Lay::F_FEAT, 128, 8, 8, 0, false, NB, NF>(c, B, B, A, hook_feat);   // feature (no activation) + this tile's view directions
+        f32x4 alpha[2], rgb[2];
+        tile_single<Lay::F_ALPHA, 144, 8, NB, NF>(c, B, alpha);            // row 0 = sigma
+        layer16<Lay::F_VIEWS, 145, 4, 8, KD, true, NB, NF>(c, A, Dv, B);   // views_linears.0 (128 rows)
+        tile_single<Lay::F_RGB, 153, 4, NB, NF>(c, B, rgb);                // rows 0..2
+        static_for<2>([&](auto cc_) {
+            constexpr int cc = cc_;
+            const int32_t p = point_index(tile, cc);
+            if (p < P32 && q == 0) {
+                f32x4 o = {rgb[cc][0], rgb[cc][1], rgb[cc][2], alpha[cc][0]};
+                *reinterpret_cast<f32x4 *>(a.out + 4 * (int64_t)p) = o;
+            }
+        });
+    } else {
+        f32x4 o[2];
+        tile_single<Lay::F_HEAD, 128, 8, NB, NF>(c, B, o);
+        static_for<2>([&](auto cc_) {
+            constexpr int cc = cc_;
+            const int32_t p = point_index(tile, cc);
+            if (p < P32) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * q + r;
+                    if (row < a.out_ch) a.out[(int64_t)a.out_ch * p + row] = o[cc][r];
+                }
+            }
+        });
+    }
+    if (!c.has_next) break;
+    tile += gridDim.x;
+    if constexpr (SHIFT != 0) {              // the next tile's block b lives in the slot this tile's block b + NB had
+        uint32_t sl[C::NS], su[C::NS];
+#pragma unroll
+        for (int i = 0; i < C::NS; ++i) { sl[i] = c.slot_lane[(i + SHIFT) % C::NS]; su[i] = c.slot_u32[(i + SHIFT) % C::NS]; }
+#pragma unroll
+        for (int i = 0; i < C::NS; ++i) { c.slot_lane[i] = sl[i]; c.slot_u32[i] = su[i]; }
+    }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // no LDS-DMA may outlive the workgroup
+}
+
+template <int LX, int LD, bool VD, class C>
+static int launch_wg16p(const MlpArgs &a, int n_frags_used, int n_tiles, hipStream_t s) {
+    constexpr int WG_THREADS = C::WAVES * 64, WG_POINTS = C::WAVES * 32;
+    using Lay = Layout16<LX, LD, VD>;
+    if (n_frags_used != Lay::F_END || n_tiles != Lay::N_TILES) return NERF_AMD_EINVAL;
+    const size_t lds = C::RING_BYTES + (size_t)Lay::N_TILES * 16 * sizeof(float);
+    static DynamicLdsOptIn opt_in;
+    if (opt_in.ensure(reinterpret_cast<const void *>(mlp_bf16_s16p_kernel<LX, LD, VD, C>), lds) != hipSuccess) return NERF_AMD_EHIP;
+    int64_t groups = (a.P + WG_POINTS - 1) / WG_POINTS;
+    if (groups <= 0) return NERF_AMD_OK;
+    if (a.P >= (int64_t)1 << 31) return NERF_AMD_EINVAL;
+    const int n_cu = device_cu_count();      // one workgroup per CU walks the tiles
+    if (groups > n_cu) groups = n_cu;
+#ifdef NERF_AMD_STAMPS
+    MlpArgs a2 = a;
+    a2.stamps = g_stamp_buf;
+    hipLaunchKernelGGL((mlp_bf16_s16p_kernel<LX, LD, VD, C>), dim3((unsigned)groups), dim3(WG_THREADS), lds, s, a2);
+    return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
+#endif
+    hipLaunchKernelGGL((mlp_bf16_s16p_kernel<LX, LD, VD, C>), dim3((unsigned)groups), dim3(WG_THREADS), lds, s, a);
+    return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
+}
+
 template <int LX, int LD, bool VD, class C, bool SAVE = false>
 static int launch_wg16(const MlpArgs &a, int n_frags_used, int n_tiles, hipStream_t s) {
     constexpr int WG_THREADS = C::WAVES * 64, WG_POINTS = C::WAVES * 32;
@@ -447,6 +723,7 @@ static int launch_wg16(const MlpArgs &a, int n_frags_used, int n_tiles, hipStrea
 // 0.606 ms against 0.630 for the round-1 shape Ctx<8, 16, 4, 8, 2> on the same device.
 using Cfg16 = Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 8>;
 using Cfg16R1 = Ctx<8, 16, 4, 8, 2>;          // round-1 shape (A/B: nerf_amd_set_tuning(0, 40))
+using Cfg16P = Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 8 + 32>;   // the pipelined kernel: Cfg16 + continuous ring
 
 int launch_mlp_bf16_s16(const MlpArgs &a, int multires, int multires_views, int use_viewdirs,
                         int n_frags_used, int n_tiles, hipStream_t s) {
@@ -467,6 +744,7 @@ int launch_mlp_bf16_s16(const MlpArgs &a, int multires, int multires_views, int 
             case 29: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 2, 0, 1, 2>>(a, n_frags_used, n_tiles, s);   // stagger: waves 4-7 half a block late
             case 30: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 2, 0, 1, 4>>(a, n_frags_used, n_tiles, s);   // pinned read-ahead (sched groups), LA 2
 #endif
+#ifdef NERF_AMD_EXPERIMENTS_R2A
             case 32: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 4, 0, 1, 4>>(a, n_frags_used, n_tiles, s);   // pinned read-ahead, LA 4
             case 34: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 8>>(a, n_frags_used, n_tiles, s);   // + split DMA issue
             case 35: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 16>>(a, n_frags_used, n_tiles, s);  // + setprio 1 for waves 4-7
@@ -474,11 +752,25 @@ int launch_mlp_bf16_s16(const MlpArgs &a, int multires, int multires_views, int 
             case 37: return launch_wg16<10, 4, true, Ctx<8, 32, 3, 16, 4, 0, 1, 4 + 8>>(a, n_frags_used, n_tiles, s);   // 32-fragment blocks, 96-KiB ring
             case 38: return launch_wg16<10, 4, true, Ctx<8, 32, 4, 16, 4, 0, 1, 4 + 8>>(a, n_frags_used, n_tiles, s);   // 32-fragment blocks, 128-KiB ring
             case 39: return launch_wg16<10, 4, true, Ctx<8, 16, 5, 8, 4, 0, 1, 4 + 8>>(a, n_frags_used, n_tiles, s);    // 5-slot ring
+#endif
+            case 42: return launch_wg16p<10, 4, true, Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 32>>(a, n_frags_used, n_tiles, s);      // pipelined, no split DMA
+            case 43: return launch_wg16p<10, 4, true, Ctx<8, 16, 4, 8, 3, 0, 1, 4 + 8 + 32>>(a, n_frags_used, n_tiles, s);  // pipelined, LA 3
+            case 44: return launch_wg16p<10, 4, true, Ctx<8, 16, 4, 8, 2, 0, 1, 4 + 8 + 32>>(a, n_frags_used, n_tiles, s);  // pipelined, LA 2
             default: break;
         }
     }
 #endif
     if (use_viewdirs && multires == 10 && multires_views == 4 && g_variant == 40) return launch_wg16<10, 4, true, Cfg16R1>(a, n_frags_used, n_tiles, s);
+    if (g_variant != 41) {                  // 41 = A/B: the simple per-tile kernel
+        if (use_viewdirs) {
+            if (multires == 10 && multires_views == 4) return launch_wg16p<10, 4, true, Cfg16P>(a, n_frags_used, n_tiles, s);
+            if (multires == 15 && multires_views == 6) return launch_wg16p<15, 6, true, Cfg16P>(a, n_frags_used, n_tiles, s);
+        } else if (a.out_ch <= 16) {
+            if (multires == 10) return launch_wg16p<10, 0, false, Cfg16P>(a, n_frags_used, n_tiles, s);
+            if (multires == 15) return launch_wg16p<15, 0, false, Cfg16P>(a, n_frags_used, n_tiles, s);
+        }
+        return NERF_AMD_EUNSUPPORTED;
+    }
     if (use_viewdirs) {
         if (multires == 10 && multires_views == 4) return launch_wg16<10, 4, true, Cfg16>(a, n_frags_used, n_tiles, s);
         if (multires == 15 && multires_views == 6) return launch_wg16<15, 6, true, Cfg16>(a, n_frags_used, n_tiles, s);
@@ -494,8 +786,9 @@ extern "C" void nerf_amd_debug_set_stamp_buffer(void *p) { g_stamp_buf = static_
 #endif
 
 int launch_mlp_bf16_s16_save(const MlpArgs &a, int multires, int multires_views, int n_frags_used, int n_tiles, hipStream_t s) {
-    if (multires == 10 && multires_views == 4) return launch_wg16<10, 4, true, Cfg16, true>(a, n_frags_used, n_tiles, s);
-    if (multires == 15 && multires_views == 6) return launch_wg16<15, 6, true, Cfg16, true>(a, n_frags_used, n_tiles, s);
+    // the training forward keeps the round-1 pipeline shape: with its activation stores the pinned / split shape spills
+    if (multires == 10 && multires_views == 4) return launch_wg16<10, 4, true, Cfg16R1, true>(a, n_frags_used, n_tiles, s);
+    if (multires == 15 && multires_views == 6) return launch_wg16<15, 6, true, Cfg16R1, true>(a, n_frags_used, n_tiles, s);
     return NERF_AMD_EUNSUPPORTED;
 }
 

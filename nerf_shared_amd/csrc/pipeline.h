@@ -66,28 +66,88 @@ struct Ctx {
     uint32_t ring_u32;       // LDS byte address of the ring
     const float *bias_half;  // LDS bias table + (lane>>5)*16
     int wave;
-    int lag;                 // STAGGER: 1 for the waves that sync half a block late (wave-uniform)
+    int lag;                 // STAGGER / SPLIT_DMA: 1 for waves WAVES/2.. (wave-uniform)
+    // OPT & 32 (CONTINUOUS): the weight stream does not stop at a tile boundary.  The blocks of consecutive tiles
+    // are numbered through (V = t NB + b, ring slot V mod NS), so the first blocks of the next tile are fetched
+    // under the last blocks of the current one and nothing drains in between.  Inside a tile block b is reached
+    // through slot_*[b mod NS]; the kernel rotates the table by NB mod NS slots when it moves to its next tile.
+    uint32_t slot_lane[NS_];   // LDS byte address of a slot + lane*16 (fragment reads)
+    uint32_t slot_u32[NS_];    // LDS byte address of a slot (DMA destination, wave-uniform)
+    const char *gstream_next;  // the next tile's stream + lane*16 (the same model here)
+    int has_next;              // this workgroup has another tile after the current one (workgroup-uniform)
 };
 
-// LDS-DMA of this wave's share of stream block BB into its ring slot.
-template <int BB, class C>
+typedef __attribute__((address_space(3))) const bf16x8 lds_frag_t;
+
+// LDS-DMA of this wave's share of stream block BB into its ring slot.  SRC >= 0: block SRC of the NEXT tile's
+// stream goes into the slot that block BB of the through-numbered stream owns (CONTINUOUS).
+// SEL: 0 = every wave issues; 1 = only waves with c.lag == 0; 2 = only waves with c.lag != 0.  The selection is a
+// scalar branch INSIDE the asm statement: to the compiler the call site stays straight-line code (a C++ `if` around the
+// DMA splits the kernel's one large scheduling region and costs the view-branch kernels ~50 VGPRs and spills).
+template <int BB, class C, int SRC = -1, int SEL = 0>
 __device__ __forceinline__ void issue_block(const C &c) {
     constexpr int slot = BB % C::NS;
 #pragma unroll
     for (int i = 0; i < C::PIECES; ++i) {
         const int piece = c.wave * C::PIECES + i;
-        const char *g = c.gstream + (size_t)BB * C::BLOCK_BYTES + piece * 1024;
-        const uint32_t l = c.ring_u32 + slot * C::BLOCK_BYTES + piece * 1024;   // wave-uniform
+        const char *g = (SRC >= 0 ? c.gstream_next + (size_t)SRC * C::BLOCK_BYTES : c.gstream + (size_t)BB * C::BLOCK_BYTES) + piece * 1024;
+        const uint32_t l = ((C::OPT & 32) != 0 ? c.slot_u32[slot] : c.ring_u32 + slot * C::BLOCK_BYTES) + piece * 1024;   // wave-uniform
         unsigned keep;
-        asm volatile(
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %2\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, off\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "v"(g), "s"(l)
-            : "memory");
+        const int lag_s = SEL == 0 ? 0 : __builtin_amdgcn_readfirstlane(c.lag);     // certainly an SGPR for the asm's s_cmp
+        if constexpr (SEL == 0) {
+            asm volatile(
+                "s_mov_b32 %0, m0\n\t"
+                "s_mov_b32 m0, %2\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %1, off\n\t"
+                "s_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "v"(g), "s"(l)
+                : "memory");
+        } else if constexpr (SEL == 1) {
+            asm volatile(
+                "s_cmp_lg_u32 %3, 0\n\t"
+                "s_cbranch_scc1 .Lskip_dma_%=\n\t"
+                "s_mov_b32 %0, m0\n\t"
+                "s_mov_b32 m0, %2\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %1, off\n\t"
+                "s_mov_b32 m0, %0\n"
+                ".Lskip_dma_%=:"
+                : "=&s"(keep)
+                : "v"(g), "s"(l), "s"(lag_s)
+                : "memory", "scc");
+        } else {
+            asm volatile(
+                "s_cmp_eq_u32 %3, 0\n\t"
+                "s_cbranch_scc1 .Lskip_dma_%=\n\t"
+                "s_mov_b32 %0, m0\n\t"
+                "s_mov_b32 m0, %2\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %1, off\n\t"
+                "s_mov_b32 m0, %0\n"
+                ".Lskip_dma_%=:"
+                : "=&s"(keep)
+                : "v"(g), "s"(l), "s"(lag_s)
+                : "memory", "scc");
+        }
+    }
+}
+
+// The DMA that sync S_B starts: block B+NS-1 of this tile, or (CONTINUOUS, with a next tile) the block of the next tile
+// that owns the same ring slot.  LATE = false: the call right behind the barrier (all waves, or with SPLIT_DMA the
+// early half); LATE = true: the late half's call half a block later.
+template <int B, int NB, bool LATE, class C>
+__device__ __forceinline__ void sync_issue(const C &c) {
+    constexpr int BB = B + C::NS - 1;
+    constexpr bool split = (C::OPT & 8) != 0;
+    if constexpr (LATE && !split) return;
+    constexpr int SEL = !split ? 0 : LATE ? 2 : 1;
+    if constexpr (BB < NB) {
+        issue_block<BB, C, -1, SEL>(c);
+    } else if constexpr ((C::OPT & 32) != 0 && BB - NB < C::NS - 1 - C::LOOKAHEAD) {
+        // the next tile's blocks 0 .. NS-2-LOOKAHEAD are what its own prologue would have issued
+        if (c.has_next) issue_block<BB, C, BB - NB, SEL>(c);
     }
 }
 
@@ -112,20 +172,24 @@ __device__ __forceinline__ void block_sync(const C &c) {
     static_assert(younger_stores >= 0, "ledger must be monotonic");
     constexpr int cnt = (last_issued > need ? last_issued - need : 0) * C::PIECES + younger_stores;
     static_assert(cnt <= 63, "vmcnt field is 6 bits");
+    // CONTINUOUS: blocks NB, NB+1, ... are the next tile's first blocks, in flight only if there is a next tile.  A sync
+    // whose allowance would include one of them (B + NS - 2 >= NB) picks its count at run time.
+    constexpr bool next_in_window = (C::OPT & 32) != 0 && C::PHASE > 0 && (B + C::NS - 2) >= NB;
+    constexpr int cnt_next = ((B + C::NS - 2) - need) * C::PIECES;
+    static_assert(cnt_next <= 63, "vmcnt field is 6 bits");
     if constexpr (C::PHASE == 0) {
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(cnt) : "memory");
+    } else if constexpr (next_in_window) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (c.has_next) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(cnt_next) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(cnt) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
     } else {
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(cnt) : "memory");
         __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (B + C::NS - 1 < NB) {
-        if constexpr ((C::OPT & 8) != 0) {     // SPLIT_DMA: the late half issues its pieces half a block later (late_issue)
-            if (!c.lag) issue_block<B + C::NS - 1>(c);
-        } else {
-            issue_block<B + C::NS - 1>(c);
-        }
-    }
+    sync_issue<B, NB, false>(c);
 }
 
 // OPT & 8 (SPLIT_DMA): waves WAVES/2.. issue their DMA pieces of block b+NS-1 half a block after sync S_b instead of
@@ -136,11 +200,9 @@ template <int n, int NB, class C>
 __device__ __forceinline__ void late_issue(const C &c) {
     if constexpr ((C::OPT & 8) != 0 && C::PHASE > 0) {
         constexpr int half = (C::PHASE + C::BF / 2) % C::BF;
-        if constexpr (n % C::BF == half) {
-            constexpr int B = (n - C::PHASE - C::BF / 2) / C::BF;     // the sync half a block ago
-            if constexpr (B >= -1 && B + C::NS - 1 < NB && (n - C::PHASE - C::BF / 2) >= -C::BF) {
-                if (c.lag) issue_block<B + C::NS - 1>(c);
-            }
+        if constexpr (n % C::BF == half && (n - C::PHASE - C::BF / 2) >= -C::BF) {
+            constexpr int B = (n - C::PHASE - C::BF / 2) / C::BF;     // the sync half a block ago (n = 0: the prologue's sync -1)
+            if constexpr (B >= -1 && B + C::LOOKAHEAD < NB) sync_issue<B, NB, true>(c);
         }
     }
 }
@@ -153,7 +215,10 @@ __device__ __forceinline__ void pipeline_prologue(const C &c) {
 
 template <int n, class C>
 __device__ __forceinline__ bf16x8 ring_frag(const C &c) {
-    return *reinterpret_cast<const bf16x8 *>(c.ring_lane + ((n % (C::NS * C::BF)) << 10));
+    if constexpr ((C::OPT & 32) != 0)
+        return *(lds_frag_t *)(uintptr_t)(c.slot_lane[(n / C::BF) % C::NS] + ((n % C::BF) << 10));
+    else
+        return *reinterpret_cast<const bf16x8 *>(c.ring_lane + ((n % (C::NS * C::BF)) << 10));
 }
 
 // Sync S_b publishes block b+1 and refills the slot of block b-1 with block b+NS-1.  The early waves reach it

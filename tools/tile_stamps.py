@@ -27,24 +27,33 @@ def main():
     R, S = 4096, 192
     pts = (torch.rand(R, S, 3, generator=g) * 6 - 3).to(dev)
     vd = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1).to(dev)
-    for _ in range(20):
-        m(pts, vd)
-    torch.cuda.synchronize()
-    buf = torch.zeros(256 * 8 * 4, dtype=torch.int64, device=dev)
-    fn(buf.data_ptr())
-    for _ in range(10):
-        m(pts, vd)
-    torch.cuda.synchronize()
-    fn(None)
-    b = buf.cpu().reshape(256, 8, 4).double()
-    per_tile = b[..., :3] / b[..., 3:4]
     out = {}
-    for name, half in (("waves0-3", slice(0, 4)), ("waves4-7", slice(4, 8))):
-        x = per_tile[:, half].reshape(-1, 3)
-        med = x.median(0).values
-        out[name] = {"start": float(med[0]), "layers": float(med[1]), "drain": float(med[2]),
-                     "start_frac": float(med[0] / med.sum()), "drain_frac": float(med[2] / med.sum())}
-    out["tiles_per_wave"] = float(b[..., 3].mean())
+    for label, variant in (("pipelined", 0), ("per_tile", 41)):
+        _lib.check(_lib.lib.nerf_amd_set_tuning(0, variant), "set_tuning")
+        for _ in range(20):
+            m(pts, vd)
+        torch.cuda.synchronize()
+        buf = torch.zeros(256 * 8 * 4, dtype=torch.int64, device=dev)
+        fn(buf.data_ptr())
+        a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            m(pts, vd)
+        b_.record()
+        torch.cuda.synchronize()
+        fn(None)
+        b = buf.cpu().reshape(256, 8, 4).double()
+        per_tile = b[..., :3] / b[..., 3:4]
+        rec = {"ms_per_launch": a.elapsed_time(b_) / 10}
+        for name, half in (("waves0-3", slice(0, 4)), ("waves4-7", slice(4, 8))):
+            x = per_tile[:, half].reshape(-1, 3)
+            med = x.median(0).values
+            rec[name] = {"start": float(med[0]), "layers": float(med[1]), "drain": float(med[2]), "tile": float(med.sum())}
+        rec["tiles_per_wave"] = float(b[..., 3].mean())
+        # effective shader clock while the kernel runs: cycles a wave spent / wall time of the launches
+        rec["approx_clock_ghz"] = float(b[..., :3].sum(-1).median() / 10) / (rec["ms_per_launch"] * 1e6)
+        out[label] = rec
+    _lib.lib.nerf_amd_set_tuning(0, 0)
     out["mfma_floor_cycles_per_tile"] = 2344 * 16 * 2
     print(json.dumps(out, indent=1))
 
