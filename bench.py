@@ -318,9 +318,10 @@ def main():
         kern_s = kern_ms / 1e3
         achieved = (kern_pts * FLOP_PER_POINT / kern_s / 1e12) if kern_s > 0 else 0.0
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_FP32_TFLOPS
-        kernel = "mlp_bf16_s16_kernel" if cls == 1 else "mlp_f32_kernel"
+        kernel = "mlp_bf16_s16p_kernel" if cls == 1 else "mlp_f32_kernel"
         traffic = measured_traffic(kernel) if key == "c2" else None
-        chunk_rays = min(w["chunk"], rays_per_step)
+        # launches are per 32768-ray group (nerf_amd_render_batch), whatever the API chunk: coarse and fine launch alternate
+        chunk_rays = min(32768, rays_per_step)
         out = {
             "metric": "rays_per_sec", "value": value, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NERF_AMD_ABI_VERSION 2
+#define NERF_AMD_ABI_VERSION 3
 
 #define NERF_AMD_OK            0
 #define NERF_AMD_EINVAL       -1   /* bad argument / unsupported shape        */
@@ -255,6 +255,20 @@ int     nerf_amd_render_rays(const nerf_amd_render_cfg *cfg, const nerf_amd_mode
 int     nerf_amd_render_chunks(const nerf_amd_render_cfg *cfg, const nerf_amd_model *coarse,
                                const nerf_amd_model *fine, const nerf_amd_render_io *ios, const int64_t *R,
                                int32_t n_chunks, void *stream);
+
+/* Renderer.render_batch (render_utils.py:51-65) over CONTIGUOUS whole-batch buffers: `io` describes all N rays exactly as
+ * for nerf_amd_render_rays (rays [N,ray_ch], draws [N,.] -- made per chunk by the caller, in the reference's order, into
+ * rows of one buffer each --, outputs [N,.]); z_coarse [N,N_samples] is normally given (one nerf_amd_coarse_z launch).
+ * Results are bit-identical to per-chunk nerf_amd_render_rays calls (every kernel is per-ray independent), but the
+ * launches are not tied to the caller's chunk size: rays are processed in groups of 32768, the two field kernels of
+ * consecutive groups run back to back on `stream`, and the per-ray kernels (coarse compositing + resampling, final
+ * compositing) run on a library-owned side stream BESIDE the next field kernel, ordered with events
+ *      stream:  C0 C1 F0 C2 F1 C3 F2 ...          side:  M0  M1+Fin0  M2+Fin1 ...  Fin(n-1)
+ * The call returns with `stream` ordered behind the last kernel of either stream.  Workspace:
+ * nerf_amd_render_batch_workspace(cfg, N, out_ch) bytes (three groups' scratch in rotation), 256-B aligned. */
+int64_t nerf_amd_render_batch_workspace(const nerf_amd_render_cfg *cfg, int64_t N, int32_t out_ch);
+int     nerf_amd_render_batch(const nerf_amd_render_cfg *cfg, const nerf_amd_model *coarse,
+                              const nerf_amd_model *fine, const nerf_amd_render_io *io, int64_t N, void *stream);
 
 /* ------------------------------------------------------------------------
  * a12/a13 + ray-batch assembly of Renderer.render   utils.py:33-71, render_utils.py:200-226

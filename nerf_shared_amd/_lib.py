@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NERF_AMD_LIB selects another build of the same library (diagnostic builds such as -DNERF_AMD_STAMPS)
 LIB_PATH = os.environ.get("NERF_AMD_LIB") or os.path.join(_HERE, "libnerf_amd.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 PREC_FP32, PREC_BF16 = 0, 1
 MAX_SKIPS = 8
 
@@ -23,6 +23,7 @@ EXPORTS = (
     "nerf_amd_model_supports_bf16", "nerf_amd_model_out_ch", "nerf_amd_pack_bf16_host",
     "nerf_amd_embed", "nerf_amd_nerf_forward", "nerf_amd_mlp_embedded", "nerf_amd_ndc_rays", "nerf_amd_raw2outputs", "nerf_amd_raw2outputs_backward", "nerf_amd_sample_pdf",
     "nerf_amd_render_rays_workspace", "nerf_amd_render_rays", "nerf_amd_render_chunks", "nerf_amd_make_rays",
+    "nerf_amd_render_batch_workspace", "nerf_amd_render_batch",
     "nerf_amd_profile_enable", "nerf_amd_profile_collect", "nerf_amd_set_tuning",
     "nerf_amd_model_supports_training", "nerf_amd_train_workspace", "nerf_amd_field_forward_train",
     "nerf_amd_field_backward", "nerf_amd_coarse_z", "nerf_amd_resample", "nerf_amd_get_rays_backward", "nerf_amd_to8b", "nerf_amd_ndc_rays_backward",
@@ -84,6 +85,8 @@ def _load():
         "nerf_amd_render_rays": (c_int, [POINTER(RenderCfg), c_void_p, c_void_p, POINTER(RenderIO), c_int64, c_void_p]),
         "nerf_amd_render_chunks": (c_int, [POINTER(RenderCfg), c_void_p, c_void_p, POINTER(RenderIO), POINTER(c_int64),
                                            c_int32, c_void_p]),
+        "nerf_amd_render_batch_workspace": (c_int64, [POINTER(RenderCfg), c_int64, c_int32]),
+        "nerf_amd_render_batch": (c_int, [POINTER(RenderCfg), c_void_p, c_void_p, POINTER(RenderIO), c_int64, c_void_p]),
         "nerf_amd_make_rays": (c_int, [c_int32, c_int32, POINTER(c_double), POINTER(c_float), POINTER(c_float),
                                        c_int64, c_int64, c_float, c_float, c_int, c_int, c_void_p, c_void_p]),
         "nerf_amd_set_tuning": (c_int, [c_int, c_int]),

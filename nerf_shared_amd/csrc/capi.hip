@@ -582,6 +582,145 @@ int nerf_amd_render_chunks(const nerf_amd_render_cfg *cfg, const nerf_amd_model 
     return rc;
 }
 
+}  // extern "C"
+
+// ---- Renderer.render_batch as ONE call over contiguous whole-batch buffers -------------------------------------
+namespace {
+constexpr int64_t SUPER_CHUNK_RAYS = 32768;      // rays per launch group (the reference's own default chunk)
+constexpr int BATCH_SLOTS = 3;                   // workspaces in rotation: a group is live from its coarse field to its final compositing
+
+// The side stream and a pool of timing-less events per device.  Streams are created once; events are handed out and
+// taken back under the mutex (an event can be re-recorded as soon as every wait on it has been ENQUEUED).
+struct SideLane {
+    hipStream_t stream = nullptr;
+    std::vector<hipEvent_t> free_events;
+};
+std::mutex g_lane_mu;
+SideLane g_lanes[64];
+
+int lane_acquire(int device, int n_events, hipStream_t *side, std::vector<hipEvent_t> *events) {
+    if (device < 0 || device >= 64) return fail(NERF_AMD_EINVAL, "device index out of range");
+    std::lock_guard<std::mutex> lk(g_lane_mu);
+    SideLane &l = g_lanes[device];
+    if (!l.stream) HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+    *side = l.stream;
+    events->clear();
+    for (int i = 0; i < n_events; ++i) {
+        hipEvent_t e;
+        if (!l.free_events.empty()) { e = l.free_events.back(); l.free_events.pop_back(); }
+        else HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        events->push_back(e);
+    }
+    return NERF_AMD_OK;
+}
+void lane_release(int device, const std::vector<hipEvent_t> &events) {
+    std::lock_guard<std::mutex> lk(g_lane_mu);
+    for (hipEvent_t e : events) g_lanes[device].free_events.push_back(e);
+}
+
+// rows [r0, r0 + R) of a whole-batch io, with `ws` as its workspace
+nerf_amd_render_io io_rows(const nerf_amd_render_cfg *cfg, const nerf_amd_render_io &io, int64_t r0, int och, void *ws, int64_t ws_bytes) {
+    nerf_amd_render_io o = io;
+    const int64_t Nc = cfg->N_samples, Ni = cfg->N_importance, Sl = Nc + Ni;
+    auto f = [&](const float *p, int64_t row_floats) { return p ? p + r0 * row_floats : nullptr; };
+    auto g = [&](float *p, int64_t row_floats) { return p ? p + r0 * row_floats : nullptr; };
+    o.rays = f(io.rays, io.ray_ch);
+    o.t_rand = f(io.t_rand, Nc); o.noise0 = f(io.noise0, Nc); o.noise1 = f(io.noise1, Sl);
+    o.u = f(io.u, Ni); o.z_coarse = f(io.z_coarse, Nc);
+    o.rgb_map = g(io.rgb_map, 3); o.disp_map = g(io.disp_map, 1); o.acc_map = g(io.acc_map, 1);
+    o.rgb0 = g(io.rgb0, 3); o.disp0 = g(io.disp0, 1); o.acc0 = g(io.acc0, 1); o.z_std = g(io.z_std, 1);
+    o.raw = g(io.raw, Sl * och); o.weights = g(io.weights, Sl); o.z_vals = g(io.z_vals, Sl);
+    o.workspace = ws; o.workspace_bytes = ws_bytes;
+    return o;
+}
+
+int64_t n_super_chunks(int64_t N) { return N <= SUPER_CHUNK_RAYS + SUPER_CHUNK_RAYS / 2 ? 1 : (N + SUPER_CHUNK_RAYS - 1) / SUPER_CHUNK_RAYS; }
+}  // namespace
+
+extern "C" {
+
+int64_t nerf_amd_render_batch_workspace(const nerf_amd_render_cfg *cfg, int64_t N, int32_t out_ch) {
+    if (!cfg || N < 0) return -1;
+    const int64_t n = n_super_chunks(N);
+    const int64_t per = nerf_amd_render_rays_workspace(cfg, n == 1 ? N : SUPER_CHUNK_RAYS, out_ch);
+    return per * (n < BATCH_SLOTS ? n : BATCH_SLOTS);
+}
+
+int nerf_amd_render_batch(const nerf_amd_render_cfg *cfg, const nerf_amd_model *coarse, const nerf_amd_model *fine,
+                          const nerf_amd_render_io *io, int64_t N, void *stream) {
+    if (!cfg || !coarse || !io || N < 0) return fail(NERF_AMD_EINVAL, "null argument");
+    if (N == 0) return NERF_AMD_OK;
+    const int64_t n = n_super_chunks(N);
+    if (n == 1) return nerf_amd_render_rays(cfg, coarse, fine, io, N, stream);
+    const int och = coarse->prog.out_ch;
+    const int64_t per = nerf_amd_render_rays_workspace(cfg, SUPER_CHUNK_RAYS, och);
+    const int slots = (int)(n < BATCH_SLOTS ? n : BATCH_SLOTS);
+    if (!io->workspace || io->workspace_bytes < per * slots) return fail(NERF_AMD_EINVAL, "workspace too small (nerf_amd_render_batch_workspace)");
+    if (!io->z_coarse && cfg->perturb && !io->t_rand) return fail(NERF_AMD_EINVAL, "perturb set but neither z_coarse nor t_rand given");
+
+    std::vector<nerf_amd_render_io> ios((size_t)n);
+    std::vector<ChunkPlan> plans((size_t)n);
+    for (int64_t k = 0; k < n; ++k) {
+        const int64_t r0 = k * SUPER_CHUNK_RAYS, R = (k + 1 == n) ? N - r0 : SUPER_CHUNK_RAYS;
+        ios[k] = io_rows(cfg, *io, r0, och, static_cast<char *>(io->workspace) + (k % slots) * per, per);
+        int rc = plan_chunk(cfg, coarse, fine, &ios[k], R, &plans[k]);
+        if (rc) return rc;
+    }
+    hipStream_t main_s = static_cast<hipStream_t>(stream), side = nullptr;
+    const int device = coarse->device;
+    const bool two_pass = plans[0].Ni > 0;
+    std::vector<hipEvent_t> ev;
+    int rc = lane_acquire(device, (int)(3 * n + 1), &side, &ev);
+    if (rc) return rc;
+    hipEvent_t *ec = ev.data(), *em = ev.data() + n, *ef = ev.data() + 2 * n;   // coarse field done / side-stream stage done / fine field done
+    hipEvent_t start = ev[3 * n];
+    auto H = [&](hipError_t e, const char *what) { if (e != hipSuccess && !rc) rc = hip_fail(e, what); };
+    // the side stream starts behind everything the caller has enqueued so far (inputs, packed weights)
+    H(hipEventRecord(start, main_s), "hipEventRecord");
+    H(hipStreamWaitEvent(side, start, 0), "hipStreamWaitEvent");
+
+    auto coarse_field = [&](int64_t k) {
+        if (k >= slots) H(hipStreamWaitEvent(main_s, em[k - slots + (two_pass ? 1 : 0)], 0), "hipStreamWaitEvent");   // its workspace is free again
+        if (!rc) rc = stage_z(plans[k], main_s);
+        if (!rc) rc = stage_field(plans[k], false, main_s);
+        H(hipEventRecord(ec[k], main_s), "hipEventRecord");
+    };
+    if (two_pass) {
+        // main:  C0 C1 F0 C2 F1 C3 F2 ...        side:  M0  M1+Fin0  M2+Fin1 ... Fin(n-1)
+        // M = coarse compositing + resampling (needs C), Fin = final compositing (needs F), both per-ray kernels that run
+        // beside the next field kernel instead of between two of them.
+        coarse_field(0);
+        for (int64_t k = 0; k < n && !rc; ++k) {
+            if (k + 1 < n) coarse_field(k + 1);
+            H(hipStreamWaitEvent(side, ec[k], 0), "hipStreamWaitEvent");
+            if (k > 0) H(hipStreamWaitEvent(side, ef[k - 1], 0), "hipStreamWaitEvent");
+            if (!rc) rc = stage_mid(plans[k], k > 0 ? &plans[k - 1] : nullptr, side);
+            H(hipEventRecord(em[k], side), "hipEventRecord");
+            H(hipStreamWaitEvent(main_s, em[k], 0), "hipStreamWaitEvent");
+            if (!rc) rc = stage_field(plans[k], true, main_s);
+            H(hipEventRecord(ef[k], main_s), "hipEventRecord");
+        }
+        H(hipStreamWaitEvent(side, ef[n - 1], 0), "hipStreamWaitEvent");
+        if (!rc) rc = stage_final(plans[n - 1], side);
+    } else {
+        for (int64_t k = 0; k < n && !rc; ++k) {
+            coarse_field(k);
+            H(hipStreamWaitEvent(side, ec[k], 0), "hipStreamWaitEvent");
+            if (!rc) rc = stage_final(plans[k], side);
+            H(hipEventRecord(em[k], side), "hipEventRecord");
+        }
+    }
+    // the caller's stream continues behind the last per-ray kernel
+    H(hipEventRecord(start, side), "hipEventRecord");
+    H(hipStreamWaitEvent(main_s, start, 0), "hipStreamWaitEvent");
+    lane_release(device, ev);
+    return rc;
+}
+
+}  // extern "C"
+
+extern "C" {
+
 int nerf_amd_set_tuning(int key, int value) {
     if (key == 0 && value >= 0 && value <= 115) { g_variant = value; return NERF_AMD_OK; }
     return fail(NERF_AMD_EINVAL, "unknown tuning key/value");

@@ -228,6 +228,54 @@ class Renderer(torch.nn.Module):
         # keep the draws alive until the stream has consumed them (caching allocator is stream-ordered)
         return keep
 
+    def _launch_batch(self, rays, starts, chunk, coarse_model, fine_model, full):
+        """render_batch as ONE library call over whole-batch buffers (nerf_amd_render_batch).  The random draws are made
+        per chunk, in the reference's order (t_rand, noise0, u, noise1 of chunk 0, then of chunk 1, ...), into the rows of
+        one buffer each -- `slice.uniform_()` / `slice.normal_()` consume the generator exactly like the reference's
+        torch.rand / torch.randn of the same shape -- so the result equals per-chunk render_rays calls bit for bit, while
+        the library is free to launch in groups that suit the GPU and to run the per-ray kernels beside the field kernels."""
+        dev = rays.device
+        hc, hf, cfg, out_ch = self._handles(dev, coarse_model, fine_model)
+        N, Nc, Ni = rays.shape[0], int(self.N_samples), int(self.N_importance)
+        f = dict(device=dev, dtype=torch.float32)
+        z_all = torch.empty(N, Nc, **f)
+        t_all = torch.empty(N, Nc, **f) if self.perturb > 0. else None
+        noisy = self.raw_noise_std > 0.
+        n0_all = torch.empty(N, Nc, **f) if noisy else None
+        n1_all = torch.empty(N, Nc + Ni, **f) if (noisy and Ni > 0) else None
+        u_all = torch.empty(N, Ni, **f) if (Ni > 0 and self.perturb > 0.) else None
+        for i in starts:                                   # the reference's order inside every render_rays call
+            if t_all is not None:
+                t_all[i:i + chunk].uniform_()
+            if n0_all is not None:
+                n0_all[i:i + chunk].normal_()
+            if u_all is not None:
+                u_all[i:i + chunk].uniform_()
+            if n1_all is not None:
+                n1_all[i:i + chunk].normal_()
+        if noisy:
+            n0_all.mul_(self.raw_noise_std)
+            if n1_all is not None:
+                n1_all.mul_(self.raw_noise_std)
+        io = _lib.RenderIO()
+        io.rays, io.ray_ch = rays.data_ptr(), rays.shape[1]
+        io.t_vals = _linspace01(Nc, dev).data_ptr()
+        io.t_rand, io.noise0, io.noise1, io.u = _lib.ptr(t_all), _lib.ptr(n0_all), _lib.ptr(n1_all), _lib.ptr(u_all)
+        io.t_lin_imp = _linspace01(Ni, dev).data_ptr() if (Ni > 0 and u_all is None) else None
+        io.z_coarse = z_all.data_ptr()
+        for k in ('rgb_map', 'disp_map', 'acc_map', 'rgb0', 'disp0', 'acc0', 'z_std', 'raw', 'weights', 'z_vals'):
+            setattr(io, k, _lib.ptr(full.get(k)))
+        ws = _workspace(dev, lib.nerf_amd_render_batch_workspace(cfg, N, out_ch))
+        io.workspace, io.workspace_bytes = ws.data_ptr(), ws.numel()
+        with torch.cuda.device(dev):
+            _lib.check(lib.nerf_amd_coarse_z(rays.data_ptr(), rays.shape[1], _linspace01(Nc, dev).data_ptr(),
+                                             _lib.ptr(t_all), N, Nc, int(bool(self.lindisp)), int(self.perturb > 0.),
+                                             z_all.data_ptr(), _lib.stream_of(dev)), "nerf_amd_coarse_z")
+            _lib.check(lib.nerf_amd_render_batch(cfg, hc, hf, io, N, _lib.stream_of(dev)), "nerf_amd_render_batch")
+        # the library's side stream reads these too; its work is ordered before the caller's stream continues, so
+        # releasing them to the caching allocator (stream-ordered on the caller's stream) is safe
+        return (rays, z_all, t_all, n0_all, n1_all, u_all, ws)
+
     def _launch_chunks(self, rays, starts, chunk, coarse_model, fine_model, full):
         """render_batch's chunk loop as one library call (nerf_amd_render_chunks): per-chunk draws (in the
         reference's per-chunk order) and output rows exactly as _launch makes them, two workspaces used
@@ -366,13 +414,19 @@ class Renderer(torch.nn.Module):
                     print(f"! [Numerical Error] {k} contains nan or inf.")
         return ret
 
-    fuse_chunk_launches = True    # render_batch: one library call for all chunks (three dependent launches per chunk)
-    overlap_chunks = False    # opt-in: two-stream chunk pipeline of render_batch (+~3 % at 4096-ray chunks)
+    pipeline_batch = True         # render_batch: one library call over whole-batch buffers (nerf_amd_render_batch): launch
+                                  # groups of 32768 rays, per-ray kernels on a side stream beside the next field kernel
+    fuse_chunk_launches = True    # (pipeline_batch off) one library call per chunk list (three dependent launches per chunk)
+    overlap_chunks = False        # (pipeline_batch off) opt-in: two-stream chunk pipeline, two field kernels at a time
 
     def render_batch(self, coarse_model, fine_model, rays_flat, chunk=1024 * 32, retraw=False):
         """Render rays in chunks (render_utils.py:51-65).  Outputs of every chunk land
         directly in one preallocated tensor per key (the reference's per-key torch.cat,
-        without the copy).  With ``Renderer.overlap_chunks = True`` consecutive chunks
+        without the copy).  By default (``Renderer.pipeline_batch``) the whole batch goes to the
+        library in one call: `chunk` then only decides how the random draws are grouped (as in
+        the reference), not how the GPU is launched -- every kernel is per-ray independent, so the
+        result is the same bit for bit.  The older modes remain for A/B runs:
+        with ``Renderer.overlap_chunks = True`` consecutive chunks
         alternate between two HIP streams (each with its own workspace) so the small
         per-ray kernels and launch/drain gaps of one chunk hide under the field kernel
         of the other; results do not depend on it (random draws come from the device's one
@@ -394,6 +448,9 @@ class Renderer(torch.nn.Module):
                 for k, v in r.items():
                     parts.setdefault(k, []).append(v)
             return {k: torch.cat(v, 0) for k, v in parts.items()}
+        if self.pipeline_batch and N > 0 and (len(starts) > 1 or N > 49152):
+            self._launch_batch(rays, starts, chunk, coarse_model, fine_model, full)
+            return full
         if not (self.overlap_chunks and len(starts) > 1):
             if len(starts) > 1 and self.fuse_chunk_launches:
                 self._launch_chunks(rays, starts, chunk, coarse_model, fine_model, full)

@@ -710,20 +710,56 @@ def test_seeded_multichunk_render_equals_per_chunk_render_rays(dev):
     torch.manual_seed(11)
     want = [r.render_rays(batch[i:i + chunk], c, f) for i in range(0, 1000, chunk)]
     want = {k: torch.cat([w[k] for w in want], 0) for k in want[0]}
-    modes = {"fused": (True, False), "per_chunk": (False, False), "overlap": (True, True)}
+    R = render_utils.Renderer
+    modes = {"pipeline_batch": (True, True, False), "fused": (False, True, False), "per_chunk": (False, False, False),
+             "overlap": (False, True, True)}
     try:
-        for name, (fuse, overlap) in modes.items():
-            render_utils.Renderer.fuse_chunk_launches, render_utils.Renderer.overlap_chunks = fuse, overlap
+        for name, (pipe, fuse, overlap) in modes.items():
+            R.pipeline_batch, R.fuse_chunk_launches, R.overlap_chunks = pipe, fuse, overlap
             torch.manual_seed(11)
             got = r.render_batch(c, f, batch, chunk=chunk)
             torch.cuda.synchronize()
             for k in want:
                 assert torch.equal(torch.nan_to_num(got[k]), torch.nan_to_num(want[k])), (name, k)
     finally:
-        render_utils.Renderer.fuse_chunk_launches, render_utils.Renderer.overlap_chunks = True, False
+        R.pipeline_batch, R.fuse_chunk_launches, R.overlap_chunks = True, True, False
     torch.manual_seed(12)                                             # and another seed gives another image
     other = r.render_batch(c, f, batch, chunk=chunk)
     assert not torch.equal(other["rgb_map"], want["rgb_map"])
+
+
+def test_pipelined_batch_over_several_launch_groups(dev):
+    """nerf_amd_render_batch: 100 000 rays = three full 32768-ray launch groups and a ragged fourth, per-ray kernels on the
+    library's side stream.  Every output equals the chunk-at-a-time path bit for bit -- deterministic, with random draws
+    (perturb + noise, chunk 4096: 25 chunks of draws inside 4 launch groups), coarse-only, and with raw / no fine model."""
+    _, render_utils, utils = amd()
+    R = render_utils.Renderer
+    K = synth.lego_intrinsics(400, 400)
+    batch = utils.make_ray_batch(400, 400, K, synth.LEGO_C2W, 2.0, 6.0, True, False, device=dev, pix0=30000, n=100000)
+    c, f = gpu_model(dev, 1, 3.0, "bf16", **VD), gpu_model(dev, 19, 3.0, "bf16", **VD)
+    cases = ((dict(), 32768, f, False, None), (dict(perturb=1.0, raw_noise_std=1.0), 4096, f, False, 5),
+             (dict(N_importance=0), 40000, None, False, None), (dict(N_samples=32, N_importance=32), 50000, None, True, None))
+    for over, chunk, fine, retraw, seed in cases:
+        r = R(**dict(BASE, **over))
+        outs = []
+        for pipe in (True, False):
+            R.pipeline_batch = pipe
+            try:
+                if seed is not None:
+                    torch.manual_seed(seed)
+                outs.append(r.render_batch(c, fine, batch, chunk=chunk, retraw=retraw))
+                torch.cuda.synchronize()
+            finally:
+                R.pipeline_batch = True
+        assert sorted(outs[0]) == sorted(outs[1])
+        for k in outs[0]:
+            assert torch.equal(torch.nan_to_num(outs[0][k]), torch.nan_to_num(outs[1][k])), (over, k)
+    # back-to-back calls reuse the side stream and its events: results stay put
+    r = R(**BASE)
+    a = r.render_batch(c, f, batch, chunk=32768)
+    b = r.render_batch(c, f, batch, chunk=32768)
+    torch.cuda.synchronize()
+    assert torch.equal(a["rgb_map"], b["rgb_map"]) and torch.equal(a["z_std"], b["z_std"])
 
 
 def test_renders_on_two_streams_do_not_share_scratch(dev):
@@ -839,33 +875,34 @@ def test_staticcam_overlap_and_batch_poses(dev, tmp_path):
     assert not torch.equal(plain, rgb)
     # two-stream chunk overlap: bit-identical results
     try:
-        render_utils.Renderer.overlap_chunks = True
+        render_utils.Renderer.overlap_chunks, render_utils.Renderer.pipeline_batch = True, False
         rgb2 = r.render(H, W, K, coarse_gpu, fine_gpu, chunk=100, c2w=c2w, c2w_staticcam=c2w_s, retraw=False)[0]
     finally:
-        render_utils.Renderer.overlap_chunks = False
+        render_utils.Renderer.overlap_chunks, render_utils.Renderer.pipeline_batch = False, True
     rgb1 = r.render(H, W, K, coarse_gpu, fine_gpu, chunk=100, c2w=c2w, c2w_staticcam=c2w_s, retraw=False)[0]
     close(rgb2, rgb1, atol=0)
     # batch of poses -> frames on disk
     # render_batch as one library call (nerf_amd_render_chunks: final compositing of chunk k-1 inside chunk k's
     # compositing/resampling launch; 6 chunks here, the last one ragged) against one render_rays call per
     # chunk: bit-identical, every output, deterministic and with random draws
-    assert render_utils.Renderer.fuse_chunk_launches
+    assert render_utils.Renderer.fuse_chunk_launches and render_utils.Renderer.pipeline_batch
     for rcfg, seed in ((cfg, None), (dict(cfg, perturb=1.0, raw_noise_std=1.0), 3), (dict(cfg, N_importance=0), None)):
         rr = render_utils.Renderer(**rcfg)
         outs = []
-        for fused in (True, False):
-            render_utils.Renderer.fuse_chunk_launches = fused
+        for pipe, fused in ((True, True), (False, True), (False, False)):      # whole-batch call / chunk list / one call per chunk
+            render_utils.Renderer.pipeline_batch, render_utils.Renderer.fuse_chunk_launches = pipe, fused
             try:
                 if seed is not None:
                     torch.manual_seed(seed)
                 outs.append(rr.render(H, W, K, coarse_gpu, fine_gpu, chunk=100, c2w=c2w, retraw=True))
             finally:
-                render_utils.Renderer.fuse_chunk_launches = True
-        for a, b in zip(outs[0][:3], outs[1][:3]):
-            assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
-        assert sorted(outs[0][3]) == sorted(outs[1][3])
-        for k in outs[0][3]:
-            assert torch.equal(torch.nan_to_num(outs[0][3][k]), torch.nan_to_num(outs[1][3][k])), k
+                render_utils.Renderer.pipeline_batch, render_utils.Renderer.fuse_chunk_launches = True, True
+        for other in outs[1:]:
+            for a, b in zip(outs[0][:3], other[:3]):
+                assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
+            assert sorted(outs[0][3]) == sorted(other[3])
+            for k in outs[0][3]:
+                assert torch.equal(torch.nan_to_num(outs[0][3][k]), torch.nan_to_num(other[3][k])), k
     # batch of poses -> quantised on the GPU, PNG frames on disk (asynchronous and synchronous writers)
     from nerf_shared_amd import image_io, utils as amd_utils
     want8 = amd_utils.to8b(plain.cpu().numpy())                 # the reference's numpy to8b
