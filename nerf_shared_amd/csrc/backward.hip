@@ -187,6 +187,185 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(DwReduceArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// dw2_kernel: the 256 x 256 weight-gradient product (16 of the 20 products of a training step) as a streaming kernel
+// that keeps HBM busy.  The first version above stages every 32-point chunk through registers, has one chunk of loads
+// in flight per CU (32 KB: less than the latency-bandwidth product of the memory system) and none while it writes LDS
+// and waits at its barrier: 3.5 TB/s.  Here
+//   * G and X rows go straight from HBM to LDS with LDS-DMA (global_load_lds_dwordx4, no VGPR staging) into a ring of
+//     four 32-point chunks, three chunks (96 KB per CU) in flight, one counted-vmcnt wait + one barrier per chunk;
+//   * the LDS image is XOR-swizzled at 16-byte granularity through the DMA's per-lane SOURCE addresses (the DMA's
+//     destination is lane-linear, its source is not): piece j of row r sits at j ^ swz(r), which makes the transposing
+//     operand reads (ds_read_b64_tr_b16, 8 rows x 32 B per 32-lane group) conflict-free on unpadded 512-byte rows;
+//   * the bias gradient (column sums of G) is one more MFMA column against an all-ones operand.
+// (Reduce jobs for the previous product's slabs inside this launch do not work out: every block of a launch reserves the
+// launch's 128 KB of LDS, so the ~1000 small reduce blocks would each occupy a whole CU.)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int dw_swz(int r) { return 2 * ((r & 3) | (((r >> 3) & 1) << 2)); }
+
+__device__ __forceinline__ bf16x8 tr_frag_swz(uint32_t img, int row_bytes, int col0, int lane) {
+    // 8 consecutive image rows (points 8g..8g+7) of column col0 + (lane & 15), as an MFMA 16x16x32 operand, from the
+    // swizzled image: 16-byte piece pc of row r lives at piece position pc ^ dw_swz(r) (dw_swz(r + 4) == dw_swz(r)).
+    const int i = lane & 15, g = lane >> 4;
+    const int r = 8 * g + (i >> 2);
+    const int pc = (col0 >> 3) + ((i & 3) >> 1);
+    const uint32_t p = img + r * row_bytes + ((pc ^ dw_swz(r)) << 4) + ((i & 1) << 3);
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(uintptr_t)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(uintptr_t)(p + 4 * row_bytes));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// One 1-KiB LDS-DMA piece: lane l fetches 16 bytes from g (per lane) into lds_base + 16 l.
+__device__ __forceinline__ void dma_piece(const char *g, uint32_t lds_base) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(g), "s"(lds_base)
+        : "memory");
+}
+
+__device__ __forceinline__ void dw_reduce_block(const DwReduceArgs &a, int block, int tid, float *part /* [8][64] LDS */) {
+    // 64 elements of the summed register dumps per job; the slabs are split eight ways over the block's waves
+    const int per = a.OT * a.IT * 256 + a.OT * 16;
+    const int t = tid & 63, grp = tid >> 6;
+    const int e = block * 64 + t;
+    float acc = 0.f;
+    if (e < per) {
+#pragma unroll 8
+        for (int b = grp; b < a.n_slabs; b += 8) acc += a.slab[(int64_t)b * per + e];
+    }
+    part[grp * 64 + t] = acc;
+    __syncthreads();
+    if (grp != 0 || e >= per) return;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) acc += part[k * 64 + t];
+    if (e < a.OT * a.IT * 256) {
+        const int r = e & 3, lane = (e >> 2) & 63, tile = e >> 8;
+        const int to = tile / a.IT, ti = tile - to * a.IT;
+        const int o = slot_to_feature(a.out_kind, to * 16 + 4 * (lane >> 4) + r, 0);
+        const int i = slot_to_feature(a.in_kind, ti * 16 + (lane & 15), a.in_L);
+        if (i >= 0 && o >= 0 && i < a.m_valid && o < a.n_valid) a.dW[(int64_t)o * a.ld_dw + a.col_off + i] = acc;
+    } else if (a.db) {
+        const int o = slot_to_feature(a.out_kind, e - a.OT * a.IT * 256, 0);
+        if (o >= 0 && o < a.n_valid) a.db[o] = acc;
+    }
+}
+
+__global__ __launch_bounds__(512) void dw_reduce8_kernel(DwReduceArgs a) {
+    __shared__ float part[8 * 64];
+    dw_reduce_block(a, blockIdx.x, threadIdx.x, part);
+}
+
+template <int OT, int IT, int WO, int WI>
+__global__ __launch_bounds__(512, 2) void dw2_kernel(DwArgs a) {
+    static_assert(WO * WI == 8 && OT % WO == 0 && IT % WI == 0 && OT >= 8 && IT >= 8, "bad shape");
+    static_assert((OT & (OT - 1)) == 0 && (IT & (IT - 1)) == 0, "the swizzle needs power-of-two rows of >= 16 pieces");
+    constexpr int TO = OT / WO, TI = IT / WI;
+    constexpr int RG = OT * 32, RX = IT * 32;                   // row bytes (unpadded)
+    constexpr int PG = OT * 2, PX = IT * 2;                     // 16-byte pieces per row
+    constexpr int IMG = 32 * (RG + RX);                         // one chunk's image
+    constexpr int NS = 4;                                       // ring slots
+    constexpr int NI = OT + IT, CNT = (NI + 7) / 8;             // 1-KiB DMA instructions per chunk; per wave (the last ones may repeat)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wo = wave / WI, wi = wave % WI;
+    const int wg = blockIdx.x, nwg = gridDim.x;
+    const uint32_t ring = (uint32_t)(uintptr_t)smem;
+
+    const int64_t n_chunks = (a.P + 31) / 32;
+    const int64_t n_local = wg < n_chunks ? (n_chunks - wg + nwg - 1) / nwg : 0;     // chunks wg, wg + nwg, ...
+    // this wave's DMA instructions of a chunk: j = wave, wave + 8, ... (indices past NI repeat the last one: every wave
+    // issues exactly CNT, which keeps the counted waits compile-time constants)
+    auto issue_chunk = [&](int64_t i) {
+        int64_t ch = wg + i * nwg;
+        if (ch >= n_chunks) ch = n_chunks - 1;                  // past the end: a harmless re-read that is never consumed
+        const uint32_t slot = ring + (uint32_t)(i % NS) * IMG;
+        const int64_t p0 = ch * 32;
+#pragma unroll
+        for (int k = 0; k < CNT; ++k) {
+            int j = wave + 8 * k;
+            if (j >= NI) j = NI - 1;
+            const bool is_g = j < OT;
+            const int jj = is_g ? j : j - OT;
+            const int e = 64 * jj + lane;                       // 16-byte piece of the G (or X) image
+            const int pr = is_g ? PG : PX;
+            const int r = e / pr, pos = e % pr;
+            int64_t p = p0 + r;
+            if (p >= pad_points(a.P)) p = pad_points(a.P) - 1;  // rows exist up to the padded point count (kernels.h)
+            const char *src = is_g ? reinterpret_cast<const char *>(a.G) + (p * a.ldg) * 2 : reinterpret_cast<const char *>(a.X) + (p * a.ldx) * 2;
+            src += (pos ^ dw_swz(r)) << 4;
+            dma_piece(src, slot + (is_g ? 0 : 32 * RG) + 1024 * jj);
+        }
+    };
+
+    f32x4 acc[TO][TI], accb[TO];
+#pragma unroll
+    for (int x = 0; x < TO; ++x) {
+        accb[x] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int y = 0; y < TI; ++y) acc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+
+    if (n_local > 0) {
+        issue_chunk(0); issue_chunk(1); issue_chunk(2);
+        for (int64_t i = 0; i < n_local; ++i) {
+            // chunk i has landed (this wave's pieces; chunks i+1, i+2 stay in flight), everyone agrees, then the slot of
+            // chunk i-1 -- which every wave finished reading before it came here -- is refilled with chunk i+3
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * CNT) : "memory");
+            issue_chunk(i + 3);
+            const uint32_t gimg = ring + (uint32_t)(i % NS) * IMG, ximg = gimg + 32 * RG;
+            const int64_t ch = wg + i * nwg;
+            if (ch == n_chunks - 1 && (a.P & 31)) {             // the last chunk: rows past P hold the padding points' data
+                const int first = (int)(a.P & 31);
+                for (int e = tid; e < (32 - first) * (RG + RX) / 16; e += 512) {
+                    const int gp = (32 - first) * PG;
+                    const uint32_t off = e < gp ? gimg + first * RG + e * 16 : ximg + first * RX + (e - gp) * 16;
+                    *(__attribute__((address_space(3))) u32x4 *)(uintptr_t)off = (u32x4){0u, 0u, 0u, 0u};
+                }
+                __syncthreads();
+            }
+            bf16x8 A[TO], B[TI];
+#pragma unroll
+            for (int x = 0; x < TO; ++x) A[x] = tr_frag_swz(gimg, RG, (wo * TO + x) * 16, lane);
+#pragma unroll
+            for (int y = 0; y < TI; ++y) B[y] = tr_frag_swz(ximg, RX, (wi * TI + y) * 16, lane);
+#pragma unroll
+            for (int x = 0; x < TO; ++x) {
+#pragma unroll
+                for (int y = 0; y < TI; ++y)
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[x], B[y], acc[x][y], 0, 0, 0);
+                if (wi == 0) accb[x] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[x], ones, accb[x], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the trailing re-reads: no DMA may outlive the workgroup
+    }
+    // ---- this workgroup's partial tile as a register dump (1 KiB per 16x16 tile, fully coalesced) + the bias partials
+    float *slab = a.slab + (int64_t)wg * (OT * IT * 256 + OT * 16);
+#pragma unroll
+    for (int x = 0; x < TO; ++x)
+#pragma unroll
+        for (int y = 0; y < TI; ++y)
+            *reinterpret_cast<f32x4 *>(slab + (((wo * TO + x) * IT + (wi * TI + y)) * 64 + lane) * 4) = acc[x][y];
+    if (wi == 0 && (lane & 15) == 0) {                          // every column of accb holds the same sums: take column 0
+#pragma unroll
+        for (int x = 0; x < TO; ++x)
+            *reinterpret_cast<f32x4 *>(slab + OT * IT * 256 + (wo * TO + x) * 16 + 4 * (lane >> 4)) = accb[x];
+    }
+}
+
 // Heads (alpha_linear, rgb_linear): G = NO <= 4 natural-order columns of g_rawb [P, 4], X = [P, n_in]
 // slot-major.  A block walks 256-row tiles; a thread owns 8 consecutive X columns (one 16-byte load
 // per row) of every (256 / groups)-th row.  Partial sums meet in LDS and leave as one slab row per
@@ -280,8 +459,10 @@ namespace {
 struct TrainWs {
     uint16_t *sv_e, *sv_d, *sv_h, *sv_feat, *sv_hv, *g_rawb, *g_hv, *g_feat, *g_h;
     uint8_t *sv_bits;
-    float *slab;        // DW_GRID partial [256 x 256 + 256] fp32 results of one weight-gradient product
+    float *slab;        // 2 x DW_GRID partial [256 x 256 + 256] fp32 results of a weight-gradient product (alternating:
+                        // the reduction of one product runs beside the next product)
 };
+constexpr size_t SLAB_FLOATS = (size_t)256 * (256 * 256 + 256);
 constexpr int DW_GRID = 256;
 size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -301,7 +482,7 @@ int64_t carve(const Program &p, int64_t P_points, char *base, TrainWs *w) {
     t.g_hv = (uint16_t *)take(P * 128 * 2);
     t.g_feat = (uint16_t *)take(P * 256 * 2);
     t.g_h = (uint16_t *)take((size_t)8 * P * 256 * 2);
-    t.slab = (float *)take((size_t)DW_GRID * (256 * 256 + 256) * sizeof(float));
+    t.slab = (float *)take(2 * SLAB_FLOATS * sizeof(float));
     if (w) *w = t;
     return (int64_t)off;
 }
@@ -323,8 +504,60 @@ void train_fill_args(const Program &p, int64_t P, void *workspace, MlpArgs *a) {
     a->g_rawb = w.g_rawb; a->g_hv = w.g_hv; a->g_feat = w.g_feat; a->g_h = w.g_h;
 }
 
+// The products of one training step in order.  Product k dumps its slabs into buffer k % 2 on the caller's stream; its
+// reduction runs on the library's side stream beside product k + 1 (a small-register kernel that co-resides with the
+// streaming workgroups), so the caller's stream only ever waits for the reduction two products back.
+struct DwSeq {
+    hipStream_t main_s = nullptr, side = nullptr;
+    std::vector<hipEvent_t> ev;      // [2k] product k dumped, [2k+1] product k reduced
+    float *slab = nullptr;
+    int k = 0;
+    bool overlap = false;
+    float *buffer() const { return slab + (size_t)(k & 1) * SLAB_FLOATS; }
+    hipStream_t begin() {            // before product k's kernel: its slab buffer is free again
+        if (overlap && k >= 2) (void)hipStreamWaitEvent(main_s, ev[2 * (k - 2) + 1], 0);
+        return main_s;
+    }
+    hipStream_t reduce_stream() {    // after product k's kernel was enqueued
+        if (!overlap) return main_s;
+        (void)hipEventRecord(ev[2 * k], main_s);
+        (void)hipStreamWaitEvent(side, ev[2 * k], 0);
+        return side;
+    }
+    void end() {                     // after product k's reduction was enqueued
+        if (overlap) (void)hipEventRecord(ev[2 * k + 1], side);
+        ++k;
+    }
+    void join() {                    // the caller's stream continues behind every reduction
+        if (!overlap) return;
+        for (int j = k - 2 < 0 ? 0 : k - 2; j < k; ++j) (void)hipStreamWaitEvent(main_s, ev[2 * j + 1], 0);
+    }
+};
+
 template <int OT, int IT, int WO, int WI>
-static int launch_dw(const DwArgs &a, const DwReduceArgs &ra, hipStream_t s) {
+static int launch_dw2(const DwArgs &a, const DwReduceArgs &ra, DwSeq &q) {
+    const size_t lds = 4 * 32 * (OT * 32 + IT * 32);
+    static DynamicLdsOptIn opt_in;
+    if (opt_in.ensure(reinterpret_cast<const void *>(dw2_kernel<OT, IT, WO, WI>), lds) != hipSuccess) return NERF_AMD_EHIP;
+    // at least ~16 chunks (512 points) per workgroup so the partial tiles are worth their dump and reduction (measured at
+    // 1024 rays: 2.35 ms per step with 16, 2.37 with 10, 2.40 with 6 chunks per workgroup)
+    const int64_t n_chunks = (a.P + 31) / 32;
+    int64_t g = n_chunks / 16;
+    if (g < 1) g = 1;
+    if (g > DW_GRID) g = DW_GRID;
+    const unsigned grid = (unsigned)g;
+    DwArgs a2 = a;
+    a2.slab = q.buffer();
+    hipLaunchKernelGGL((dw2_kernel<OT, IT, WO, WI>), dim3(grid), dim3(512), lds, q.begin(), a2);
+    DwReduceArgs r = ra;
+    r.slab = a2.slab; r.n_slabs = (int)grid; r.OT = OT; r.IT = IT;
+    hipLaunchKernelGGL(dw_reduce8_kernel, dim3((OT * IT * 256 + OT * 16 + 63) / 64), dim3(512), 0, q.reduce_stream(), r);
+    q.end();
+    return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
+}
+
+template <int OT, int IT, int WO, int WI>
+static int launch_dw(const DwArgs &a, const DwReduceArgs &ra, DwSeq &q) {
     constexpr int RSG = OT * 32 + 32, RSX = IT * 32 + 32;
     const size_t lds = 2 * 32 * (RSG + RSX);
     static DynamicLdsOptIn opt_in;
@@ -335,15 +568,18 @@ static int launch_dw(const DwArgs &a, const DwReduceArgs &ra, hipStream_t s) {
     if (g < 1) g = 1;
     if (g > DW_GRID) g = DW_GRID;
     const unsigned grid = (unsigned)g;
-    hipLaunchKernelGGL((dw_kernel<OT, IT, WO, WI>), dim3(grid), dim3(512), lds, s, a);
+    DwArgs a2 = a;
+    a2.slab = q.buffer();
+    hipLaunchKernelGGL((dw_kernel<OT, IT, WO, WI>), dim3(grid), dim3(512), lds, q.begin(), a2);
     DwReduceArgs r = ra;
-    r.n_slabs = (int)grid; r.OT = OT; r.IT = IT;
-    hipLaunchKernelGGL(dw_reduce_kernel, dim3((OT * IT * 256 + OT * 16 + 63) / 64), dim3(256), 0, s, r);
+    r.slab = a2.slab; r.n_slabs = (int)grid; r.OT = OT; r.IT = IT;
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3((OT * IT * 256 + OT * 16 + 63) / 64), dim3(256), 0, q.reduce_stream(), r);
+    q.end();
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
 
 // dW[:, col_off : col_off + m_valid] (+ db) of one Linear from G [P, 16*OT] and X [P, 16*IT].
-static int weight_grad(hipStream_t s, int64_t P, float *slab, const uint16_t *X, int n_in_slots, int in_kind, int in_L,
+static int weight_grad(DwSeq &s, int64_t P, float *slab, const uint16_t *X, int n_in_slots, int in_kind, int in_L,
                        int m_valid, const uint16_t *G, int n_out_slots, int n_valid, float *dW, int ld_dw, int col_off,
                        float *db) {
     DwArgs a;
@@ -352,7 +588,8 @@ static int weight_grad(hipStream_t s, int64_t P, float *slab, const uint16_t *X,
     r.slab = slab; r.n_slabs = 0; r.OT = 0; r.IT = 0;
     r.dW = dW; r.ld_dw = ld_dw; r.col_off = col_off; r.db = db;
     r.out_kind = PERM_ACC; r.in_kind = in_kind; r.in_L = in_L; r.n_valid = n_valid; r.m_valid = m_valid;
-    if (n_out_slots == 256 && n_in_slots == 256) return launch_dw<16, 16, 4, 2>(a, r, s);
+    if (n_out_slots == 256 && n_in_slots == 256) return g_variant == 50 ? launch_dw<16, 16, 4, 2>(a, r, s) : launch_dw2<16, 16, 4, 2>(a, r, s);
+    if (n_out_slots == 128 && n_in_slots == 256 && g_variant != 50) return launch_dw2<8, 16, 4, 2>(a, r, s);
     if (n_out_slots == 256 && n_in_slots == 64) return launch_dw<16, 4, 8, 1>(a, r, s);
     if (n_out_slots == 256 && n_in_slots == 96) return launch_dw<16, 6, 4, 2>(a, r, s);
     if (n_out_slots == 128 && n_in_slots == 64) return launch_dw<8, 4, 8, 1>(a, r, s);
@@ -364,9 +601,19 @@ static int weight_grad(hipStream_t s, int64_t P, float *slab, const uint16_t *X,
 // Parameter gradients of the view-branch model from the saved activations and the
 // pre-activation gradients the dX-chain kernel left in the workspace.  Every product overwrites
 // its destination (no accumulation into gw / gb).
-int train_param_grads(const Program &p, int64_t P, void *workspace, float *const *gw, float *const *gb, hipStream_t s) {
+int train_param_grads(const Program &p, int64_t P, void *workspace, float *const *gw, float *const *gb, int device, hipStream_t stream) {
     TrainWs w;
     carve(p, P, static_cast<char *>(workspace), &w);
+    DwSeq s;
+    s.main_s = stream; s.slab = w.slab;
+    constexpr int MAX_PRODUCTS = 24;
+    // Measured: with the reductions on the side stream a 1024-ray step takes 2.78 ms instead of 2.38 -- 24 cross-stream
+    // event hand-offs per model cost more than the 9-us reductions they hide.  Off; nerf_amd_set_tuning(0, 52) turns it on.
+    s.overlap = g_variant == 52 && lane_acquire(device, 2 * MAX_PRODUCTS + 1, &s.side, &s.ev) == NERF_AMD_OK;
+    if (s.overlap) {                                   // the side stream starts behind the backward-chain kernel
+        (void)hipEventRecord(s.ev[2 * MAX_PRODUCTS], stream);
+        (void)hipStreamWaitEvent(s.side, s.ev[2 * MAX_PRODUCTS], 0);
+    }
     const int D = p.arch.D, W = p.arch.W, E = 32 * p.KE16, Dd = 32 * p.KD16, ic = p.input_ch, icv = p.input_ch_views;
     if (W != 256 || (E != 64 && E != 96) || (Dd != 32 && Dd != 64)) return NERF_AMD_EUNSUPPORTED;
     const int64_t HS = pad_points(P) * 256;
@@ -390,10 +637,12 @@ int train_param_grads(const Program &p, int64_t P, void *workspace, float *const
     // views_linears.0: [feature | dirs]
     if (!rc) rc = weight_grad(s, P, w.slab, w.sv_feat, W, PERM_ACC, 0, W, w.g_hv, W / 2, W / 2, gw[D + 2], W + icv, 0, gb[D + 2]);
     if (!rc) rc = weight_grad(s, P, w.slab, w.sv_d, Dd, PERM_GEN, Ld, icv, w.g_hv, W / 2, W / 2, gw[D + 2], W + icv, W, nullptr);
+    s.join();
+    if (s.overlap) lane_release(device, s.ev);
     if (rc) return rc;
     // alpha_linear (column 3 of g_rawb) and rgb_linear (columns 0..2)
-    launch_dw_small<1>(s, P, w.slab, w.g_rawb, 3, h8, W, gw[D + 1], gb[D + 1]);
-    launch_dw_small<3>(s, P, w.slab, w.g_rawb, 0, w.sv_hv, W / 2, gw[D + 3], gb[D + 3]);
+    launch_dw_small<1>(stream, P, w.slab, w.g_rawb, 3, h8, W, gw[D + 1], gb[D + 1]);
+    launch_dw_small<3>(stream, P, w.slab, w.g_rawb, 0, w.sv_hv, W / 2, gw[D + 3], gb[D + 3]);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
 

@@ -337,7 +337,7 @@ int nerf_amd_field_backward(const nerf_amd_model *m, const float *g_raw, const f
     train_fill_args(m->prog, n_points, workspace, &a);
     int rc = launch_mlp_bwd_s16(a, m->prog.arch.multires, m->prog.arch.multires_views, m->prog.n_frags_bwd_used, s);
     if (rc) return fail(rc, "backward kernel launch failed");
-    rc = train_param_grads(m->prog, n_points, workspace, grad_weights, grad_biases, s);
+    rc = train_param_grads(m->prog, n_points, workspace, grad_weights, grad_biases, m->device, s);
     return rc ? fail(rc, "weight-gradient GEMMs failed") : NERF_AMD_OK;
 }
 
@@ -598,6 +598,8 @@ struct SideLane {
 std::mutex g_lane_mu;
 SideLane g_lanes[64];
 
+}  // namespace
+namespace na {
 int lane_acquire(int device, int n_events, hipStream_t *side, std::vector<hipEvent_t> *events) {
     if (device < 0 || device >= 64) return fail(NERF_AMD_EINVAL, "device index out of range");
     std::lock_guard<std::mutex> lk(g_lane_mu);
@@ -617,6 +619,8 @@ void lane_release(int device, const std::vector<hipEvent_t> &events) {
     std::lock_guard<std::mutex> lk(g_lane_mu);
     for (hipEvent_t e : events) g_lanes[device].free_events.push_back(e);
 }
+}  // namespace na
+namespace {
 
 // rows [r0, r0 + R) of a whole-batch io, with `ws` as its workspace
 nerf_amd_render_io io_rows(const nerf_amd_render_cfg *cfg, const nerf_amd_render_io &io, int64_t r0, int och, void *ws, int64_t ws_bytes) {

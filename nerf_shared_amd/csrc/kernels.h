@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 
 #include "program.h"
 
@@ -90,7 +91,12 @@ int launch_mlp_bwd_s16(const MlpArgs &a, int multires, int multires_views, int n
 bool train_supported(const Program &p);
 int64_t train_workspace_bytes(const Program &p, int64_t P);
 void train_fill_args(const Program &p, int64_t P, void *workspace, MlpArgs *a);
-int train_param_grads(const Program &p, int64_t P, void *workspace, float *const *gw, float *const *gb, hipStream_t s);
+int train_param_grads(const Program &p, int64_t P, void *workspace, float *const *gw, float *const *gb, int device, hipStream_t s);
+
+// capi.hip: the library's side stream of a device and a pool of timing-less events (used by nerf_amd_render_batch and
+// by the weight-gradient products, whose slab reductions run beside the next product)
+int lane_acquire(int device, int n_events, hipStream_t *side, std::vector<hipEvent_t> *events);
+void lane_release(int device, const std::vector<hipEvent_t> &events);
 
 // render.hip
 struct RenderCfgK {

@@ -26,7 +26,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--adam", choices=["foreach", "fused"], default="fused", help="torch.optim.Adam implementation")
+    ap.add_argument("--tuning", type=int, default=0, help="nerf_amd_set_tuning(0, value): 50 = round-1 weight-gradient kernel")
     args = ap.parse_args()
+    from nerf_shared_amd import _lib
+    _lib.check(_lib.lib.nerf_amd_set_tuning(0, args.tuning), "set_tuning")
     dev = torch.device("cuda:0")
     models = []
     for seed in (0, 10):
