@@ -39,6 +39,16 @@ def _workspace(device, nbytes):
 
 
 _side_streams = {}
+_draw_streams = {}
+
+
+def _draw_stream(device):
+    """The stream the whole-batch path makes its random draws on (see Renderer._launch_batch)."""
+    s = _draw_streams.get(device)
+    if s is None:
+        s = torch.cuda.Stream(device=device)
+        _draw_streams[device] = s
+    return s
 
 
 def _chunk_streams(device, n=2):
@@ -239,24 +249,38 @@ class Renderer(torch.nn.Module):
         N, Nc, Ni = rays.shape[0], int(self.N_samples), int(self.N_importance)
         f = dict(device=dev, dtype=torch.float32)
         z_all = torch.empty(N, Nc, **f)
-        t_all = torch.empty(N, Nc, **f) if self.perturb > 0. else None
         noisy = self.raw_noise_std > 0.
-        n0_all = torch.empty(N, Nc, **f) if noisy else None
-        n1_all = torch.empty(N, Nc + Ni, **f) if (noisy and Ni > 0) else None
-        u_all = torch.empty(N, Ni, **f) if (Ni > 0 and self.perturb > 0.) else None
-        for i in starts:                                   # the reference's order inside every render_rays call
-            if t_all is not None:
-                t_all[i:i + chunk].uniform_()
-            if n0_all is not None:
-                n0_all[i:i + chunk].normal_()
-            if u_all is not None:
-                u_all[i:i + chunk].uniform_()
-            if n1_all is not None:
-                n1_all[i:i + chunk].normal_()
-        if noisy:
-            n0_all.mul_(self.raw_noise_std)
-            if n1_all is not None:
-                n1_all.mul_(self.raw_noise_std)
+        t_all = n0_all = n1_all = u_all = None
+        if self.perturb > 0. or noisy:
+            # The draws depend on nothing but the generator (whose state lives on the host), so they go on a stream of
+            # their own: the dozens of small RNG launches of this call then run beside whatever the device is still busy
+            # with (the field kernels of the previous frame, when frames are rendered back to back) instead of in front
+            # of this frame's first field kernel.  Same values as on the caller's stream.
+            cur, ds = torch.cuda.current_stream(dev), _draw_stream(dev)
+            with torch.cuda.stream(ds):
+                t_all = torch.empty(N, Nc, **f) if self.perturb > 0. else None
+                n0_all = torch.empty(N, Nc, **f) if noisy else None
+                n1_all = torch.empty(N, Nc + Ni, **f) if (noisy and Ni > 0) else None
+                u_all = torch.empty(N, Ni, **f) if (Ni > 0 and self.perturb > 0.) else None
+                for i in starts:                               # the reference's order inside every render_rays call
+                    if t_all is not None:
+                        t_all[i:i + chunk].uniform_()
+                    if n0_all is not None:
+                        n0_all[i:i + chunk].normal_()
+                    if u_all is not None:
+                        u_all[i:i + chunk].uniform_()
+                    if n1_all is not None:
+                        n1_all[i:i + chunk].normal_()
+                if noisy:
+                    n0_all.mul_(self.raw_noise_std)
+                    if n1_all is not None:
+                        n1_all.mul_(self.raw_noise_std)
+                drawn = torch.cuda.Event()
+                drawn.record(ds)
+            cur.wait_event(drawn)
+            for t in (t_all, n0_all, n1_all, u_all):           # allocated on the draw stream, consumed on the caller's
+                if t is not None:
+                    t.record_stream(cur)
         io = _lib.RenderIO()
         io.rays, io.ray_ch = rays.data_ptr(), rays.shape[1]
         io.t_vals = _linspace01(Nc, dev).data_ptr()
