@@ -219,7 +219,7 @@ def main():
     backend = os.environ.get("NERF_AMD_DIST_BACKEND", "nccl")
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:        # under torch.distributed.run also with one rank (RCCL smoke of the C5 path)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
@@ -253,10 +253,10 @@ def main():
         fm = fine_model if wk["Ni"] > 0 else None
 
         def frames(first, count):
-            if world == 1:
+            if world == 1 and not (wk.get("poses") and dist.is_initialized()):
                 for k in range(first, first + count):
                     renderer.render(H, W, K, models[0], fm, chunk=chunk, c2w=poses_t[k % len(poses_t)], retraw=False)
-            elif mode == "pixel_ranges":
+            elif mode == "pixel_ranges" or world == 1:
                 nd.render_poses_gathered(renderer, H, W, K, chunk, [poses_t[k % len(poses_t)] for k in range(first, first + count)],
                                          models[0], fm, on_frame=lambda i, rgb, disp, acc: None)
             else:       # whole frames round-robin: rank r renders frames r, r + world, ...
@@ -347,7 +347,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and key in ("c1", "c2"):
             out["cpu_baseline"] = cpu_baseline(torch, synth, w)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -8,6 +8,8 @@ rank 0 per image (RCCL over xGMI when the backend is "nccl"; gloo on CPU tests).
 The reference has no distributed code; this is the build's
 own multi-GPU row (section 8e).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -28,6 +30,10 @@ def _start_gather(local, n_total, dst, group, async_op):
     [n_total, C] tensor on dst (None elsewhere) once the collective is complete."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    if world == 1:                                   # a one-rank group (forced collective): the gather list is one tensor
+        out = torch.empty_like(local)
+        work = dist.gather(local.contiguous(), [out], dst=dst, group=group, async_op=async_op)
+        return work, (lambda: out)
     sizes = shard_sizes(n_total, world)
     assert local.shape[0] == sizes[rank], (local.shape, sizes, rank)
     C = local.shape[1]
@@ -73,6 +79,9 @@ class OverlappedGather:
     def __init__(self, n_total, dst=0, group=None, depth=2):
         self.n_total, self.dst, self.group, self.depth = n_total, dst, group, max(1, int(depth))
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # NERF_AMD_FORCE_COLLECTIVE=1: issue the collective even in a one-rank group (a 1-GPU box can then exercise the
+        # RCCL side-stream path: async gather under a stream context, stream-level wait, events)
+        self.single = self.world == 1 and not (dist.is_initialized() and os.environ.get("NERF_AMD_FORCE_COLLECTIVE") == "1")
         self._pending = []        # (finish, work, done_event, keepalive) in submission order
         self._ready = []
         self._side = None
@@ -91,7 +100,7 @@ class OverlappedGather:
 
     def submit(self, rows):
         self.submitted += 1
-        if self.world == 1:
+        if self.single:
             self._ready.append(rows)
             return
         while len(self._pending) >= self.depth:

@@ -601,6 +601,33 @@ def test_empty_and_errors(dev):
         m(torch.zeros(2, 3, 3, device=dev), None)                    # use_viewdirs model needs viewdirs
 
 
+def test_sample_counts_beyond_the_lds_are_refused_with_the_real_reason(dev):
+    """The per-ray kernels keep a ray's samples in LDS.  Counts that do not fit the CU's 160 KiB are refused before
+    anything is launched, with the byte counts in the message (not a HIP launch failure with a made-up limit); counts
+    that need more than the 64-KiB default opt in and run."""
+    nerf, render_utils, utils = amd()
+    from nerf_shared_amd._lib import NerfAmdError
+    K = synth.lego_intrinsics(40, 40)
+    m = gpu_model(dev, 1, 3.0, "bf16", **VD)
+    batch = utils.make_ray_batch(40, 40, K, synth.LEGO_C2W, 2.0, 6.0, True, False, device=dev, n=8)
+    big = render_utils.Renderer(**dict(BASE, N_samples=2049, N_importance=2047))
+    with pytest.raises(NerfAmdError, match="bytes of LDS"):
+        big.render_rays(batch, m, m)
+    mid = render_utils.Renderer(**dict(BASE, N_samples=1024, N_importance=1024))      # 4 rays x 20 KB: beyond the 64-KiB default
+    out = mid.render_rays(batch, m, m, retweights=True)
+    torch.cuda.synchronize()
+    z = out["z_vals"]
+    assert z.shape == (8, 2048) and bool((z[:, 1:] >= z[:, :-1]).all()) and bool(torch.isfinite(out["rgb_map"]).all())
+    r = render_utils.Renderer(**BASE)
+    with pytest.raises(NerfAmdError, match="bytes of LDS"):
+        utils.sample_pdf(torch.rand(4, 6000, device=dev).sort(-1)[0], torch.rand(4, 5999, device=dev), 16, det=True)
+    raw = torch.randn(4, 4000, 4, device=dev, requires_grad=True)
+    zz = torch.rand(4, 4000, device=dev).sort(-1)[0]
+    rgb = r.raw2outputs(raw, zz, torch.randn(4, 3, device=dev))[0]
+    with pytest.raises(NerfAmdError, match="bytes of LDS"):
+        rgb.sum().backward()
+
+
 def test_gradient_requests_outside_the_training_kernels_raise(dev):
     """main.py:103 calls loss.backward() on whatever render() returned: a model the HIP training kernels do not
     cover must raise when gradients are requested instead of returning outputs without autograd history
@@ -818,6 +845,16 @@ with torch.no_grad():
         ok = ok and got8.dtype == torch.uint8 and torch.equal(got8, utils.to8b(rgb))
     else:
         ok = ok and got8 is None
+    # the C5 loop: every pose rendered by all ranks together, gathers overlapped with the next frame
+    poses3 = [torch.from_numpy(synth.pose_spherical(a)) for a in (10.0, 130.0, 250.0)]
+    frames = nd.render_poses_gathered(r, H, W, K, 500, poses3, models[0], models[1])
+    if rank == 0:
+        ok = ok and len(frames) == 3
+        for (g_rgb, g_disp, g_acc), c2w in zip(frames, poses3):
+            w_rgb, w_disp, w_acc, _ = r.render(H, W, K, models[0], models[1], chunk=4096, c2w=c2w, retraw=False)
+            ok = ok and torch.equal(g_rgb, w_rgb) and torch.equal(g_acc, w_acc) and torch.equal(torch.nan_to_num(g_disp), torch.nan_to_num(w_disp))
+    else:
+        ok = ok and frames is None
     # whole frames dealt round-robin, every rank writes its own PNGs
     import numpy as np
     from nerf_shared_amd import image_io, utils

@@ -239,6 +239,50 @@ def test_backward_kernel_vmcnt_ledger_matches_its_isa(tmp_path):
         assert not check_vmcnt.check(asm, tag, verbose=False, slack=-4)["ok"]
 
 
+def test_field_kernel_keeps_its_weight_read_ahead(tmp_path):
+    """The fused kernels read every weight fragment from LDS through a software queue, several MFMAs ahead of its use.
+    The machine scheduler once sank half of those reads back to their first use (38 % with zero MFMAs in between),
+    which no test of the RESULTS can see; csrc pins them with scheduling groups (mlp_bf16_s16.hip sched_step).  Check the
+    compiled ISA of the default inference kernel: nearly every fragment read is issued >= 4 MFMAs before its MFMA."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import isa_readahead
+    src = os.path.join(REPO, "nerf_shared_amd", "csrc", "mlp_bf16_s16.hip")
+    asm = str(tmp_path / "s16.s")
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", src, "-o", asm],
+                   check=True, capture_output=True, timeout=900)
+    for tag, n_mfma in (("mlp_bf16_s16p_kernelILi10ELi4ELb1E", 2344),):
+        hist = isa_readahead.main(asm, tag)
+        total = sum(hist.values())
+        assert total == n_mfma // 2, (tag, total)                  # one read per weight fragment, two MFMAs per fragment
+        ahead = sum(v for d, v in hist.items() if d >= 4)
+        assert ahead >= 0.97 * total, (tag, dict(hist))
+        assert hist.get(0, 0) <= 0.01 * total, (tag, dict(hist))
+
+
+def test_bench_reports_traffic_only_for_the_build_it_was_measured_on(tmp_path, monkeypatch):
+    """bench.py's roofline.traffic comes from a profiles/ PMC summary; it must not survive a kernel change."""
+    sys.path.insert(0, REPO)
+    import bench
+    h = bench.csrc_hash()
+    assert len(h) == 16 and h == bench.csrc_hash()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    grids = {"131072": {"FETCH_SIZE": {"launches": 4, "mean_per_launch": 100.0}, "WRITE_SIZE": {"launches": 4, "mean_per_launch": 50.0},
+                        "hbm_bytes_per_launch": {"read_corrected_x2": 204800.0, "write": 51200.0, "total": 256000.0}}}
+    import json
+    (prof / "r99_pmc_summary_x.json").write_text(json.dumps({"_meta": {"csrc_hash": h}, "void na::mlp_bf16_s16p_kernel<10>": grids}))
+    monkeypatch.setattr(bench, "REPO", str(tmp_path))
+    monkeypatch.setattr(bench, "csrc_hash", lambda: h)
+    got = bench.measured_traffic("mlp_bf16_s16p_kernel")
+    assert got is not None and got[0] == 256000.0 and got[1] == "r99_pmc_summary_x.json"
+    monkeypatch.setattr(bench, "csrc_hash", lambda: "0" * 16)           # the kernels changed: the stale figure is dropped
+    assert bench.measured_traffic("mlp_bf16_s16p_kernel") is None
+
+
 def test_png_codec_roundtrip_and_async_writer(tmp_path):
     """image_io: the zlib PNG writer/reader that replaces imageio for the render output and the
     dataset frames (render_utils.py:312-315, load_blender.py:69)."""

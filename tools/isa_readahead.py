@@ -14,16 +14,17 @@ import sys
 
 
 def kernel_body(path, tag):
+    """Instruction lines of the first kernel whose mangled name contains `tag` (from its label to s_endpgm)."""
     out, on = [], False
     with open(path) as f:
         for line in f:
-            if not on and line.startswith("_ZN") and tag in line and line.rstrip().endswith(tuple(": ; @" + x for x in [""])) is False and ":" in line.split()[0]:
-                on = True
+            if not on:
+                head = line.split()[0] if line.split() else ""
+                on = head.startswith("_ZN") and head.endswith(":") and tag in head
                 continue
-            if on:
-                out.append(line.strip())
-                if line.strip().startswith("s_endpgm"):
-                    break
+            out.append(line.strip())
+            if line.strip().startswith("s_endpgm"):
+                break
     return out
 
 
