@@ -386,6 +386,7 @@ __global__ __launch_bounds__(256) void dw_small_kernel(const uint16_t *G, int g_
     }
     for (int64_t r0 = (int64_t)blockIdx.x * 256; r0 < P; r0 += (int64_t)gridDim.x * 256) {
         const int64_t r1 = r0 + 256 < P ? r0 + 256 : P;
+#pragma unroll 4
         for (int64_t p = r0 + ty; p < r1; p += rows_par) {
             const u32x4 xv = *reinterpret_cast<const u32x4 *>(X + p * ldx + cg * 8);
             float x[8];
@@ -449,7 +450,8 @@ template <int NO>
 static void launch_dw_small(hipStream_t s, int64_t P, float *slab, const uint16_t *G, int g_col0, const uint16_t *X, int n_in,
                             float *dW, float *db) {
     int64_t g = (P + 255) / 256;
-    if (g > 256) g = 256;                              // one block per CU; 256 * (3 * 256 + 3) floats fit the slab
+    const int64_t cap = g_variant == 50 ? 256 : 1024;  // four 256-thread blocks per CU keep enough 16-byte loads in flight; 1024 * (3 * 256 + 3) floats fit the slab
+    if (g > cap) g = cap;
     hipLaunchKernelGGL(dw_small_kernel<NO>, dim3((unsigned)g), dim3(256), 0, s, G, g_col0, X, n_in, n_in, P, slab);
     hipLaunchKernelGGL(dw_small_reduce_kernel, dim3((NO * n_in + NO + 63) / 64), dim3(256), 0, s, slab, (int)g, NO, n_in,
                        (int)PERM_ACC, dW, n_in, db);
