@@ -202,15 +202,26 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(DwReduceArgs a) {
 // (Reduce jobs for the previous product's slabs inside this launch do not work out: every block of a launch reserves the
 // launch's 128 KB of LDS, so the ~1000 small reduce blocks would each occupy a whole CU.)
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int dw_swz(int r) { return 2 * ((r & 3) | (((r >> 3) & 1) << 2)); }
+// One 32-lane group of a transposing read covers rows {0..3, 8..11} (+4 for the second half) x 32 bytes.  Rows of >= 256
+// bytes all start at bank 0, so the eight rows need eight different piece pairs: XOR with 0, 2, .., 14.  Rows of 128 bytes
+// (PIECES == 8) alternate between the two halves of the banks, so the four even rows {0, 2, 8, 10} (and the four odd ones)
+// need four different pairs: XOR with 0, 2, 4, 6.  Both forms satisfy swz(r + 4) == swz(r).
+template <int PIECES>
+__device__ __forceinline__ int dw_swz(int r) {
+    static_assert(PIECES == 8 || (PIECES >= 16 && (PIECES & (PIECES - 1)) == 0), "unsupported row width");
+    if (PIECES == 8) return 2 * (((r >> 1) & 1) | (((r >> 3) & 1) << 1));
+    return 2 * ((r & 3) | (((r >> 3) & 1) << 2));
+}
 
-__device__ __forceinline__ bf16x8 tr_frag_swz(uint32_t img, int row_bytes, int col0, int lane) {
+template <int PIECES>
+__device__ __forceinline__ bf16x8 tr_frag_swz(uint32_t img, int col0, int lane) {
     // 8 consecutive image rows (points 8g..8g+7) of column col0 + (lane & 15), as an MFMA 16x16x32 operand, from the
-    // swizzled image: 16-byte piece pc of row r lives at piece position pc ^ dw_swz(r) (dw_swz(r + 4) == dw_swz(r)).
+    // swizzled image: 16-byte piece pc of row r lives at piece position pc ^ dw_swz(r).
+    constexpr int row_bytes = PIECES * 16;
     const int i = lane & 15, g = lane >> 4;
     const int r = 8 * g + (i >> 2);
     const int pc = (col0 >> 3) + ((i & 3) >> 1);
-    const uint32_t p = img + r * row_bytes + ((pc ^ dw_swz(r)) << 4) + ((i & 1) << 3);
+    const uint32_t p = img + r * row_bytes + ((pc ^ dw_swz<PIECES>(r)) << 4) + ((i & 1) << 3);
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(uintptr_t)(p));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(uintptr_t)(p + 4 * row_bytes));
@@ -267,8 +278,7 @@ __global__ __launch_bounds__(512) void dw_reduce8_kernel(DwReduceArgs a) {
 
 template <int OT, int IT, int WO, int WI>
 __global__ __launch_bounds__(512, 2) void dw2_kernel(DwArgs a) {
-    static_assert(WO * WI == 8 && OT % WO == 0 && IT % WI == 0 && OT >= 8 && IT >= 8, "bad shape");
-    static_assert((OT & (OT - 1)) == 0 && (IT & (IT - 1)) == 0, "the swizzle needs power-of-two rows of >= 16 pieces");
+    static_assert(WO * WI == 8 && OT % WO == 0 && IT % WI == 0 && OT >= 4 && IT >= 4, "bad shape");
     constexpr int TO = OT / WO, TI = IT / WI;
     constexpr int RG = OT * 32, RX = IT * 32;                   // row bytes (unpadded)
     constexpr int PG = OT * 2, PX = IT * 2;                     // 16-byte pieces per row
@@ -303,7 +313,7 @@ __global__ __launch_bounds__(512, 2) void dw2_kernel(DwArgs a) {
             int64_t p = p0 + r;
             if (p >= pad_points(a.P)) p = pad_points(a.P) - 1;  // rows exist up to the padded point count (kernels.h)
             const char *src = is_g ? reinterpret_cast<const char *>(a.G) + (p * a.ldg) * 2 : reinterpret_cast<const char *>(a.X) + (p * a.ldx) * 2;
-            src += (pos ^ dw_swz(r)) << 4;
+            src += (pos ^ (is_g ? dw_swz<PG>(r) : dw_swz<PX>(r))) << 4;
             dma_piece(src, slot + (is_g ? 0 : 32 * RG) + 1024 * jj);
         }
     };
@@ -339,9 +349,9 @@ __global__ __launch_bounds__(512, 2) void dw2_kernel(DwArgs a) {
             }
             bf16x8 A[TO], B[TI];
 #pragma unroll
-            for (int x = 0; x < TO; ++x) A[x] = tr_frag_swz(gimg, RG, (wo * TO + x) * 16, lane);
+            for (int x = 0; x < TO; ++x) A[x] = tr_frag_swz<PG>(gimg, (wo * TO + x) * 16, lane);
 #pragma unroll
-            for (int y = 0; y < TI; ++y) B[y] = tr_frag_swz(ximg, RX, (wi * TI + y) * 16, lane);
+            for (int y = 0; y < TI; ++y) B[y] = tr_frag_swz<PX>(ximg, (wi * TI + y) * 16, lane);
 #pragma unroll
             for (int x = 0; x < TO; ++x) {
 #pragma unroll
@@ -592,7 +602,7 @@ static int weight_grad(DwSeq &s, int64_t P, float *slab, const uint16_t *X, int 
     r.out_kind = PERM_ACC; r.in_kind = in_kind; r.in_L = in_L; r.n_valid = n_valid; r.m_valid = m_valid;
     if (n_out_slots == 256 && n_in_slots == 256) return g_variant == 50 ? launch_dw<16, 16, 4, 2>(a, r, s) : launch_dw2<16, 16, 4, 2>(a, r, s);
     if (n_out_slots == 128 && n_in_slots == 256 && g_variant != 50) return launch_dw2<8, 16, 4, 2>(a, r, s);
-    if (n_out_slots == 256 && n_in_slots == 64) return launch_dw<16, 4, 8, 1>(a, r, s);
+    if (n_out_slots == 256 && n_in_slots == 64) return g_variant == 50 ? launch_dw<16, 4, 8, 1>(a, r, s) : launch_dw2<16, 4, 8, 1>(a, r, s);
     if (n_out_slots == 256 && n_in_slots == 96) return launch_dw<16, 6, 4, 2>(a, r, s);
     if (n_out_slots == 128 && n_in_slots == 64) return launch_dw<8, 4, 8, 1>(a, r, s);
     if (n_out_slots == 128 && n_in_slots == 256) return launch_dw<8, 16, 4, 2>(a, r, s);
