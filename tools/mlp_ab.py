@@ -3,7 +3,11 @@
 (cdna_hip_programming.md rule 24).  Variants are (tuning key, value) settings of
 nerf_amd_set_tuning; outputs must be bit-identical across variants.
 
-    python tools/mlp_ab.py [--rounds 15] [--rays 4096] [--samples 192] --variants 0:8 0:4
+    python tools/mlp_ab.py [--rounds 15] [--rays 4096] [--samples 192] --variants 0:0 0:41 0:40
+
+Values of key 0 in a normal build: 0 = default (pipelined kernel, pinned read-ahead, split DMA), 41 = the simple per-tile
+kernel with the same pipeline shape, 40 = round 1's pipeline shape, 100+ = the 32x32x16 kernel.  A build with
+-DNERF_AMD_EXPERIMENTS adds the shapes listed in launch_mlp_bf16_s16 (mlp_bf16_s16.hip).
 """
 import argparse
 import json
