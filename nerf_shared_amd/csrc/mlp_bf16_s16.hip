@@ -296,6 +296,12 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16_kernel(MlpArgs 
     c.ring_lane = smem + lane * 16;
     c.ring_u32 = (uint32_t)(uintptr_t)smem;
     c.bias_half = bias_lds + q * 4;          // this lane's 4 rows of every 16-row tile
+    if constexpr ((C::OPT & 64) != 0) {
+        c.rsrc = make_rsrc(a.stream_s16, (unsigned)(NB * C::BLOCK_BYTES));
+        c.rsrc_next = c.rsrc;
+        c.lane16 = lane * 16;
+        c.wave_off = c.wave * C::PIECES * 1024;
+    }
 
     for (int i = tid; i < Lay::N_TILES * 16; i += WG_THREADS) bias_lds[i] = a.bias_s16[i];
 
@@ -500,6 +506,12 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16p_kernel(MlpArgs
     for (int i = 0; i < C::NS; ++i) {
         c.slot_u32[i] = c.ring_u32 + i * C::BLOCK_BYTES;
         c.slot_lane[i] = c.slot_u32[i] + lane * 16;
+    }
+    if constexpr ((C::OPT & 64) != 0) {
+        c.rsrc = make_rsrc(a.stream_s16, (unsigned)(NB * C::BLOCK_BYTES));
+        c.rsrc_next = c.rsrc;                  // one model per launch: the next tile streams the same weights
+        c.lane16 = lane * 16;
+        c.wave_off = c.wave * C::PIECES * 1024;
     }
     c.bias_half = bias_lds + q * 4;          // this lane's 4 rows of every 16-row tile
     for (int i = tid; i < Lay::N_TILES * 16; i += WG_THREADS) bias_lds[i] = a.bias_s16[i];
@@ -721,9 +733,11 @@ static int launch_wg16(const MlpArgs &a, int n_frags_used, int n_tiles, hipStrea
 // 64-KiB ring of 16-fragment blocks, mid-block sync, 4-deep read-ahead pinned in front of the MFMAs it runs ahead of
 // (OPT 4), DMA issue of the two SIMD partners half a block apart (OPT 8).  tools/mlp_ab.py, 4096 x 192 points:
 // 0.606 ms against 0.630 for the round-1 shape Ctx<8, 16, 4, 8, 2> on the same device.
-using Cfg16 = Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 8>;
+// + ring DMA as buffer_load ... lds (OPT 64: one asm statement per wave and block, no per-piece address arithmetic):
+// another -2.3 ... -3.6 % (fine) / -2.1 ... -4.5 % (coarse) depending on the device.
+using Cfg16 = Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 8 + 64>;
 using Cfg16R1 = Ctx<8, 16, 4, 8, 2>;          // round-1 shape (A/B: nerf_amd_set_tuning(0, 40))
-using Cfg16P = Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 8 + 32>;   // the pipelined kernel: Cfg16 + continuous ring
+using Cfg16P = Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 8 + 32 + 64>;   // the pipelined kernel: Cfg16 + continuous ring
 
 int launch_mlp_bf16_s16(const MlpArgs &a, int multires, int multires_views, int use_viewdirs,
                         int n_frags_used, int n_tiles, hipStream_t s) {
@@ -753,6 +767,12 @@ int launch_mlp_bf16_s16(const MlpArgs &a, int multires, int multires_views, int 
             case 38: return launch_wg16<10, 4, true, Ctx<8, 32, 4, 16, 4, 0, 1, 4 + 8>>(a, n_frags_used, n_tiles, s);   // 32-fragment blocks, 128-KiB ring
             case 39: return launch_wg16<10, 4, true, Ctx<8, 16, 5, 8, 4, 0, 1, 4 + 8>>(a, n_frags_used, n_tiles, s);    // 5-slot ring
 #endif
+            // timing-only ablations of the current shape (WRONG results): what syncs + DMA / LDS fragment reads still cost
+            case 45: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 4, 1, 1, 4 + 8>>(a, n_frags_used, n_tiles, s);       // no syncs, no DMA
+            case 46: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 4, 3, 1, 4 + 8>>(a, n_frags_used, n_tiles, s);       // neither syncs/DMA nor LDS fragment reads
+            case 47: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 8>>(a, n_frags_used, n_tiles, s);        // simple kernel, global_load_lds DMA
+            case 48: return launch_wg16p<10, 4, true, Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 8 + 32>>(a, n_frags_used, n_tiles, s);  // pipelined, global_load_lds DMA
+            case 49: return launch_wg16p<10, 4, true, Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 32 + 64>>(a, n_frags_used, n_tiles, s);  // pipelined + buffer DMA, no split
             case 42: return launch_wg16p<10, 4, true, Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 32>>(a, n_frags_used, n_tiles, s);      // pipelined, no split DMA
             case 43: return launch_wg16p<10, 4, true, Ctx<8, 16, 4, 8, 3, 0, 1, 4 + 8 + 32>>(a, n_frags_used, n_tiles, s);  // pipelined, LA 3
             case 44: return launch_wg16p<10, 4, true, Ctx<8, 16, 4, 8, 2, 0, 1, 4 + 8 + 32>>(a, n_frags_used, n_tiles, s);  // pipelined, LA 2

@@ -75,7 +75,26 @@ struct Ctx {
     uint32_t slot_u32[NS_];    // LDS byte address of a slot (DMA destination, wave-uniform)
     const char *gstream_next;  // the next tile's stream + lane*16 (the same model here)
     int has_next;              // this workgroup has another tile after the current one (workgroup-uniform)
+    // OPT & 64 (BUFFER_DMA): the ring DMA as buffer_load ... lds: a buffer resource over the stream (scalar), one constant
+    // VGPR (lane * 16) and a scalar offset per block instead of a 64-bit per-lane address pair and two VALU per piece;
+    // the instruction's immediate offset advances the memory AND the LDS address, so a wave's pieces of a block are
+    // consecutive immediates.  Out-of-range reads return zero instead of faulting (num_records = stream bytes).
+    typedef __attribute__((ext_vector_type(4))) unsigned rsrc_t;
+    rsrc_t rsrc, rsrc_next;    // buffer resources of this tile's / the next tile's stream
+    unsigned lane16;           // lane * 16
+    unsigned wave_off;         // wave * PIECES * 1024: this wave's first piece inside a block (memory and LDS)
 };
+
+// Raw buffer resource over `bytes` bytes at `base` (gfx9 dword 3: 32-bit data format, no swizzle).
+__device__ __forceinline__ __attribute__((ext_vector_type(4))) unsigned make_rsrc(const void *base, unsigned bytes) {
+    const unsigned long long b = (unsigned long long)(uintptr_t)base;
+    __attribute__((ext_vector_type(4))) unsigned r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)b);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xffffu);
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000u;
+    return r;
+}
 
 typedef __attribute__((address_space(3))) const bf16x8 lds_frag_t;
 
@@ -87,6 +106,52 @@ typedef __attribute__((address_space(3))) const bf16x8 lds_frag_t;
 template <int BB, class C, int SRC = -1, int SEL = 0>
 __device__ __forceinline__ void issue_block(const C &c) {
     constexpr int slot = BB % C::NS;
+    if constexpr ((C::OPT & 64) != 0) {
+        static_assert(C::PIECES * 1024 <= 4096, "a wave's pieces must fit the 12-bit immediate offset");
+        const unsigned soff = __builtin_amdgcn_readfirstlane(c.wave_off + (unsigned)(SRC >= 0 ? SRC : BB) * C::BLOCK_BYTES);
+        const unsigned l0 = __builtin_amdgcn_readfirstlane(((C::OPT & 32) != 0 ? c.slot_u32[slot] : c.ring_u32 + slot * C::BLOCK_BYTES) + c.wave_off);
+        const int lag_s = SEL == 0 ? 0 : __builtin_amdgcn_readfirstlane(c.lag);
+        const auto rs = SRC >= 0 ? c.rsrc_next : c.rsrc;
+        unsigned keep;
+        // one asm statement per block: M0 is set once, the pieces are consecutive immediates
+        if constexpr (C::PIECES == 2) {
+            if constexpr (SEL == 0) {
+                asm volatile(
+                    "s_mov_b32 %0, m0\n\t"
+                    "s_mov_b32 m0, %3\n\t"
+                    "s_nop 0\n\t"
+                    "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
+                    "buffer_load_dwordx4 %1, %2, %4 offen offset:1024 lds\n\t"
+                    "s_mov_b32 m0, %0"
+                    : "=&s"(keep) : "v"(c.lane16), "s"(rs), "s"(l0), "s"(soff) : "memory");
+            } else if constexpr (SEL == 1) {
+                asm volatile(
+                    "s_cmp_lg_u32 %5, 0\n\t"
+                    "s_cbranch_scc1 .Lskip_bdma_%=\n\t"
+                    "s_mov_b32 %0, m0\n\t"
+                    "s_mov_b32 m0, %3\n\t"
+                    "s_nop 0\n\t"
+                    "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
+                    "buffer_load_dwordx4 %1, %2, %4 offen offset:1024 lds\n\t"
+                    "s_mov_b32 m0, %0\n"
+                    ".Lskip_bdma_%=:"
+                    : "=&s"(keep) : "v"(c.lane16), "s"(rs), "s"(l0), "s"(soff), "s"(lag_s) : "memory", "scc");
+            } else {
+                asm volatile(
+                    "s_cmp_eq_u32 %5, 0\n\t"
+                    "s_cbranch_scc1 .Lskip_bdma_%=\n\t"
+                    "s_mov_b32 %0, m0\n\t"
+                    "s_mov_b32 m0, %3\n\t"
+                    "s_nop 0\n\t"
+                    "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
+                    "buffer_load_dwordx4 %1, %2, %4 offen offset:1024 lds\n\t"
+                    "s_mov_b32 m0, %0\n"
+                    ".Lskip_bdma_%=:"
+                    : "=&s"(keep) : "v"(c.lane16), "s"(rs), "s"(l0), "s"(soff), "s"(lag_s) : "memory", "scc");
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < C::PIECES; ++i) {
         const int piece = c.wave * C::PIECES + i;
