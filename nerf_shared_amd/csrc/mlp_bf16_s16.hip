@@ -773,6 +773,9 @@ int launch_mlp_bf16_s16(const MlpArgs &a, int multires, int multires_views, int 
             case 47: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 8>>(a, n_frags_used, n_tiles, s);        // simple kernel, global_load_lds DMA
             case 48: return launch_wg16p<10, 4, true, Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 8 + 32>>(a, n_frags_used, n_tiles, s);  // pipelined, global_load_lds DMA
             case 49: return launch_wg16p<10, 4, true, Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 32 + 64>>(a, n_frags_used, n_tiles, s);  // pipelined + buffer DMA, no split
+            case 56: return launch_wg16<10, 4, true, Ctx<8, 32, 3, 16, 4, 0, 1, 4 + 8 + 64>>(a, n_frags_used, n_tiles, s);  // 32-fragment blocks (half the barriers), 96-KiB ring
+            case 57: return launch_wg16<10, 4, true, Ctx<8, 32, 4, 16, 4, 0, 1, 4 + 8 + 64>>(a, n_frags_used, n_tiles, s);  // 32-fragment blocks, 128-KiB ring
+            case 58: return launch_wg16<10, 4, true, Ctx<8, 32, 4, 16, 8, 0, 1, 4 + 8 + 64>>(a, n_frags_used, n_tiles, s);  // + 8-deep read-ahead
             case 42: return launch_wg16p<10, 4, true, Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 32>>(a, n_frags_used, n_tiles, s);      // pipelined, no split DMA
             case 43: return launch_wg16p<10, 4, true, Ctx<8, 16, 4, 8, 3, 0, 1, 4 + 8 + 32>>(a, n_frags_used, n_tiles, s);  // pipelined, LA 3
             case 44: return launch_wg16p<10, 4, true, Ctx<8, 16, 4, 8, 2, 0, 1, 4 + 8 + 32>>(a, n_frags_used, n_tiles, s);  // pipelined, LA 2

@@ -114,42 +114,27 @@ __device__ __forceinline__ void issue_block(const C &c) {
         const auto rs = SRC >= 0 ? c.rsrc_next : c.rsrc;
         unsigned keep;
         // one asm statement per block: M0 is set once, the pieces are consecutive immediates
-        if constexpr (C::PIECES == 2) {
-            if constexpr (SEL == 0) {
-                asm volatile(
-                    "s_mov_b32 %0, m0\n\t"
-                    "s_mov_b32 m0, %3\n\t"
-                    "s_nop 0\n\t"
-                    "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
-                    "buffer_load_dwordx4 %1, %2, %4 offen offset:1024 lds\n\t"
-                    "s_mov_b32 m0, %0"
-                    : "=&s"(keep) : "v"(c.lane16), "s"(rs), "s"(l0), "s"(soff) : "memory");
-            } else if constexpr (SEL == 1) {
-                asm volatile(
-                    "s_cmp_lg_u32 %5, 0\n\t"
-                    "s_cbranch_scc1 .Lskip_bdma_%=\n\t"
-                    "s_mov_b32 %0, m0\n\t"
-                    "s_mov_b32 m0, %3\n\t"
-                    "s_nop 0\n\t"
-                    "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
-                    "buffer_load_dwordx4 %1, %2, %4 offen offset:1024 lds\n\t"
-                    "s_mov_b32 m0, %0\n"
-                    ".Lskip_bdma_%=:"
-                    : "=&s"(keep) : "v"(c.lane16), "s"(rs), "s"(l0), "s"(soff), "s"(lag_s) : "memory", "scc");
-            } else {
-                asm volatile(
-                    "s_cmp_eq_u32 %5, 0\n\t"
-                    "s_cbranch_scc1 .Lskip_bdma_%=\n\t"
-                    "s_mov_b32 %0, m0\n\t"
-                    "s_mov_b32 m0, %3\n\t"
-                    "s_nop 0\n\t"
-                    "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
-                    "buffer_load_dwordx4 %1, %2, %4 offen offset:1024 lds\n\t"
-                    "s_mov_b32 m0, %0\n"
-                    ".Lskip_bdma_%=:"
-                    : "=&s"(keep) : "v"(c.lane16), "s"(rs), "s"(l0), "s"(soff), "s"(lag_s) : "memory", "scc");
-            }
-        }
+#define NA_BDMA2 "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t" "buffer_load_dwordx4 %1, %2, %4 offen offset:1024 lds\n\t"
+#define NA_BDMA4 NA_BDMA2 "buffer_load_dwordx4 %1, %2, %4 offen offset:2048 lds\n\t" "buffer_load_dwordx4 %1, %2, %4 offen offset:3072 lds\n\t"
+#define NA_BDMA_ASM(LOADS)                                                                                               \
+    do {                                                                                                                  \
+        if constexpr (SEL == 0) {                                                                                         \
+            asm volatile("s_mov_b32 %0, m0\n\t" "s_mov_b32 m0, %3\n\t" "s_nop 0\n\t" LOADS "s_mov_b32 m0, %0"            \
+                         : "=&s"(keep) : "v"(c.lane16), "s"(rs), "s"(l0), "s"(soff) : "memory");                           \
+        } else if constexpr (SEL == 1) {                                                                                  \
+            asm volatile("s_cmp_lg_u32 %5, 0\n\t" "s_cbranch_scc1 .Lskip_bdma_%=\n\t" "s_mov_b32 %0, m0\n\t"               \
+                         "s_mov_b32 m0, %3\n\t" "s_nop 0\n\t" LOADS "s_mov_b32 m0, %0\n" ".Lskip_bdma_%=:"                 \
+                         : "=&s"(keep) : "v"(c.lane16), "s"(rs), "s"(l0), "s"(soff), "s"(lag_s) : "memory", "scc");        \
+        } else {                                                                                                          \
+            asm volatile("s_cmp_eq_u32 %5, 0\n\t" "s_cbranch_scc1 .Lskip_bdma_%=\n\t" "s_mov_b32 %0, m0\n\t"               \
+                         "s_mov_b32 m0, %3\n\t" "s_nop 0\n\t" LOADS "s_mov_b32 m0, %0\n" ".Lskip_bdma_%=:"                 \
+                         : "=&s"(keep) : "v"(c.lane16), "s"(rs), "s"(l0), "s"(soff), "s"(lag_s) : "memory", "scc");        \
+        }                                                                                                                 \
+    } while (0)
+        static_assert(C::PIECES == 2 || C::PIECES == 4, "pieces per wave and block");
+        if constexpr (C::PIECES == 2) NA_BDMA_ASM(NA_BDMA2);
+        else NA_BDMA_ASM(NA_BDMA4);
+#undef NA_BDMA_ASM
         return;
     }
 #pragma unroll
