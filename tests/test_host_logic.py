@@ -261,6 +261,20 @@ def test_field_kernel_keeps_its_weight_read_ahead(tmp_path):
         ahead = sum(v for d, v in hist.items() if d >= 4)
         assert ahead >= 0.97 * total, (tag, dict(hist))
         assert hist.get(0, 0) <= 0.01 * total, (tag, dict(hist))
+    # The counted vmcnt waits of the ring syncs, replayed on the same ISA for both halves of the workgroup (SPLIT_DMA
+    # selects the DMA site per half inside the asm statement; the DMA is buffer_load ... lds): no sync may publish a block
+    # whose pieces can still be in flight.  Straight-line kernels only: the per-tile inference kernel (every architecture)
+    # and the training forward; the pipelined kernel picks one count at run time (has_next) and is covered by bit-exact
+    # comparison with the per-tile kernel instead (tools/mlp_ab.py, the GPU parity tests).
+    import check_vmcnt
+    for tag, syncs in (("mlp_bf16_s16_kernelILi10ELi4ELb1ENS_3CtxILi8ELi16ELi4ELi8ELi4ELi0ELi1ELi76", 74),
+                       ("mlp_bf16_s16_kernelILi15ELi6ELb1ENS_3CtxILi8ELi16ELi4ELi8ELi4ELi0ELi1ELi76", 76),
+                       ("mlp_bf16_s16_kernelILi10ELi0ELb0ENS_3CtxILi8ELi16ELi4ELi8ELi4ELi0ELi1ELi76", 61),
+                       ("mlp_bf16_s16_kernelILi10ELi4ELb1ENS_3CtxILi8ELi16ELi4ELi8ELi2ELi0ELi1ELi0ENS_8NoLedgerEEELb1", 74)):
+        for lag in (0, 1):
+            st = check_vmcnt.check(asm, tag, verbose=False, lag=lag)
+            assert st["kernels"] == 1 and st["ok"] and st["syncs"] == syncs and st["dma_pieces"] == 2 * syncs, (tag, lag, st)
+            assert not check_vmcnt.check(asm, tag, verbose=False, lag=lag, slack=3)["ok"]      # the checker can fail
 
 
 def test_bench_reports_traffic_only_for_the_build_it_was_measured_on(tmp_path, monkeypatch):

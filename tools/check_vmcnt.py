@@ -14,15 +14,18 @@ import re
 import sys
 
 
-def check(path, want="", verbose=True, slack=0):
+def check(path, want="", verbose=True, slack=0, lag=0):
     """Replay every ring kernel in `path` whose symbol contains `want`.  `slack` is added to every
-    sync's vmcnt (negative = pretend the ledger claimed more stores; used to test the checker)."""
+    sync's vmcnt (negative = pretend the ledger claimed more stores; used to test the checker).
+    `lag`: which half of the workgroup's waves to replay when the kernel selects its DMA sites inside the asm
+    statement (pipeline.h SPLIT_DMA: `s_cmp_lg_u32 flag, 0` skips the site for lag != 0, `s_cmp_eq_u32` for lag == 0);
+    both halves must pass.  The ring DMA is global_load_lds or buffer_load ... lds."""
     text = open(path).read()
     funcs = re.split(r"\n(?=_Z[_A-Za-z0-9.$]+:)", text)       # function symbols only; local labels stay inside
     stats = {"ok": True, "kernels": 0, "syncs": 0, "dma_pieces": 0, "min_inflight": None}
     for f in funcs:
         name = f.split(":", 1)[0].strip()
-        if "s_barrier" not in f or "global_load_lds" not in f or want not in name:
+        if "s_barrier" not in f or not ("global_load_lds" in f or re.search(r"buffer_load_dwordx4 .* lds", f)) or want not in name:
             continue
         stats["kernels"] += 1
         queue = []          # in issue order: ('dma', block) / ('st',) / ('ld',)
@@ -30,9 +33,26 @@ def check(path, want="", verbose=True, slack=0):
         pieces = 2          # BF / WAVES
         n_sync = 0
         lines = f.splitlines()
+        skip_to = None      # label that ends a DMA site this half does not execute
+        pending_cmp = None
         for idx, line in enumerate(lines):
-            ins = line.strip().split(" ")[0] if line.strip() else ""
-            if ins.startswith("global_load_lds"):
+            stripped = line.strip()
+            if skip_to is not None:
+                if stripped.startswith(skip_to + ":"):
+                    skip_to = None
+                continue
+            ins = stripped.split(" ")[0] if stripped else ""
+            if ins in ("s_cmp_lg_u32", "s_cmp_eq_u32") and stripped.endswith(", 0"):
+                pending_cmp = ins
+                continue
+            if ins == "s_cbranch_scc1" and pending_cmp and ".Lskip_" in stripped:
+                skipped = (lag != 0) if pending_cmp == "s_cmp_lg_u32" else (lag == 0)
+                if skipped:
+                    skip_to = stripped.split()[-1]
+                pending_cmp = None
+                continue
+            pending_cmp = None
+            if ins.startswith("global_load_lds") or (ins == "buffer_load_dwordx4" and stripped.endswith("lds")):
                 queue.append(("dma", n_dma // pieces)); n_dma += 1
             elif ins.startswith(("global_store", "global_atomic", "scratch_store", "buffer_store", "flat_store")):
                 queue.append(("st",))
@@ -47,6 +67,8 @@ def check(path, want="", verbose=True, slack=0):
                         n = max(0, n - slack) if slack < 0 else n + slack
                     queue = queue[len(queue) - n:] if n else []
             elif ins == "s_barrier":
+                if n_dma == 0:         # a barrier before any ring DMA (a tile loop's end-of-tile drain laid out in front
+                    continue           # of the loop body): not one of the numbered syncs
                 need = n_sync          # sync B = n_sync - 1 publishes block B + 1
                 if any(q[0] == "dma" and q[1] <= need for q in queue):
                     stats["ok"] = False
@@ -65,4 +87,5 @@ def check(path, want="", verbose=True, slack=0):
 
 
 if __name__ == "__main__":
-    sys.exit(0 if check(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "")["ok"] else 1)
+    tag = sys.argv[2] if len(sys.argv) > 2 else ""
+    sys.exit(0 if check(sys.argv[1], tag, lag=0)["ok"] and check(sys.argv[1], tag, lag=1)["ok"] else 1)
