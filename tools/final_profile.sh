@@ -15,4 +15,8 @@ for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUS
   N=$(echo $C | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$N -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_$N.json 2> $OUT/pmc_$N.err || echo "pmc pass $N failed"
 done
+# keep what is judged (the summaries) and drop the per-dispatch tables: gpurun merges at most 64 MiB back
+python tools/pmc_summary.py $OUT $OUT/pmc_summary.json
+cp $OUT/stats/*/*_kernel_stats.csv $OUT/kernel_stats.csv
+rm -rf $OUT/stats $OUT/pmc_*/
 echo final-profile-done
