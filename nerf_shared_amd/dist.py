@@ -133,6 +133,34 @@ class OverlappedGather:
         return out
 
 
+def broadcast_parameters(models, src=0, group=None):
+    """Replicate the parameters of `models` (NeRF modules; None entries are skipped) from rank `src` to every rank:
+    one broadcast of one flat buffer per model (2.4 MB for the 8x256 field), then the packed device copies are marked
+    stale so the next render re-packs them.  The ranks of a sharded render must hold identical weights (SURVEY.md
+    section 8e: weights replicated once at load); loading the same checkpoint on every rank makes this unnecessary."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for m in models:
+        if m is None:
+            continue
+        params = [p for p in m.parameters()]
+        flat = torch.cat([p.detach().reshape(-1) for p in params])
+        if flat.is_cuda and dist.get_backend(group) == "gloo":
+            host = flat.cpu()
+            dist.broadcast(host, src=src, group=group)
+            flat = host.to(flat.device)
+        else:
+            dist.broadcast(flat, src=src, group=group)
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                n = p.numel()
+                p.copy_(flat[off:off + n].view_as(p))
+                off += n
+        if hasattr(m, "weights_changed"):
+            m.weights_changed()
+
+
 def pack_maps(ret):
     """[n, 5] = rgb(3) | disp | acc rows of a render_batch result: the gather payload."""
     return torch.cat([ret['rgb_map'], ret['disp_map'][:, None], ret['acc_map'][:, None]], -1)

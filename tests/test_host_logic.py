@@ -178,6 +178,19 @@ for n in (10, 11, 4096):
     ok = ok and ((got8 is not None and got8.dtype == torch.uint8 and torch.equal(got8, full8)) if rank == 0 else got8 is None)
     # round-robin frame assignment of render_poses_sharded
     ok = ok and list(range(rank, n, world)) == [i for i in range(n) if i %% world == rank]
+# weights replicated from rank 0: every rank ends with rank 0's parameters and a stale pack key
+import torch.nn as tnn
+class _M(tnn.Module):
+    def __init__(self, seed):
+        super().__init__()
+        torch.manual_seed(seed)
+        self.a, self.b = tnn.Linear(5, 7), tnn.Linear(7, 3)
+        self.stale = False
+    def weights_changed(self):
+        self.stale = True
+mine, ref = _M(100 + rank), _M(100)
+nd.broadcast_parameters([mine, None], src=0)
+ok = ok and all(torch.equal(p, q) for p, q in zip(mine.parameters(), ref.parameters())) and mine.stale
 # the overlapped per-frame gather: frames come back in submission order with the right rows, whatever the
 # depth of the in-flight window, for even and ragged shards; submit() does not complete the gather itself
 for n, depth in ((12, 1), (12, 2), (11, 2), (4097, 3)):
