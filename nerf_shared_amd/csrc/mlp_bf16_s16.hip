@@ -288,7 +288,10 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16_kernel(MlpArgs 
     const int q = lane >> 4;
     C c;
     c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    c.lag = __builtin_amdgcn_readfirstlane(c.wave >= C::WAVES / 2 ? 1 : 0);   // an SGPR: the DMA asm branches on it
+    c.lag = __builtin_amdgcn_readfirstlane(c.wave >= C::WAVES / 2 ? 1 : 0);
+    // SPLIT_DMA issue phase (an SGPR: the DMA asm branches on it): two phases 0 / 2 by wave half; four phases
+    // 0 1 2 3 2 3 0 1 over the waves, so that SIMD partners (w, w + 4) are always half a block apart
+    c.phase = __builtin_amdgcn_readfirstlane(C::N_PHASES == 4 ? ((c.wave + 2 * (c.wave >> 2)) & 3) : (c.wave >= C::WAVES / 2 ? 2 : 0));
     if constexpr ((C::OPT & 16) != 0) {      // static priority for the second-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
         if (c.lag) __builtin_amdgcn_s_setprio(1);
     }
@@ -497,7 +500,10 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16p_kernel(MlpArgs
     if (tile >= n_point_tiles) return;                     // whole workgroups only (the launcher never over-provisions)
     C c;
     c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    c.lag = __builtin_amdgcn_readfirstlane(c.wave >= C::WAVES / 2 ? 1 : 0);   // an SGPR: the DMA asm branches on it
+    c.lag = __builtin_amdgcn_readfirstlane(c.wave >= C::WAVES / 2 ? 1 : 0);
+    // SPLIT_DMA issue phase (an SGPR: the DMA asm branches on it): two phases 0 / 2 by wave half; four phases
+    // 0 1 2 3 2 3 0 1 over the waves, so that SIMD partners (w, w + 4) are always half a block apart
+    c.phase = __builtin_amdgcn_readfirstlane(C::N_PHASES == 4 ? ((c.wave + 2 * (c.wave >> 2)) & 3) : (c.wave >= C::WAVES / 2 ? 2 : 0));
     c.gstream = reinterpret_cast<const char *>(a.stream_s16) + lane * 16;
     c.gstream_next = c.gstream;
     c.ring_lane = smem + lane * 16;
@@ -773,6 +779,8 @@ int launch_mlp_bf16_s16(const MlpArgs &a, int multires, int multires_views, int 
             case 47: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 8>>(a, n_frags_used, n_tiles, s);        // simple kernel, global_load_lds DMA
             case 48: return launch_wg16p<10, 4, true, Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 8 + 32>>(a, n_frags_used, n_tiles, s);  // pipelined, global_load_lds DMA
             case 49: return launch_wg16p<10, 4, true, Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 32 + 64>>(a, n_frags_used, n_tiles, s);  // pipelined + buffer DMA, no split
+            case 59: return launch_wg16p<10, 4, true, Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 128 + 32 + 64>>(a, n_frags_used, n_tiles, s);  // four DMA issue phases
+            case 60: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 128 + 64>>(a, n_frags_used, n_tiles, s);         // simple kernel, four phases
             case 56: return launch_wg16<10, 4, true, Ctx<8, 32, 3, 16, 4, 0, 1, 4 + 8 + 64>>(a, n_frags_used, n_tiles, s);  // 32-fragment blocks (half the barriers), 96-KiB ring
             case 57: return launch_wg16<10, 4, true, Ctx<8, 32, 4, 16, 4, 0, 1, 4 + 8 + 64>>(a, n_frags_used, n_tiles, s);  // 32-fragment blocks, 128-KiB ring
             case 58: return launch_wg16<10, 4, true, Ctx<8, 32, 4, 16, 8, 0, 1, 4 + 8 + 64>>(a, n_frags_used, n_tiles, s);  // + 8-deep read-ahead

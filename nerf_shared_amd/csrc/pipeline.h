@@ -60,13 +60,15 @@ struct Ctx {
     static constexpr int BLOCK_BYTES = BF * 1024;
     static constexpr int RING_BYTES = NS * BLOCK_BYTES;
     static constexpr int LOOKAHEAD = PHASE > 0 ? 1 : 0;  // a sync at block b publishes block b + LOOKAHEAD
+    static constexpr int N_PHASES = (OPT_ & 128) ? 4 : (OPT_ & 8) ? 2 : 1;   // SPLIT_DMA issue phases (late_issue)
     static_assert(BF % WAVES == 0 && NS >= 3 && PHASE < BF, "bad pipeline shape");
     const char *gstream;     // this lane's view of the fragment stream (base + lane*16)
     const char *ring_lane;   // LDS ring + lane*16
     uint32_t ring_u32;       // LDS byte address of the ring
     const float *bias_half;  // LDS bias table + (lane>>5)*16
     int wave;
-    int lag;                 // STAGGER / SPLIT_DMA: 1 for waves WAVES/2.. (wave-uniform)
+    int lag;                 // STAGGER: 1 for waves WAVES/2.. (wave-uniform)
+    int phase;               // SPLIT_DMA: this wave's issue phase 0..3 (wave-uniform; SIMD partners w, w+4 differ by 2)
     // OPT & 32 (CONTINUOUS): the weight stream does not stop at a tile boundary.  The blocks of consecutive tiles
     // are numbered through (V = t NB + b, ring slot V mod NS), so the first blocks of the next tile are fetched
     // under the last blocks of the current one and nothing drains in between.  Inside a tile block b is reached
@@ -100,7 +102,8 @@ typedef __attribute__((address_space(3))) const bf16x8 lds_frag_t;
 
 // LDS-DMA of this wave's share of stream block BB into its ring slot.  SRC >= 0: block SRC of the NEXT tile's
 // stream goes into the slot that block BB of the through-numbered stream owns (CONTINUOUS).
-// SEL: 0 = every wave issues; 1 = only waves with c.lag == 0; 2 = only waves with c.lag != 0.  The selection is a
+// SEL: 0 = every wave issues; 1 + p = only the waves whose c.phase == p (SPLIT_DMA: p = 0 right behind the sync,
+// p = 2 half a block later; with four phases p = 1, 3 a quarter block in between).  The selection is a
 // scalar branch INSIDE the asm statement: to the compiler the call site stays straight-line code (a C++ `if` around the
 // DMA splits the kernel's one large scheduling region and costs the view-branch kernels ~50 VGPRs and spills).
 template <int BB, class C, int SRC = -1, int SEL = 0>
@@ -110,7 +113,7 @@ __device__ __forceinline__ void issue_block(const C &c) {
         static_assert(C::PIECES * 1024 <= 4096, "a wave's pieces must fit the 12-bit immediate offset");
         const unsigned soff = __builtin_amdgcn_readfirstlane(c.wave_off + (unsigned)(SRC >= 0 ? SRC : BB) * C::BLOCK_BYTES);
         const unsigned l0 = __builtin_amdgcn_readfirstlane(((C::OPT & 32) != 0 ? c.slot_u32[slot] : c.ring_u32 + slot * C::BLOCK_BYTES) + c.wave_off);
-        const int lag_s = SEL == 0 ? 0 : __builtin_amdgcn_readfirstlane(c.lag);
+        const int lag_s = SEL == 0 ? 0 : __builtin_amdgcn_readfirstlane(c.phase);
         const auto rs = SRC >= 0 ? c.rsrc_next : c.rsrc;
         unsigned keep;
         // one asm statement per block: M0 is set once, the pieces are consecutive immediates
@@ -121,14 +124,11 @@ __device__ __forceinline__ void issue_block(const C &c) {
         if constexpr (SEL == 0) {                                                                                         \
             asm volatile("s_mov_b32 %0, m0\n\t" "s_mov_b32 m0, %3\n\t" "s_nop 0\n\t" LOADS "s_mov_b32 m0, %0"            \
                          : "=&s"(keep) : "v"(c.lane16), "s"(rs), "s"(l0), "s"(soff) : "memory");                           \
-        } else if constexpr (SEL == 1) {                                                                                  \
-            asm volatile("s_cmp_lg_u32 %5, 0\n\t" "s_cbranch_scc1 .Lskip_bdma_%=\n\t" "s_mov_b32 %0, m0\n\t"               \
-                         "s_mov_b32 m0, %3\n\t" "s_nop 0\n\t" LOADS "s_mov_b32 m0, %0\n" ".Lskip_bdma_%=:"                 \
-                         : "=&s"(keep) : "v"(c.lane16), "s"(rs), "s"(l0), "s"(soff), "s"(lag_s) : "memory", "scc");        \
         } else {                                                                                                          \
-            asm volatile("s_cmp_eq_u32 %5, 0\n\t" "s_cbranch_scc1 .Lskip_bdma_%=\n\t" "s_mov_b32 %0, m0\n\t"               \
+            asm volatile("s_cmp_lg_u32 %5, %6\n\t" "s_cbranch_scc1 .Lskip_bdma_%=\n\t" "s_mov_b32 %0, m0\n\t"              \
                          "s_mov_b32 m0, %3\n\t" "s_nop 0\n\t" LOADS "s_mov_b32 m0, %0\n" ".Lskip_bdma_%=:"                 \
-                         : "=&s"(keep) : "v"(c.lane16), "s"(rs), "s"(l0), "s"(soff), "s"(lag_s) : "memory", "scc");        \
+                         : "=&s"(keep) : "v"(c.lane16), "s"(rs), "s"(l0), "s"(soff), "s"(lag_s), "n"(SEL - 1)              \
+                         : "memory", "scc");                                                                              \
         }                                                                                                                 \
     } while (0)
         static_assert(C::PIECES == 2 || C::PIECES == 4, "pieces per wave and block");
@@ -143,7 +143,7 @@ __device__ __forceinline__ void issue_block(const C &c) {
         const char *g = (SRC >= 0 ? c.gstream_next + (size_t)SRC * C::BLOCK_BYTES : c.gstream + (size_t)BB * C::BLOCK_BYTES) + piece * 1024;
         const uint32_t l = ((C::OPT & 32) != 0 ? c.slot_u32[slot] : c.ring_u32 + slot * C::BLOCK_BYTES) + piece * 1024;   // wave-uniform
         unsigned keep;
-        const int lag_s = SEL == 0 ? 0 : __builtin_amdgcn_readfirstlane(c.lag);     // certainly an SGPR for the asm's s_cmp
+        const int lag_s = SEL == 0 ? 0 : __builtin_amdgcn_readfirstlane(c.phase);   // certainly an SGPR for the asm's s_cmp
         if constexpr (SEL == 0) {
             asm volatile(
                 "s_mov_b32 %0, m0\n\t"
@@ -154,22 +154,9 @@ __device__ __forceinline__ void issue_block(const C &c) {
                 : "=&s"(keep)
                 : "v"(g), "s"(l)
                 : "memory");
-        } else if constexpr (SEL == 1) {
-            asm volatile(
-                "s_cmp_lg_u32 %3, 0\n\t"
-                "s_cbranch_scc1 .Lskip_dma_%=\n\t"
-                "s_mov_b32 %0, m0\n\t"
-                "s_mov_b32 m0, %2\n\t"
-                "s_nop 0\n\t"
-                "global_load_lds_dwordx4 %1, off\n\t"
-                "s_mov_b32 m0, %0\n"
-                ".Lskip_dma_%=:"
-                : "=&s"(keep)
-                : "v"(g), "s"(l), "s"(lag_s)
-                : "memory", "scc");
         } else {
             asm volatile(
-                "s_cmp_eq_u32 %3, 0\n\t"
+                "s_cmp_lg_u32 %3, %4\n\t"
                 "s_cbranch_scc1 .Lskip_dma_%=\n\t"
                 "s_mov_b32 %0, m0\n\t"
                 "s_mov_b32 m0, %2\n\t"
@@ -178,21 +165,21 @@ __device__ __forceinline__ void issue_block(const C &c) {
                 "s_mov_b32 m0, %0\n"
                 ".Lskip_dma_%=:"
                 : "=&s"(keep)
-                : "v"(g), "s"(l), "s"(lag_s)
+                : "v"(g), "s"(l), "s"(lag_s), "n"(SEL - 1)
                 : "memory", "scc");
         }
     }
 }
 
 // The DMA that sync S_B starts: block B+NS-1 of this tile, or (CONTINUOUS, with a next tile) the block of the next tile
-// that owns the same ring slot.  LATE = false: the call right behind the barrier (all waves, or with SPLIT_DMA the
-// early half); LATE = true: the late half's call half a block later.
-template <int B, int NB, bool LATE, class C>
+// that owns the same ring slot.  PH: the issue phase of this call site (0 = right behind the barrier).  Without
+// SPLIT_DMA every wave issues at phase 0; with it only the waves of that phase do.
+template <int B, int NB, int PH, class C>
 __device__ __forceinline__ void sync_issue(const C &c) {
     constexpr int BB = B + C::NS - 1;
-    constexpr bool split = (C::OPT & 8) != 0;
-    if constexpr (LATE && !split) return;
-    constexpr int SEL = !split ? 0 : LATE ? 2 : 1;
+    constexpr bool split = C::N_PHASES > 1;
+    if constexpr (PH != 0 && !split) return;
+    constexpr int SEL = !split ? 0 : 1 + PH;
     if constexpr (BB < NB) {
         issue_block<BB, C, -1, SEL>(c);
     } else if constexpr ((C::OPT & 32) != 0 && BB - NB < C::NS - 1 - C::LOOKAHEAD) {
@@ -239,21 +226,36 @@ __device__ __forceinline__ void block_sync(const C &c) {
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(cnt) : "memory");
         __builtin_amdgcn_sched_barrier(0);
     }
-    sync_issue<B, NB, false>(c);
+    sync_issue<B, NB, 0>(c);
 }
 
-// OPT & 8 (SPLIT_DMA): waves WAVES/2.. issue their DMA pieces of block b+NS-1 half a block after sync S_b instead of
-// right behind its barrier, so the two waves of a SIMD are never both inside the (slow, ~100 cycles per piece)
-// LDS-DMA issue path at the same time.  The pieces are still issued between S_b and S_b+1 in every wave's program
-// order, so the counted vmcnt waits are unchanged.
-template <int n, int NB, class C>
+// SPLIT_DMA (OPT & 8: two phases, OPT & 128: four): the waves of phase p issue their DMA pieces of block b+NS-1 p quarter
+// blocks after sync S_b instead of right behind its barrier (phases 0 and 2 with two phases), so the two waves of a SIMD
+// -- whose phases differ by 2 -- are never both inside the slow LDS-DMA issue path, and with four phases only two of the
+// CU's eight waves are at any time.  The pieces are still issued between S_b and S_b+1 in every wave's program order, so
+// the counted vmcnt waits are unchanged.
+template <int n, int NB, int NFRAGS, class C>
 __device__ __forceinline__ void late_issue(const C &c) {
-    if constexpr ((C::OPT & 8) != 0 && C::PHASE > 0) {
-        constexpr int half = (C::PHASE + C::BF / 2) % C::BF;
-        if constexpr (n % C::BF == half && (n - C::PHASE - C::BF / 2) >= -C::BF) {
-            constexpr int B = (n - C::PHASE - C::BF / 2) / C::BF;     // the sync half a block ago (n = 0: the prologue's sync -1)
-            if constexpr (B >= -1 && B + C::LOOKAHEAD < NB) sync_issue<B, NB, true>(c);
-        }
+    if constexpr (C::N_PHASES > 1 && C::PHASE > 0) {
+        static_for<3>([&](auto i_) {
+            constexpr int ph = i_ + 1;                                  // phases 1, 2, 3
+            if constexpr (C::N_PHASES == 4 || ph == 2) {
+                constexpr int off = C::PHASE + ph * (C::BF / 4);            // fragments behind the block start of the sync's block
+                if constexpr ((n - off) % C::BF == 0 && n - off >= -C::BF) {
+                    constexpr int B = (n - off) / C::BF;                    // the sync this issue belongs to (n = off - BF: the prologue's sync -1)
+                    if constexpr (B >= -1 && B + C::LOOKAHEAD < NB) sync_issue<B, NB, ph>(c);
+                }
+                // a phase whose slot behind the prologue's sync -1 would lie in front of fragment 0 issues at fragment 0
+                if constexpr (n == 0 && off < C::BF && -1 + C::LOOKAHEAD < NB) sync_issue<-1, NB, ph>(c);
+                // ... and one whose slot behind the tile's last syncs would lie past the last fragment issues at the last one
+                if constexpr (n == NFRAGS - 1) {
+                    static_for<2>([&](auto j_) {
+                        constexpr int B = NB - 2 - j_;
+                        if constexpr (B >= 0 && B * C::BF + off > NFRAGS - 1) sync_issue<B, NB, ph>(c);
+                    });
+                }
+            }
+        });
     }
 }
 
@@ -296,7 +298,7 @@ __device__ __forceinline__ void maybe_sync(const C &c) {
 template <int n, int NB, int NFRAGS, class C>
 __device__ __forceinline__ bf16x8 take(C &c) {
     maybe_sync<n, NB>(c);
-    late_issue<n, NB>(c);
+    late_issue<n, NB, NFRAGS>(c);
     if constexpr (C::ABL & 2) {
         bf16x8 f = c.q[0];
         asm volatile("" : "+v"(f));     // opaque: keeps one MFMA per fragment without an LDS read

@@ -17,9 +17,9 @@ import sys
 def check(path, want="", verbose=True, slack=0, lag=0):
     """Replay every ring kernel in `path` whose symbol contains `want`.  `slack` is added to every
     sync's vmcnt (negative = pretend the ledger claimed more stores; used to test the checker).
-    `lag`: which half of the workgroup's waves to replay when the kernel selects its DMA sites inside the asm
-    statement (pipeline.h SPLIT_DMA: `s_cmp_lg_u32 flag, 0` skips the site for lag != 0, `s_cmp_eq_u32` for lag == 0);
-    both halves must pass.  The ring DMA is global_load_lds or buffer_load ... lds."""
+    `lag`: the DMA issue phase of the waves to replay when the kernel selects its DMA sites inside the asm statement
+    (pipeline.h SPLIT_DMA: `s_cmp_lg_u32 phase, K` + a branch over the site of phase K; two phases: 0 and 2); every
+    phase must pass.  The ring DMA is global_load_lds or buffer_load ... lds."""
     text = open(path).read()
     funcs = re.split(r"\n(?=_Z[_A-Za-z0-9.$]+:)", text)       # function symbols only; local labels stay inside
     stats = {"ok": True, "kernels": 0, "syncs": 0, "dma_pieces": 0, "min_inflight": None}
@@ -42,12 +42,12 @@ def check(path, want="", verbose=True, slack=0, lag=0):
                     skip_to = None
                 continue
             ins = stripped.split(" ")[0] if stripped else ""
-            if ins in ("s_cmp_lg_u32", "s_cmp_eq_u32") and stripped.endswith(", 0"):
-                pending_cmp = ins
+            m_cmp = re.match(r"s_cmp_lg_u32 s\d+, (\d+)$", stripped)
+            if m_cmp:                   # `s_cmp_lg_u32 phase, K; s_cbranch_scc1 .Lskip_...`: the site belongs to phase K
+                pending_cmp = int(m_cmp.group(1))
                 continue
-            if ins == "s_cbranch_scc1" and pending_cmp and ".Lskip_" in stripped:
-                skipped = (lag != 0) if pending_cmp == "s_cmp_lg_u32" else (lag == 0)
-                if skipped:
+            if ins == "s_cbranch_scc1" and pending_cmp is not None and ".Lskip_" in stripped:
+                if lag != pending_cmp:
                     skip_to = stripped.split()[-1]
                 pending_cmp = None
                 continue
@@ -88,4 +88,4 @@ def check(path, want="", verbose=True, slack=0, lag=0):
 
 if __name__ == "__main__":
     tag = sys.argv[2] if len(sys.argv) > 2 else ""
-    sys.exit(0 if check(sys.argv[1], tag, lag=0)["ok"] and check(sys.argv[1], tag, lag=1)["ok"] else 1)
+    sys.exit(0 if check(sys.argv[1], tag, lag=0)["ok"] and check(sys.argv[1], tag, lag=2)["ok"] else 1)
