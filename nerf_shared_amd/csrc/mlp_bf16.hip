@@ -182,9 +182,9 @@ __global__ __launch_bounds__(C::WAVES * 64, C::WAVES_PER_SIMD) void mlp_bf16_ker
         } else {
             const float *r = a.rays + ray * a.ray_stride;
             const float z = a.z_vals[pc];
-            x0 = __fadd_rn(r[0], __fmul_rn(r[3], z));
-            x1 = __fadd_rn(r[1], __fmul_rn(r[4], z));
-            x2 = __fadd_rn(r[2], __fmul_rn(r[5], z));
+            x0 = mul_then_add(r[3], z, r[0]);
+            x1 = mul_then_add(r[4], z, r[1]);
+            x2 = mul_then_add(r[5], z, r[2]);
         }
         if constexpr (C::ABL & 4) {
             static_for<KE>([&](auto k_) { constexpr int k = k_; for (int j = 0; j < 8; ++j) E[k * NP + i][j] = (__bf16)(x0 + j); });

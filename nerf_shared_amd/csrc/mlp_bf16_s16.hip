@@ -365,9 +365,9 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16_kernel(MlpArgs 
             load_dirs();
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {                       // pts = o + d z, rounded like the reference's two ops
-                xs[cc][0] = __fadd_rn(o[cc][0], __fmul_rn(o[cc][3], z[cc]));
-                xs[cc][1] = __fadd_rn(o[cc][1], __fmul_rn(o[cc][4], z[cc]));
-                xs[cc][2] = __fadd_rn(o[cc][2], __fmul_rn(o[cc][5], z[cc]));
+                xs[cc][0] = mul_then_add(o[cc][3], z[cc], o[cc][0]);
+                xs[cc][1] = mul_then_add(o[cc][4], z[cc], o[cc][1]);
+                xs[cc][2] = mul_then_add(o[cc][5], z[cc], o[cc][2]);
             }
         }
     }
@@ -557,9 +557,9 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16p_kernel(MlpArgs
         if (a.pts) {
             xsn[0] = ld[0]; xsn[1] = ld[1]; xsn[2] = ld[2];
         } else {                                             // pts = o + d z, rounded like the reference's two ops
-            xsn[0] = __fadd_rn(ld[0], __fmul_rn(ld[3], ld[6]));
-            xsn[1] = __fadd_rn(ld[1], __fmul_rn(ld[4], ld[6]));
-            xsn[2] = __fadd_rn(ld[2], __fmul_rn(ld[5], ld[6]));
+            xsn[0] = mul_then_add(ld[3], ld[6], ld[0]);
+            xsn[1] = mul_then_add(ld[4], ld[6], ld[1]);
+            xsn[2] = mul_then_add(ld[5], ld[6], ld[2]);
         }
     };
 

@@ -250,9 +250,9 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bwd_s16_kernel(MlpArgs a
             } else {
                 const float *r = a.rays + ray * a.ray_stride;
                 zp[cc] = a.z_vals[pc];
-                xp[cc][0] = __fadd_rn(r[0], __fmul_rn(r[3], zp[cc]));
-                xp[cc][1] = __fadd_rn(r[1], __fmul_rn(r[4], zp[cc]));
-                xp[cc][2] = __fadd_rn(r[2], __fmul_rn(r[5], zp[cc]));
+                xp[cc][0] = mul_then_add(r[3], zp[cc], r[0]);
+                xp[cc][1] = mul_then_add(r[4], zp[cc], r[1]);
+                xp[cc][2] = mul_then_add(r[5], zp[cc], r[2]);
             }
             const float *d = a.viewdirs + ray * a.vd_stride;
             dv[cc][0] = d[0]; dv[cc][1] = d[1]; dv[cc][2] = d[2];

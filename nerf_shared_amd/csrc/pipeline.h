@@ -312,6 +312,16 @@ __device__ __forceinline__ bf16x8 take(C &c) {
     }
 }
 
+// o + d * z with the product rounded before the sum, as the reference's two ATen ops do (render_utils.py:131).  HIP's
+// __fmul_rn / __fadd_rn are plain operators to the compiler, which contracts them into one v_fma (single rounding) under
+// the default -ffp-contract=fast -- the round-1 kernels did, in the rays + depths mode.  The empty asm makes the product
+// opaque, so it stays a product.
+__device__ __forceinline__ float mul_then_add(float a, float b, float c) {
+    float m = a * b;
+    asm volatile("" : "+v"(m));
+    return m + c;
+}
+
 // ReLU as one integer max on the fp32 bits (negative floats are negative ints);
 // fmaxf would cost a second v_max to canonicalise a possible sNaN.
 __device__ __forceinline__ float relu_bits(float v) {

@@ -212,6 +212,53 @@ def test_nerf_forward_ragged_and_large(dev, golden):
     close(one, fullbf[:1, :1], atol=0)
 
 
+def test_pipelined_kernel_equals_per_tile_kernel_on_many_shapes(dev):
+    """The default inference kernel carries its weight stream and the next tile's encoding across tile boundaries
+    (continuous ring: run-time choice of one sync's vmcnt count, next tile's first blocks fetched early, slot table
+    rotated per tile).  Its outputs must equal the simple per-tile kernel's (nerf_amd_set_tuning(0, 41)) bit for bit for
+    every shape of launch: fewer tiles than CUs, exactly one / two / three tiles per workgroup with and without a ragged
+    last tile, one point, both input modes (explicit points, rays + depths), both encodings, with and without view branch."""
+    nerf, _, _ = amd()
+    from nerf_shared_amd import _lib
+    rng = np.random.default_rng(77)
+    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+    tile = 256
+    sizes = [1, 31, 255, 256, 257, 1000, tile * n_cu - 1, tile * n_cu, tile * n_cu + 1, tile * n_cu + 300,
+             2 * tile * n_cu - 7, 2 * tile * n_cu, 2 * tile * n_cu + 513, 3 * tile * n_cu + 1, 5 * tile * n_cu - 255]
+    archs = [(VD, 1), (dict(VD, multires=15, multires_views=6), 6), (NOVD, 2), (dict(NOVD, multires=15), 2)]
+    try:
+        for arch, seed in archs:
+            m = gpu_model(dev, seed, 3.0, "bf16", **arch)
+            vd_on = arch["use_viewdirs"]
+            for P in sizes:
+                S = int(rng.choice([1, 3, 64, 192, 128]))
+                R = -(-P // S)
+                pts = torch.from_numpy(rng.uniform(-3, 3, size=(R, S, 3)).astype(np.float32)).to(dev)
+                vd = torch.nn.functional.normalize(torch.randn(R, 3, device=dev), dim=-1) if vd_on else None
+                outs = []
+                for variant in (0, 41):
+                    _lib.check(_lib.lib.nerf_amd_set_tuning(0, variant), "set_tuning")
+                    outs.append(m(pts, vd).clone())
+                torch.cuda.synchronize()
+                assert torch.equal(outs[0], outs[1]), (arch["multires"], vd_on, "points", R, S)
+        # rays + depths mode (what render_rays launches), view-branch model
+        _, render_utils, utils = amd()
+        K = synth.lego_intrinsics(400, 400)
+        c, f = gpu_model(dev, 1, 3.0, "bf16", **VD), gpu_model(dev, 19, 3.0, "bf16", **VD)
+        r = render_utils.Renderer(**BASE)
+        for n in (1, 5, 341, 1024, 1365, 4096, 4097):
+            batch = utils.make_ray_batch(400, 400, K, synth.LEGO_C2W, 2.0, 6.0, True, False, device=dev, pix0=70000, n=n)
+            outs = []
+            for variant in (0, 41):
+                _lib.check(_lib.lib.nerf_amd_set_tuning(0, variant), "set_tuning")
+                outs.append({k: v.clone() for k, v in r.render_rays(batch, c, f, retraw=True).items()})
+            torch.cuda.synchronize()
+            for k in outs[0]:
+                assert torch.equal(torch.nan_to_num(outs[0][k]), torch.nan_to_num(outs[1][k])), ("rays", n, k)
+    finally:
+        _lib.lib.nerf_amd_set_tuning(0, 0)
+
+
 def test_weight_update_repacks(dev, golden):
     g = golden("g2_nerf")
     pts, vd = torch.from_numpy(g["pts"]).to(dev), torch.from_numpy(g["viewdirs"]).to(dev)
