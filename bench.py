@@ -308,10 +308,12 @@ def main():
                             "workload": WORKLOADS["c5"]["name"],
                             "note": "the N>1 workload on one GPU: the N=1 point of the strong-scaling curve"}
         if world > 1:
-            drr, rrr, _ = run(w, args.perturb, args.steps, min(args.warmup, 1), mode="frames_round_robin")
-            sub["frames_round_robin"] = {"value": rrr * args.steps / drr, "unit": "rays/s", "ms_per_step": drr / args.steps * 1e3,
-                                         "steps": args.steps,
-                                         "note": "whole frames dealt round-robin, no data-path collective, frames stay on their rank"}
+            k_rr = -(-args.steps // world) * world          # whole rounds, so that every rank renders the same number of frames
+            drr, rrr, _ = run(w, args.perturb, k_rr, min(args.warmup, 1), mode="frames_round_robin")
+            sub["frames_round_robin"] = {"value": rrr * k_rr / drr, "unit": "rays/s", "ms_per_step": drr / k_rr * 1e3,
+                                         "steps": k_rr,
+                                         "note": "whole frames dealt round-robin (steps rounded up to whole rounds), no data-path collective, "
+                                                 "frames stay on their rank"}
 
     if rank == 0:
         value = rays_per_step * args.steps / dt
