@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NERF_AMD_ABI_VERSION 3
+#define NERF_AMD_ABI_VERSION 4
 
 #define NERF_AMD_OK            0
 #define NERF_AMD_EINVAL       -1   /* bad argument / unsupported shape        */
@@ -291,6 +291,18 @@ int nerf_amd_get_rays_backward(int32_t H, int32_t W, const double *K4, int64_t p
  * (render_utils.py:312): out[i] = uint8(255 * clip(x[i], 0, 1)), truncating; NaN -> 0.
  * x [n] fp32 DEVICE (16-byte aligned), out [n] uint8 DEVICE (4-byte aligned). */
 int nerf_amd_to8b(const float *x, int64_t n, uint8_t *out, void *stream);
+
+/* Optimizer step of the training loop (main.py:104 on the torch.optim.Adam of utils.py:163-172): Adam for
+ * n parameter tensors in one launch.  params / grads / exp_avg / exp_avg_sq: HOST arrays of n DEVICE pointers
+ * to fp32 tensors of numel[i] elements (4-byte aligned; any n).  Per element, in fp32 and in the order of
+ * torch/optim/adam.py _single_tensor_adam:
+ *   g += weight_decay p (if != 0);  m += (1 - beta1)(g - m);  v = v beta2 + (1 - beta2) g g;
+ *   p -= (lr / bias_correction1) * m / (sqrt(v) / sqrt(bias_correction2) + eps)
+ * with bias_correction{1,2} = 1 - beta{1,2}^step evaluated in double from `step` (>= 1, the count INCLUDING
+ * this step).  amsgrad / maximize are not provided. */
+int nerf_amd_adam_step(int32_t n, float *const *params, const float *const *grads, float *const *exp_avg,
+                       float *const *exp_avg_sq, const int64_t *numel, int64_t step, double lr, double beta1,
+                       double beta2, double eps, double weight_decay, void *stream);
 
 /* ------------------------------------------------------------------------
  * Measurement hook (bench.py): while enabled, every field-MLP launch is

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NERF_AMD_LIB selects another build of the same library (diagnostic builds such as -DNERF_AMD_STAMPS)
 LIB_PATH = os.environ.get("NERF_AMD_LIB") or os.path.join(_HERE, "libnerf_amd.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 PREC_FP32, PREC_BF16 = 0, 1
 MAX_SKIPS = 8
 
@@ -26,7 +26,7 @@ EXPORTS = (
     "nerf_amd_render_batch_workspace", "nerf_amd_render_batch",
     "nerf_amd_profile_enable", "nerf_amd_profile_collect", "nerf_amd_set_tuning",
     "nerf_amd_model_supports_training", "nerf_amd_train_workspace", "nerf_amd_field_forward_train",
-    "nerf_amd_field_backward", "nerf_amd_coarse_z", "nerf_amd_resample", "nerf_amd_get_rays_backward", "nerf_amd_to8b", "nerf_amd_ndc_rays_backward",
+    "nerf_amd_field_backward", "nerf_amd_coarse_z", "nerf_amd_resample", "nerf_amd_get_rays_backward", "nerf_amd_to8b", "nerf_amd_ndc_rays_backward", "nerf_amd_adam_step",
 )
 
 
@@ -102,6 +102,8 @@ def _load():
         "nerf_amd_get_rays_backward": (c_int, [c_int32, c_int32, POINTER(c_double), c_int64, c_int64, c_void_p, c_void_p,
                                                c_void_p, c_void_p]),
         "nerf_amd_to8b": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+        "nerf_amd_adam_step": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double,
+                               c_double, c_double, c_double, c_void_p]),
         "nerf_amd_ndc_rays_backward": (c_int, [c_int32, c_int32, c_double, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_int64, c_void_p, c_void_p, c_void_p]),
         "nerf_amd_profile_enable": (c_int, [c_int]),

@@ -277,7 +277,7 @@ __global__ __launch_bounds__(512) void dw_reduce8_kernel(DwReduceArgs a) {
 }
 
 template <int OT, int IT, int WO, int WI>
-__global__ __launch_bounds__(512, 2) void dw2_kernel(DwArgs a) {
+__device__ __forceinline__ void dw2_body(const DwArgs &a, const int wg, const int nwg) {
     static_assert(WO * WI == 8 && OT % WO == 0 && IT % WI == 0 && OT >= 4 && IT >= 4, "bad shape");
     constexpr int TO = OT / WO, TI = IT / WI;
     constexpr int RG = OT * 32, RX = IT * 32;                   // row bytes (unpadded)
@@ -289,7 +289,6 @@ __global__ __launch_bounds__(512, 2) void dw2_kernel(DwArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wo = wave / WI, wi = wave % WI;
-    const int wg = blockIdx.x, nwg = gridDim.x;
     const uint32_t ring = (uint32_t)(uintptr_t)smem;
 
     const int64_t n_chunks = (a.P + 31) / 32;
@@ -374,6 +373,52 @@ __global__ __launch_bounds__(512, 2) void dw2_kernel(DwArgs a) {
         for (int x = 0; x < TO; ++x)
             *reinterpret_cast<f32x4 *>(slab + OT * IT * 256 + (wo * TO + x) * 16 + 4 * (lane >> 4)) = accb[x];
     }
+}
+
+template <int OT, int IT, int WO, int WI>
+__global__ __launch_bounds__(512, 2) void dw2_kernel(DwArgs a) {
+    dw2_body<OT, IT, WO, WI>(a, blockIdx.x, gridDim.x);
+}
+
+// Every streaming product of one model's backward pass in ONE launch, and their reductions in a second one: a job owns a
+// range of workgroups sized to its bytes per point, 256 workgroups in all -- one per CU from the first chunk to the last, all
+// products in flight together (no ramp and tail per product, ~23 slabs per product to reduce instead of 128-256, and 2
+// launches per model instead of 22 on a step that is host-bound at the reference's batch size).
+constexpr int DW_MAX_JOBS = 16;
+struct DwJob {
+    DwArgs a;
+    int shape;                           // 0: <16,16,4,2>  1: <8,16,4,2>  2: <16,4,8,1>
+    int first_block, n_blocks;
+};
+struct DwMulti {
+    DwJob job[DW_MAX_JOBS];
+    int n;
+};
+struct DwReduceMulti {
+    DwReduceArgs r[DW_MAX_JOBS];
+    int first_block[DW_MAX_JOBS + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(512, 2) void dw_multi_kernel(DwMulti m) {
+    int j = 0;
+    while (j + 1 < m.n && (int)blockIdx.x >= m.job[j + 1].first_block) ++j;
+    j = __builtin_amdgcn_readfirstlane(j);
+    const DwJob &J = m.job[j];
+    const int wg = (int)blockIdx.x - J.first_block;
+    switch (J.shape) {
+    case 0: dw2_body<16, 16, 4, 2>(J.a, wg, J.n_blocks); break;
+    case 1: dw2_body<8, 16, 4, 2>(J.a, wg, J.n_blocks); break;
+    default: dw2_body<16, 4, 8, 1>(J.a, wg, J.n_blocks); break;
+    }
+}
+
+__global__ __launch_bounds__(512) void dw_reduce_multi_kernel(DwReduceMulti m) {
+    __shared__ float part[8 * 64];
+    int j = 0;
+    while (j + 1 < m.n && (int)blockIdx.x >= m.first_block[j + 1]) ++j;
+    j = __builtin_amdgcn_readfirstlane(j);
+    dw_reduce_block(m.r[j], (int)blockIdx.x - m.first_block[j], threadIdx.x, part);
 }
 
 // Heads (alpha_linear, rgb_linear): G = NO <= 4 natural-order columns of g_rawb [P, 4], X = [P, n_in]
@@ -525,12 +570,33 @@ struct DwSeq {
     float *slab = nullptr;
     int k = 0;
     bool overlap = false;
-    float *buffer() const { return slab + (size_t)(k & 1) * SLAB_FLOATS; }
+    int lanes = 0;                   // > 0: products go round-robin over this many streams (the caller's and lane_s[]), each with
+                                     // its own share of the slab buffer; a product's reduction follows it on its own stream
+                                     // (one fork and one join per model instead of a hand-off per product)
+    hipStream_t lane_s[3] = {nullptr, nullptr, nullptr};
+    int grid_cap = DW_GRID;
+    bool multi = false;              // streaming products are collected and leave as one launch (flush); the others run
+                                     // on lane 1 with the second half of the slab buffer
+    DwMulti mj;
+    DwReduceMulti mr;
+    float *buffer() const {
+        if (multi) return slab + SLAB_FLOATS;
+        if (lanes > 0) return slab + (size_t)(k % lanes) * (2 * SLAB_FLOATS / lanes);
+        return slab + (size_t)(k & 1) * SLAB_FLOATS;
+    }
+    hipStream_t lane() const {
+        if (multi) return lane_s[0];
+        const int l = k % lanes;
+        return l ? lane_s[l - 1] : main_s;
+    }
+    int flush();
     hipStream_t begin() {            // before product k's kernel: its slab buffer is free again
+        if (lanes) return lane();
         if (overlap && k >= 2) (void)hipStreamWaitEvent(main_s, ev[2 * (k - 2) + 1], 0);
         return main_s;
     }
     hipStream_t reduce_stream() {    // after product k's kernel was enqueued
+        if (lanes) return lane();
         if (!overlap) return main_s;
         (void)hipEventRecord(ev[2 * k], main_s);
         (void)hipStreamWaitEvent(side, ev[2 * k], 0);
@@ -541,6 +607,13 @@ struct DwSeq {
         ++k;
     }
     void join() {                    // the caller's stream continues behind every reduction
+        if (lanes) {
+            for (int l = 1; l < lanes; ++l) {
+                (void)hipEventRecord(ev[l], lane_s[l - 1]);
+                (void)hipStreamWaitEvent(main_s, ev[l], 0);
+            }
+            return;
+        }
         if (!overlap) return;
         for (int j = k - 2 < 0 ? 0 : k - 2; j < k; ++j) (void)hipStreamWaitEvent(main_s, ev[2 * j + 1], 0);
     }
@@ -548,6 +621,17 @@ struct DwSeq {
 
 template <int OT, int IT, int WO, int WI>
 static int launch_dw2(const DwArgs &a, const DwReduceArgs &ra, DwSeq &q) {
+    if (q.multi) {
+        static_assert((OT == 16 && IT == 16) || (OT == 8 && IT == 16) || (OT == 16 && IT == 4), "shape not in dw_multi_kernel");
+        if (q.mj.n >= DW_MAX_JOBS) return NERF_AMD_EINVAL;
+        DwJob &J = q.mj.job[q.mj.n];
+        J.a = a;
+        J.shape = OT == 16 ? (IT == 16 ? 0 : 2) : 1;
+        DwReduceArgs &r = q.mr.r[q.mj.n];
+        r = ra; r.OT = OT; r.IT = IT;
+        ++q.mj.n;
+        return NERF_AMD_OK;
+    }
     const size_t lds = 4 * 32 * (OT * 32 + IT * 32);
     static DynamicLdsOptIn opt_in;
     if (opt_in.ensure(reinterpret_cast<const void *>(dw2_kernel<OT, IT, WO, WI>), lds) != hipSuccess) return NERF_AMD_EHIP;
@@ -556,7 +640,7 @@ static int launch_dw2(const DwArgs &a, const DwReduceArgs &ra, DwSeq &q) {
     const int64_t n_chunks = (a.P + 31) / 32;
     int64_t g = n_chunks / 16;
     if (g < 1) g = 1;
-    if (g > DW_GRID) g = DW_GRID;
+    if (g > q.grid_cap) g = q.grid_cap;
     const unsigned grid = (unsigned)g;
     DwArgs a2 = a;
     a2.slab = q.buffer();
@@ -578,7 +662,7 @@ static int launch_dw(const DwArgs &a, const DwReduceArgs &ra, DwSeq &q) {
     const int64_t n_chunks = (a.P + 31) / 32;
     int64_t g = n_chunks / 16;
     if (g < 1) g = 1;
-    if (g > DW_GRID) g = DW_GRID;
+    if (g > q.grid_cap) g = q.grid_cap;
     const unsigned grid = (unsigned)g;
     DwArgs a2 = a;
     a2.slab = q.buffer();
@@ -587,6 +671,40 @@ static int launch_dw(const DwArgs &a, const DwReduceArgs &ra, DwSeq &q) {
     r.slab = a2.slab; r.n_slabs = (int)grid; r.OT = OT; r.IT = IT;
     hipLaunchKernelGGL(dw_reduce_kernel, dim3((OT * IT * 256 + OT * 16 + 63) / 64), dim3(256), 0, q.reduce_stream(), r);
     q.end();
+    return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
+}
+
+int DwSeq::flush() {
+    if (!multi || mj.n == 0) return NERF_AMD_OK;
+    const size_t lds = 4 * 32 * (16 * 32 + 16 * 32);
+    static DynamicLdsOptIn opt_in;
+    if (opt_in.ensure(reinterpret_cast<const void *>(dw_multi_kernel), lds) != hipSuccess) return NERF_AMD_EHIP;
+    // workgroups in proportion to the bytes per point of a product, DW_GRID in all (never more than a product has
+    // 8-chunk pieces); every product's slabs follow the previous product's
+    static const int OTs[3] = {16, 8, 16}, ITs[3] = {16, 16, 4};
+    const int64_t n_chunks = (mj.job[0].a.P + 31) / 32;
+    int w[DW_MAX_JOBS], total_w = 0, nb[DW_MAX_JOBS], used = 0;
+    for (int j = 0; j < mj.n; ++j) { w[j] = OTs[mj.job[j].shape] + ITs[mj.job[j].shape]; total_w += w[j]; }
+    for (int j = 0; j < mj.n; ++j) { nb[j] = DW_GRID * w[j] / total_w; if (nb[j] < 1) nb[j] = 1; used += nb[j]; }
+    for (int j = 0; used < DW_GRID; j = (j + 1) % mj.n) { ++nb[j]; ++used; }
+    const int cap = n_chunks / 8 < 1 ? 1 : (int)(n_chunks / 8 > DW_GRID ? DW_GRID : n_chunks / 8);
+    float *sl = slab;
+    int first = 0, rfirst = 0;
+    for (int j = 0; j < mj.n; ++j) {
+        if (nb[j] > cap) nb[j] = cap;
+        const int OT = OTs[mj.job[j].shape], IT = ITs[mj.job[j].shape];
+        mj.job[j].a.slab = sl;
+        mj.job[j].first_block = first; mj.job[j].n_blocks = nb[j];
+        mr.r[j].slab = sl; mr.r[j].n_slabs = nb[j];
+        mr.first_block[j] = rfirst;
+        sl += (size_t)nb[j] * (OT * IT * 256 + OT * 16);
+        first += nb[j];
+        rfirst += (OT * IT * 256 + OT * 16 + 63) / 64;
+    }
+    mr.first_block[mj.n] = rfirst;
+    mr.n = mj.n;
+    hipLaunchKernelGGL(dw_multi_kernel, dim3((unsigned)first), dim3(512), lds, main_s, mj);
+    hipLaunchKernelGGL(dw_reduce_multi_kernel, dim3((unsigned)rfirst), dim3(512), 0, main_s, mr);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
 
@@ -616,19 +734,55 @@ static int weight_grad(DwSeq &s, int64_t P, float *slab, const uint16_t *X, int 
 int train_param_grads(const Program &p, int64_t P, void *workspace, float *const *gw, float *const *gb, int device, hipStream_t stream) {
     TrainWs w;
     carve(p, P, static_cast<char *>(workspace), &w);
+    const int D = p.arch.D, W = p.arch.W, E = 32 * p.KE16, Dd = 32 * p.KD16, ic = p.input_ch, icv = p.input_ch_views;
+    if (W != 256 || (E != 64 && E != 96) || (Dd != 32 && Dd != 64)) return NERF_AMD_EUNSUPPORTED;
     DwSeq s;
     s.main_s = stream; s.slab = w.slab;
     constexpr int MAX_PRODUCTS = 24;
     // Measured: with the reductions on the side stream a 1024-ray step takes 2.78 ms instead of 2.38 -- 24 cross-stream
     // event hand-offs per model cost more than the 9-us reductions they hide.  Off; nerf_amd_set_tuning(0, 52) turns it on.
     s.overlap = g_variant == 52 && lane_acquire(device, 2 * MAX_PRODUCTS + 1, &s.side, &s.ev) == NERF_AMD_OK;
+    // Two lanes of 128 workgroups: the products of one model are independent, and one product alone cannot keep the
+    // memory system busy through its ramp, its tail and its 9-us reduction (the coarse pass even has only 128 workgroups'
+    // worth of points).  Measured at 1024 rays (ms per step, same session): one lane x 256 workgroups 2.25, two x 256 2.19,
+    // two x 128 2.08, two x 64 2.26, three x 128 2.28, three x 96 2.27, four x 128 2.50, four x 64 2.41.
+    int n_lanes = 2;
+    bool heads_first = false;        // the two head products open lane 1 instead of following the join
+    bool heads_tail = true;          // ... or close lane 1, beside lane 0's last product
+    s.grid_cap = 128;
+    bool multi = true;               // all streaming products of the model as one launch (DwSeq::flush)
+    switch (g_variant) {             // A/B
+    case 56: multi = false; break;   // two lanes x 128 workgroups, one launch per product
+    case 50: case 51: case 52: multi = false; n_lanes = 0; s.grid_cap = DW_GRID; heads_tail = false; break;   // one lane (51: this round's kernels)
+    case 53: multi = false; s.grid_cap = DW_GRID; heads_tail = false; break;
+    case 54: multi = false; heads_tail = false; break;
+    case 55: multi = false; heads_tail = false; heads_first = true; break;
+    default: break;
+    }
+    if (n_lanes > 0 && lane_acquire(device, n_lanes, &s.side, &s.ev) == NERF_AMD_OK) {
+        if (lane_streams(device, n_lanes - 1, s.lane_s) == NERF_AMD_OK) s.lanes = n_lanes;
+        else lane_release(device, s.ev);
+    }
+    if (!s.lanes) s.grid_cap = DW_GRID;
+    s.multi = multi && s.lanes == 2;
+    s.mj.n = 0;
+    if (s.multi) s.grid_cap = DW_GRID;
+    if (s.lanes) {                                     // the other lanes start behind the backward-chain kernel
+        (void)hipEventRecord(s.ev[0], stream);
+        for (int l = 1; l < s.lanes; ++l) (void)hipStreamWaitEvent(s.lane_s[l - 1], s.ev[0], 0);
+    }
     if (s.overlap) {                                   // the side stream starts behind the backward-chain kernel
         (void)hipEventRecord(s.ev[2 * MAX_PRODUCTS], stream);
         (void)hipStreamWaitEvent(s.side, s.ev[2 * MAX_PRODUCTS], 0);
     }
-    const int D = p.arch.D, W = p.arch.W, E = 32 * p.KE16, Dd = 32 * p.KD16, ic = p.input_ch, icv = p.input_ch_views;
-    if (W != 256 || (E != 64 && E != 96) || (Dd != 32 && Dd != 64)) return NERF_AMD_EUNSUPPORTED;
     const int64_t HS = pad_points(P) * 256;
+    heads_first = heads_first && s.lanes >= 2;
+    heads_tail = heads_tail && s.lanes >= 2;
+    auto heads = [&](hipStream_t hs, float *slab) {    // alpha_linear (column 3 of g_rawb) and rgb_linear (columns 0..2)
+        launch_dw_small<1>(hs, P, slab, w.g_rawb, 3, w.sv_h + (D - 1) * HS, W, gw[D + 1], gb[D + 1]);
+        launch_dw_small<3>(hs, P, slab, w.g_rawb, 0, w.sv_hv, W / 2, gw[D + 3], gb[D + 3]);
+    };
+    if (heads_first) heads(s.lane_s[0], w.slab + 2 * SLAB_FLOATS / s.lanes);   // lane 1's share of the slab, ahead of its products
     const int Lx = p.arch.multires, Ld = p.arch.multires_views;
     int rc = 0;
     for (int l = 0; l < D && !rc; ++l) {
@@ -649,12 +803,12 @@ int train_param_grads(const Program &p, int64_t P, void *workspace, float *const
     // views_linears.0: [feature | dirs]
     if (!rc) rc = weight_grad(s, P, w.slab, w.sv_feat, W, PERM_ACC, 0, W, w.g_hv, W / 2, W / 2, gw[D + 2], W + icv, 0, gb[D + 2]);
     if (!rc) rc = weight_grad(s, P, w.slab, w.sv_d, Dd, PERM_GEN, Ld, icv, w.g_hv, W / 2, W / 2, gw[D + 2], W + icv, W, nullptr);
+    if (heads_tail) heads(s.lane_s[0], w.slab + 2 * SLAB_FLOATS / s.lanes);    // behind lane 1's last reduction, same slab share
+    if (!rc) rc = s.flush();
     s.join();
-    if (s.overlap) lane_release(device, s.ev);
+    if (s.overlap || s.lanes) lane_release(device, s.ev);
     if (rc) return rc;
-    // alpha_linear (column 3 of g_rawb) and rgb_linear (columns 0..2)
-    launch_dw_small<1>(stream, P, w.slab, w.g_rawb, 3, h8, W, gw[D + 1], gb[D + 1]);
-    launch_dw_small<3>(stream, P, w.slab, w.g_rawb, 0, w.sv_hv, W / 2, gw[D + 3], gb[D + 3]);
+    if (!heads_first && !heads_tail) heads(stream, w.slab);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
 

@@ -1,6 +1,8 @@
 // capi.hip -- the extern "C" boundary declared in include/nerf_amd.h.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -593,6 +595,7 @@ constexpr int BATCH_SLOTS = 3;                   // workspaces in rotation: a gr
 // taken back under the mutex (an event can be re-recorded as soon as every wait on it has been ENQUEUED).
 struct SideLane {
     hipStream_t stream = nullptr;
+    hipStream_t more[2] = {nullptr, nullptr};      // further streams for work that splits more than two ways (lane_streams)
     std::vector<hipEvent_t> free_events;
 };
 std::mutex g_lane_mu;
@@ -612,6 +615,18 @@ int lane_acquire(int device, int n_events, hipStream_t *side, std::vector<hipEve
         if (!l.free_events.empty()) { e = l.free_events.back(); l.free_events.pop_back(); }
         else HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         events->push_back(e);
+    }
+    return NERF_AMD_OK;
+}
+int lane_streams(int device, int n, hipStream_t *out) {
+    if (device < 0 || device >= 64 || n < 1 || n > 3) return fail(NERF_AMD_EINVAL, "lane_streams: device or count out of range");
+    std::lock_guard<std::mutex> lk(g_lane_mu);
+    SideLane &l = g_lanes[device];
+    if (!l.stream) HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+    out[0] = l.stream;
+    for (int i = 1; i < n; ++i) {
+        if (!l.more[i - 1]) HIP_TRY(hipStreamCreateWithFlags(&l.more[i - 1], hipStreamNonBlocking));
+        out[i] = l.more[i - 1];
     }
     return NERF_AMD_OK;
 }
@@ -756,6 +771,21 @@ int nerf_amd_get_rays_backward(int32_t H, int32_t W, const double *K4, int64_t p
         return fail(NERF_AMD_EINVAL, "bad get_rays_backward arguments");
     int rc = launch_get_rays_bwd(H, W, K4, pix0, n, g_rays_o, g_rays_d, g_c2w, static_cast<hipStream_t>(stream));
     return rc ? fail(rc, "get_rays backward launch failed") : NERF_AMD_OK;
+}
+
+int nerf_amd_adam_step(int32_t n, float *const *params, const float *const *grads, float *const *exp_avg,
+                       float *const *exp_avg_sq, const int64_t *numel, int64_t step, double lr, double beta1,
+                       double beta2, double eps, double weight_decay, void *stream) {
+    if (n < 0 || step < 1 || (n > 0 && (!params || !grads || !exp_avg || !exp_avg_sq || !numel)))
+        return fail(NERF_AMD_EINVAL, "bad adam arguments");
+    for (int i = 0; i < n; ++i) {
+        if (numel[i] < 0 || numel[i] > 0x7fffffff) return fail(NERF_AMD_EINVAL, "adam: tensor size out of range");
+        if (numel[i] > 0 && (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i])) return fail(NERF_AMD_EINVAL, "adam: null tensor pointer");
+    }
+    const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);
+    int rc = na::launch_adam(n, params, grads, exp_avg, exp_avg_sq, numel, (float)(lr / bc1), beta1, beta2,
+                             (float)eps, (float)weight_decay, (float)std::sqrt(bc2), static_cast<hipStream_t>(stream));
+    return rc ? fail(rc, "adam launch failed") : NERF_AMD_OK;
 }
 
 int nerf_amd_to8b(const float *x, int64_t n, uint8_t *out, void *stream) {

@@ -97,6 +97,12 @@ int train_param_grads(const Program &p, int64_t P, void *workspace, float *const
 // by the weight-gradient products, whose slab reductions run beside the next product)
 int lane_acquire(int device, int n_events, hipStream_t *side, std::vector<hipEvent_t> *events);
 void lane_release(int device, const std::vector<hipEvent_t> &events);
+int lane_streams(int device, int n, hipStream_t *out);      // the device's side stream and up to two more
+
+// adam.hip
+int launch_adam(int n, float *const *params, const float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
+                const int64_t *numel, float step_size, double beta1, double beta2, float eps, float weight_decay,
+                float bc2_sqrt, hipStream_t s);
 
 // render.hip
 struct RenderCfgK {

@@ -43,52 +43,76 @@ NA_HD inline int frag_source(const FragDesc &d, int lane, int j, int n_out, int 
     return d.col_base + c;
 }
 
-__global__ __launch_bounds__(512) void pack_bf16_kernel(const FragDesc *frags, const TensorDesc *tensors,
-                                                        PtrTable weights_tab, uint16_t *stream) {
-    const float *const *weights = weights_tab.p;
-    const FragDesc d = frags[blockIdx.x];
+// Every packed copy of a model from ONE launch (a re-pack follows every optimizer step of a training loop, where six
+// small launches cost more on the host than on the GPU): block ranges select the job.
+struct PackJobs {
+    const FragDesc *frags_bwd, *frags16, *frags;
+    const TileDesc *tiles16, *tiles;
+    const LayerF32 *layers;
+    const TensorDesc *tensors;
+    uint16_t *stream_bwd, *stream_s16, *stream_bf16;
+    float *bias_s16, *bias_bf16, *stream_f32, *bias_f32;
+    int n_bwd, n16, n32, n_tiles16, n_tiles, n_layers;
+    int b_bias16, b_bias32;          // blocks of the two bias tables
+};
+constexpr int PACK_F32_BLOCKS = 32;  // per layer
+
+__device__ __forceinline__ void pack_frag(const FragDesc *frags, int n, const TensorDesc *tensors, const float *const *weights,
+                                          uint16_t *stream) {
+    const FragDesc d = frags[n];
     const int lane = threadIdx.x >> 3, j = threadIdx.x & 7;
     int row;
     const TensorDesc t = tensors[d.tensor];
     const int col = frag_source(d, lane, j, t.n_out, &row);
     const float v = col < 0 ? 0.0f : weights[d.tensor][(int64_t)row * t.n_in + col];
-    stream[(int64_t)blockIdx.x * 512 + threadIdx.x] = f32_to_bf16_rne(v);
+    stream[(int64_t)n * 512 + threadIdx.x] = f32_to_bf16_rne(v);
 }
 
-__global__ __launch_bounds__(32) void pack_bias_bf16_kernel(const TileDesc *tiles, const TensorDesc *tensors,
-                                                            PtrTable biases_tab, float *table) {
-    const float *const *biases = biases_tab.p;
-    const TileDesc t = tiles[blockIdx.x];
-    const int h = threadIdx.x >> 4, r = threadIdx.x & 15;
-    const int row = t.row0 + acc_row(r, h);
-    table[blockIdx.x * 32 + threadIdx.x] = row < tensors[t.tensor].n_out ? biases[t.tensor][row] : 0.0f;
-}
-
-__global__ __launch_bounds__(16) void pack_bias_s16_kernel(const TileDesc *tiles, const TensorDesc *tensors,
-                                                           PtrTable biases_tab, float *table) {
-    const float *const *biases = biases_tab.p;
-    const TileDesc t = tiles[blockIdx.x];
-    const int row = t.row0 + threadIdx.x;           // [q][r] with row = 4q + r is just the natural order
-    table[blockIdx.x * 16 + threadIdx.x] = row < tensors[t.tensor].n_out ? biases[t.tensor][row] : 0.0f;
-}
-
-// fp32 stream: one block per (layer, tile, group); 256 threads = 64 lanes x 4 k-pairs.
-__global__ __launch_bounds__(256) void pack_f32_kernel(const LayerF32 *layers, int n_layers,
-                                                       PtrTable weights_tab, PtrTable biases_tab,
-                                                       float *stream, float *bias_out) {
+__global__ __launch_bounds__(512) void pack_all_kernel(PackJobs J, PtrTable weights_tab, PtrTable biases_tab) {
     const float *const *weights = weights_tab.p;
     const float *const *biases = biases_tab.p;
-    const LayerF32 L = layers[blockIdx.y];
+    int b = blockIdx.x;
+    if (b < J.n_bwd) { pack_frag(J.frags_bwd, b, J.tensors, weights, J.stream_bwd); return; }
+    b -= J.n_bwd;
+    if (b < J.n16) { pack_frag(J.frags16, b, J.tensors, weights, J.stream_s16); return; }
+    b -= J.n16;
+    if (b < J.n32) { pack_frag(J.frags, b, J.tensors, weights, J.stream_bf16); return; }
+    b -= J.n32;
+    if (b < J.b_bias16) {            // [tile][16 rows], natural row order
+        const int e = b * 512 + threadIdx.x;
+        if (e < J.n_tiles16 * 16) {
+            const TileDesc t = J.tiles16[e >> 4];
+            const int row = t.row0 + (e & 15);
+            J.bias_s16[e] = row < J.tensors[t.tensor].n_out ? biases[t.tensor][row] : 0.0f;
+        }
+        return;
+    }
+    b -= J.b_bias16;
+    if (b < J.b_bias32) {            // [tile][h][r] of the 32x32x16 kernel
+        const int e = b * 512 + threadIdx.x;
+        if (e < J.n_tiles * 32) {
+            const TileDesc t = J.tiles[e >> 5];
+            const int row = t.row0 + acc_row(e & 15, (e >> 4) & 1);
+            J.bias_bf16[e] = row < J.tensors[t.tensor].n_out ? biases[t.tensor][row] : 0.0f;
+        }
+        return;
+    }
+    b -= J.b_bias32;
+    // fp32 stream: blocks of 256 values = one (tile, group) of a layer; a 512-thread block packs two at a time
+    const int layer = b / PACK_F32_BLOCKS, bx = b - layer * PACK_F32_BLOCKS;
+    if (layer >= J.n_layers) return;
+    const LayerF32 L = J.layers[layer];
     const int tiles = (L.n_out + 31) >> 5, groups = (L.n_in + 7) >> 3;
-    for (int blk = blockIdx.x; blk < tiles * groups; blk += gridDim.x) {
+    const int half = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    for (int blk = 2 * bx + half; blk < tiles * groups; blk += 2 * PACK_F32_BLOCKS) {
         const int t = blk / groups, g = blk - t * groups;
-        const int lane = threadIdx.x >> 2, i = threadIdx.x & 3;
+        const int lane = tid >> 2, i = tid & 3;
         const int row = 32 * t + (lane & 31), col = 8 * g + 2 * i + (lane >> 5);
         const float v = (row < L.n_out && col < L.n_in) ? weights[L.tensor][(int64_t)row * L.n_in + col] : 0.0f;
-        stream[L.frag_off + (int64_t)blk * 256 + threadIdx.x] = v;
+        J.stream_f32[L.frag_off + (int64_t)blk * 256 + tid] = v;
     }
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < tiles * 32; i += gridDim.x * 256)
-        bias_out[L.bias_off + i] = i < L.n_out ? biases[L.tensor][i] : 0.0f;
+    for (int i = bx * 512 + threadIdx.x; i < tiles * 32; i += PACK_F32_BLOCKS * 512)
+        J.bias_f32[L.bias_off + i] = i < L.n_out ? biases[L.tensor][i] : 0.0f;
 }
 
 int launch_pack(const Program &p, const FragDesc *d_frags, const TileDesc *d_tiles, const LayerF32 *d_layers,
@@ -96,21 +120,21 @@ int launch_pack(const Program &p, const FragDesc *d_frags, const TileDesc *d_til
                 uint16_t *stream_bf16, float *bias_bf16, float *stream_f32, float *bias_f32,
                 const FragDesc *d_frags16, const TileDesc *d_tiles16, uint16_t *stream_s16, float *bias_s16,
                 const FragDesc *d_frags_bwd, uint16_t *stream_bwd, hipStream_t s) {
-    if (p.bf16_ok && !p.frags_bwd.empty())
-        hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)p.frags_bwd.size()), dim3(512), 0, s,
-                           d_frags_bwd, d_tensors, d_w, stream_bwd);
-    if (p.bf16_ok) {
-        hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)p.frags16.size()), dim3(512), 0, s,
-                           d_frags16, d_tensors, d_w, stream_s16);
-        hipLaunchKernelGGL(pack_bias_s16_kernel, dim3((unsigned)p.tiles16.size()), dim3(16), 0, s,
-                           d_tiles16, d_tensors, d_b, bias_s16);
-        hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)p.frags.size()), dim3(512), 0, s,
-                           d_frags, d_tensors, d_w, stream_bf16);
-        hipLaunchKernelGGL(pack_bias_bf16_kernel, dim3((unsigned)p.tiles.size()), dim3(32), 0, s,
-                           d_tiles, d_tensors, d_b, bias_bf16);
-    }
-    hipLaunchKernelGGL(pack_f32_kernel, dim3(64, (unsigned)p.layers.size()), dim3(256), 0, s,
-                       d_layers, (int)p.layers.size(), d_w, d_b, stream_f32, bias_f32);
+    PackJobs J;
+    J.frags_bwd = d_frags_bwd; J.frags16 = d_frags16; J.frags = d_frags;
+    J.tiles16 = d_tiles16; J.tiles = d_tiles; J.layers = d_layers; J.tensors = d_tensors;
+    J.stream_bwd = stream_bwd; J.stream_s16 = stream_s16; J.stream_bf16 = stream_bf16;
+    J.bias_s16 = bias_s16; J.bias_bf16 = bias_bf16; J.stream_f32 = stream_f32; J.bias_f32 = bias_f32;
+    J.n_bwd = p.bf16_ok ? (int)p.frags_bwd.size() : 0;
+    J.n16 = p.bf16_ok ? (int)p.frags16.size() : 0;
+    J.n32 = p.bf16_ok ? (int)p.frags.size() : 0;
+    J.n_tiles16 = p.bf16_ok ? (int)p.tiles16.size() : 0;
+    J.n_tiles = p.bf16_ok ? (int)p.tiles.size() : 0;
+    J.n_layers = (int)p.layers.size();
+    J.b_bias16 = (J.n_tiles16 * 16 + 511) / 512;
+    J.b_bias32 = (J.n_tiles * 32 + 511) / 512;
+    const unsigned grid = (unsigned)(J.n_bwd + J.n16 + J.n32 + J.b_bias16 + J.b_bias32 + J.n_layers * PACK_F32_BLOCKS);
+    hipLaunchKernelGGL(pack_all_kernel, dim3(grid), dim3(512), 0, s, J, d_w, d_b);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
 

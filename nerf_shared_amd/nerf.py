@@ -132,16 +132,13 @@ class _FieldTrainFn(torch.autograd.Function):
                                     "taken against the wrong weights; run backward before updating the parameters")
         dev = ws.device
         g = g_raw.contiguous().float()
-        mods = model._linears()
         # one zeroed buffer for every gradient (head and ray gradients accumulate with atomics), views per tensor
-        sizes = [m.weight.numel() for m in mods] + [m.bias.numel() for m in mods]
-        flat = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
-        views = torch.split(flat, sizes)
-        n = len(mods)
-        gw = [v.view_as(m.weight) for v, m in zip(views[:n], mods)]
-        gb = list(views[n:])
-        wp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in gw])
-        bp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in gb])
+        sizes, shapes = model._grad_layout()
+        n = len(shapes)
+        flat = torch.zeros(sizes[-1], device=dev, dtype=torch.float32)
+        base = flat.data_ptr()
+        wp = (ctypes.c_void_p * n)(*[base + 4 * o for o in sizes[0:n]])
+        bp = (ctypes.c_void_p * n)(*[base + 4 * o for o in sizes[n:2 * n]])
         need_pts, need_vd, need_rays = ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
         g_pts = torch.empty(R * S, 3, device=dev, dtype=torch.float32) if (pts is not None and need_pts) else None
         g_rays6 = torch.zeros(R, 6, device=dev, dtype=torch.float32) if (rays is not None and need_rays) else None
@@ -155,9 +152,11 @@ class _FieldTrainFn(torch.autograd.Function):
         g_rays = None
         if g_rays6 is not None:           # [R, 11] = d/d(o, d, near, far, viewdir)
             g_rays = torch.cat([g_rays6, torch.zeros(R, 2, device=dev), g_vd], -1)
-        grads = []
-        for w, b in zip(gw, gb):          # parameter order of _train_params(): weight, bias per linear
-            grads += [w, b]
+        grads = []                        # parameter order of _train_params(): weight, bias per linear
+        parts = flat.split([sh[0] * sh[1] for sh in shapes] + [sh[0] for sh in shapes])
+        for i, shape in enumerate(shapes):
+            grads.append(parts[i].view(shape))
+            grads.append(parts[n + i])
         return (None, g_pts, g_vd if (pts is not None and need_vd) else None, g_rays, None, None, None) + tuple(grads)
 
 
@@ -221,6 +220,8 @@ class NeRF(nn.Module):
         # copies / pickles never share the library handle: the copy creates its own on first use
         state = self.__dict__.copy()
         state.update(_handle=None, _handle_device=None, _packed_key=None, _finalizer=None)
+        for k in ('_mods_cache', '_grad_layout_cache', '_trainable_kernels'):
+            state.pop(k, None)
         return state
 
     def __setstate__(self, state):
@@ -235,21 +236,33 @@ class NeRF(nn.Module):
     # -- device-side packed copy of the parameters --------------------------------
     def _linears(self):
         """nn.Linear modules in the C ABI's tensor order (include/nerf_amd.h)."""
-        mods = list(self.pts_linears)
-        if self.use_viewdirs:
-            mods += [self.feature_linear, self.alpha_linear, self.views_linears[0], self.rgb_linear]
-        else:
-            mods += [self.output_linear]
+        mods = self.__dict__.get('_mods_cache')
+        if mods is None:
+            mods = list(self.pts_linears)
+            if self.use_viewdirs:
+                mods += [self.feature_linear, self.alpha_linear, self.views_linears[0], self.rgb_linear]
+            else:
+                mods += [self.output_linear]
+            self.__dict__['_mods_cache'] = mods
         return mods
 
-    def _model_handle(self, device):
-        """Create the library handle on first use and re-pack when any parameter changed."""
-        mods = self._linears()
-        for m in mods:
-            for t in (m.weight, m.bias):
-                if t.device != device or t.dtype != torch.float32:
-                    raise _lib.NerfAmdError("NeRF parameters must be fp32 on %s (found %s on %s); call model.to(device)"
-                                            % (device, t.dtype, t.device))
+    def _grad_layout(self):
+        """Offsets (in floats) of every weight, then every bias, in one flat gradient buffer (+ the total), and the
+        weight shapes -- constants of the architecture."""
+        lay = self.__dict__.get('_grad_layout_cache')
+        if lay is None:
+            mods = self._linears()
+            shapes = [tuple(m.weight.shape) for m in mods]
+            offs, o = [], 0
+            for sh in shapes:
+                offs.append(o); o += sh[0] * sh[1]
+            for sh in shapes:
+                offs.append(o); o += sh[0]
+            lay = (offs + [o], shapes)
+            self.__dict__['_grad_layout_cache'] = lay
+        return lay
+
+    def _ensure_handle(self, device):
         if self._handle is None or self._handle_device != device:
             if self._finalizer is not None:
                 self._finalizer()
@@ -261,13 +274,24 @@ class NeRF(nn.Module):
                            "nerf_amd_model_create")
             self._handle, self._handle_device, self._packed_key = h, device, None
             self._finalizer = weakref.finalize(self, _destroy_handle, h)
-        ws = [m.weight.detach().contiguous() for m in mods]
-        bs = [m.bias.detach().contiguous() for m in mods]
-        key = tuple((t.data_ptr(), t._version) for t in ws + bs)
+            self.__dict__['_trainable_kernels'] = bool(lib.nerf_amd_model_supports_training(h))
+        return self._handle
+
+    def _model_handle(self, device):
+        """Create the library handle on first use and re-pack when any parameter changed."""
+        self._ensure_handle(device)
+        # (data_ptr, _version) of every parameter: unchanged = same storage, same contents, hence same device and dtype
+        params = [m._parameters[k] for k in ('weight', 'bias') for m in self._linears()]
+        key = tuple([t.data_ptr() for t in params] + [t._version for t in params])
         if key != self._packed_key:
-            n = len(mods)
-            wp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in ws])
-            bp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in bs])
+            for t in params:
+                if t.device != device or t.dtype != torch.float32:
+                    raise _lib.NerfAmdError("NeRF parameters must be fp32 on %s (found %s on %s); call model.to(device)"
+                                            % (device, t.dtype, t.device))
+            n = len(params) // 2
+            live = [t.detach().contiguous() for t in params]       # parameters are contiguous unless someone made them not
+            wp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in live[:n]])
+            bp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in live[n:]])
             with torch.cuda.device(device):
                 _lib.check(lib.nerf_amd_model_update(self._handle, wp, bp, n, _lib.stream_of(device)),
                            "nerf_amd_model_update")
@@ -277,7 +301,8 @@ class NeRF(nn.Module):
     def _train_params(self):
         out = []
         for m in self._linears():
-            out += [m.weight, m.bias]
+            p = m._parameters
+            out += [p['weight'], p['bias']]
         return out
 
     def _wants_grad(self, device, *inputs):
@@ -290,7 +315,8 @@ class NeRF(nn.Module):
                                                or any(t is not None and t.requires_grad for t in inputs)):
             return False
         prec = self.precision or _default_precision
-        if prec != "bf16" or not lib.nerf_amd_model_supports_training(self._model_handle(device)):
+        self._ensure_handle(device)
+        if prec != "bf16" or not self.__dict__['_trainable_kernels']:
             raise _lib.NerfAmdError(
                 "gradients were requested (grad mode is on and a parameter or input requires grad) but the HIP "
                 "training kernels cover NeRF(D=8, W=256, skips=[4], use_viewdirs=True) with multires/multires_views "

@@ -461,7 +461,6 @@ class Renderer(torch.nn.Module):
         self._check_model(coarse_model, "coarse_model")
         N, dev = rays.shape[0], rays.device
         out_ch = 4 if coarse_model.use_viewdirs else coarse_model.output_ch
-        full = self._alloc_outputs(N, dev, out_ch, retraw, False)
         starts = list(range(0, N, chunk))
         if N > 0 and (coarse_model._wants_grad(dev, rays_flat) or (fine_model is not None and self.N_importance > 0
                                                                  and fine_model._wants_grad(dev, rays_flat))):
@@ -471,7 +470,9 @@ class Renderer(torch.nn.Module):
                 r = self.render_rays(live[i:i + chunk], coarse_model, fine_model, retraw)
                 for k, v in r.items():
                     parts.setdefault(k, []).append(v)
-            return {k: torch.cat(v, 0) for k, v in parts.items()}
+            # (one chunk: the reference's torch.cat of a single tensor is a copy of it)
+            return {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in parts.items()}
+        full = self._alloc_outputs(N, dev, out_ch, retraw, False)
         if self.pipeline_batch and N > 0 and (len(starts) > 1 or N > 49152):
             self._launch_batch(rays, starts, chunk, coarse_model, fine_model, full)
             return full

@@ -231,14 +231,16 @@ def get_renderer(args, bds_dict):
 
 # ---------------------------------------------------------------- optimizer + checkpoints (utils.py:163-214, 444-456)
 def get_optimizer(coarse_model, fine_model, args):
-    """Adam over both models' parameters, lr = args.lrate (utils.py:163-172).  With the parameters on
-    the GPU the single-kernel ("fused") implementation of torch.optim.Adam is used: the step is host-bound
-    otherwise (48 small tensors; 2.5 vs 3.3 ms per 1024-ray training step)."""
+    """Adam over both models' parameters, lr = args.lrate (utils.py:163-172).  With the parameters on the GPU this is
+    `nerf_shared_amd.optim.Adam`: a torch.optim.Adam (same state, same checkpoints) whose step is one kernel launch for
+    all 48 tensors -- the 1024-ray training step is host-bound otherwise.  CPU parameters get the plain torch optimizer."""
     params = list(coarse_model.parameters())
     if fine_model is not None:
         params += list(fine_model.parameters())
-    fused = len(params) > 0 and all(p.is_cuda for p in params)
-    return torch.optim.Adam(params=params, lr=args.lrate, betas=(0.9, 0.999), fused=fused)
+    if len(params) > 0 and all(p.is_cuda for p in params):
+        from . import optim
+        return optim.Adam(params=params, lr=args.lrate, betas=(0.9, 0.999))
+    return torch.optim.Adam(params=params, lr=args.lrate, betas=(0.9, 0.999))
 
 
 def save_checkpoints(args, coarse_model, fine_model, optimizer, global_step, i):

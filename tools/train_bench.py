@@ -25,8 +25,10 @@ def main():
     ap.add_argument("--rays", type=int, default=1024)      # N_rand of configs/lego.txt:15
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--adam", choices=["foreach", "fused"], default="fused", help="torch.optim.Adam implementation")
+    ap.add_argument("--adam", choices=["foreach", "fused", "amd"], default="amd",
+                    help="amd: nerf_shared_amd.optim.Adam (what utils.get_optimizer returns); foreach / fused: torch.optim.Adam")
     ap.add_argument("--tuning", type=int, default=0, help="nerf_amd_set_tuning(0, value): 50 = round-1 weight-gradient kernel")
+    ap.add_argument("--cprofile", action="store_true", help="print the host-side profile of the timed steps (cProfile)")
     args = ap.parse_args()
     from nerf_shared_amd import _lib
     _lib.check(_lib.lib.nerf_amd_set_tuning(0, args.tuning), "set_tuning")
@@ -38,8 +40,12 @@ def main():
         models.append(m.to(dev))
     r = render_utils.Renderer(perturb=1.0, N_importance=128, N_samples=64, use_viewdirs=True, white_bkgd=True,
                               raw_noise_std=0.0, near=2.0, far=6.0)
-    opt = torch.optim.Adam(list(models[0].parameters()) + list(models[1].parameters()), lr=5e-4, betas=(0.9, 0.999),
-                           fused=args.adam == "fused")
+    params = list(models[0].parameters()) + list(models[1].parameters())
+    if args.adam == "amd":
+        from nerf_shared_amd import optim
+        opt = optim.Adam(params, lr=5e-4, betas=(0.9, 0.999))
+    else:
+        opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.999), fused=args.adam == "fused")
     rng = np.random.default_rng(0)
     K = synth.lego_intrinsics(400, 400)
     idx = rng.choice(160000, size=args.rays, replace=False)
@@ -58,13 +64,26 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    if args.cprofile:
+        import cProfile
+        import pstats
+        prof = cProfile.Profile()
+        prof.enable()
+        for _ in range(args.steps):
+            step()
+        prof.disable()
+        torch.cuda.synchronize()
+        pstats.Stats(prof).sort_stats("cumulative").print_stats(45)
+        pstats.Stats(prof).sort_stats("tottime").print_stats(30)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    host = (time.perf_counter() - t0) / args.steps        # time to ENQUEUE a step: close to ms_per_step = host-bound
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     pts = args.rays * 256
     print(json.dumps({"rays_per_step": args.rays, "ms_per_step": dt * 1e3, "steps_per_s": 1 / dt,
+                      "host_enqueue_ms_per_step": host * 1e3,
                       "rays_per_s": args.rays / dt, "loss": float(loss), "adam": args.adam,
                       "model_tflops": pts * 1186816 * 3 / dt / 1e12}))
 
