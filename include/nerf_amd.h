@@ -292,6 +292,19 @@ int nerf_amd_get_rays_backward(int32_t H, int32_t W, const double *K4, int64_t p
  * x [n] fp32 DEVICE (16-byte aligned), out [n] uint8 DEVICE (4-byte aligned). */
 int nerf_amd_to8b(const float *x, int64_t n, uint8_t *out, void *stream);
 
+/* utils.img2mse (utils.py:24; the loss of main.py:93-98): out[0] = mean((x - y)^2) over n fp32 DEVICE values.
+ * One launch for n <= 16384 (a training batch); beyond that `partials` (256 floats, DEVICE) is required and a second
+ * tiny launch sums the per-block partials in a fixed order.  _backward: gx = g[0] * 2 (x - y) / n, gy = -gx (either may
+ * be NULL), g = the DEVICE scalar gradient of the loss. */
+int nerf_amd_img2mse(const float *x, const float *y, int64_t n, float *out, float *partials, void *stream);
+int nerf_amd_img2mse_backward(const float *x, const float *y, int64_t n, const float *g, float *gx, float *gy, void *stream);
+
+/* Renderer.render(rays=...) batch assembly (render_utils.py:205-222) in one launch: out[i] = [rays_o[i] | rays_d[i] |
+ * near | far | viewdir_src[i] / |viewdir_src[i]|]; viewdir_src NULL -> 8 columns, else 11.  All [n, 3] fp32 DEVICE,
+ * contiguous.  (The c2w path has nerf_amd_make_rays.) */
+int nerf_amd_assemble_rays(const float *rays_o, const float *rays_d, const float *viewdir_src, int64_t n, float near,
+                           float far, float *out, void *stream);
+
 /* Optimizer step of the training loop (main.py:104 on the torch.optim.Adam of utils.py:163-172): Adam for
  * n parameter tensors in one launch.  params / grads / exp_avg / exp_avg_sq: HOST arrays of n DEVICE pointers
  * to fp32 tensors of numel[i] elements (4-byte aligned; any n).  Per element, in fp32 and in the order of

@@ -773,6 +773,25 @@ int nerf_amd_get_rays_backward(int32_t H, int32_t W, const double *K4, int64_t p
     return rc ? fail(rc, "get_rays backward launch failed") : NERF_AMD_OK;
 }
 
+int nerf_amd_img2mse(const float *x, const float *y, int64_t n, float *out, float *partials, void *stream) {
+    if (n < 1 || !x || !y || !out) return fail(NERF_AMD_EINVAL, "bad img2mse arguments");
+    int rc = na::launch_img2mse(x, y, n, out, partials, static_cast<hipStream_t>(stream));
+    return rc ? fail(rc, rc == NERF_AMD_EINVAL ? "img2mse: n > 16384 needs the partials buffer" : "img2mse launch failed") : NERF_AMD_OK;
+}
+
+int nerf_amd_img2mse_backward(const float *x, const float *y, int64_t n, const float *g, float *gx, float *gy, void *stream) {
+    if (n < 1 || !x || !y || !g) return fail(NERF_AMD_EINVAL, "bad img2mse_backward arguments");
+    int rc = na::launch_img2mse_bwd(x, y, n, g, gx, gy, static_cast<hipStream_t>(stream));
+    return rc ? fail(rc, "img2mse_backward launch failed") : NERF_AMD_OK;
+}
+
+int nerf_amd_assemble_rays(const float *rays_o, const float *rays_d, const float *viewdir_src, int64_t n, float near,
+                           float far, float *out, void *stream) {
+    if (n < 0 || (n > 0 && (!rays_o || !rays_d || !out))) return fail(NERF_AMD_EINVAL, "bad assemble_rays arguments");
+    int rc = na::launch_assemble_rays(rays_o, rays_d, viewdir_src, n, near, far, out, static_cast<hipStream_t>(stream));
+    return rc ? fail(rc, "assemble_rays launch failed") : NERF_AMD_OK;
+}
+
 int nerf_amd_adam_step(int32_t n, float *const *params, const float *const *grads, float *const *exp_avg,
                        float *const *exp_avg_sq, const int64_t *numel, int64_t step, double lr, double beta1,
                        double beta2, double eps, double weight_decay, void *stream) {

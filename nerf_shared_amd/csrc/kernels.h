@@ -99,6 +99,10 @@ int lane_acquire(int device, int n_events, hipStream_t *side, std::vector<hipEve
 void lane_release(int device, const std::vector<hipEvent_t> &events);
 int lane_streams(int device, int n, hipStream_t *out);      // the device's side stream and up to two more
 
+int launch_img2mse(const float *x, const float *y, int64_t n, float *out, float *partials, hipStream_t s);
+int launch_img2mse_bwd(const float *x, const float *y, int64_t n, const float *g, float *gx, float *gy, hipStream_t s);
+int launch_assemble_rays(const float *o, const float *d, const float *v, int64_t n, float near, float far, float *out, hipStream_t s);
+
 // adam.hip
 int launch_adam(int n, float *const *params, const float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
                 const int64_t *numel, float step_size, double beta1, double beta2, float eps, float weight_decay,

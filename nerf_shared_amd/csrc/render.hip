@@ -763,6 +763,101 @@ int launch_to8b(const float *x, int64_t n, uint8_t *out, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
 
+// ---- utils.img2mse (utils.py:24): mean((x - y)^2) and its gradient, one launch each --------------------------------
+constexpr int MSE_BLOCK = 1024, MSE_PER_BLOCK = 16384, MSE_MAX_BLOCKS = 256;
+
+__device__ __forceinline__ float block_sum_1024(float v, float *part /* [16] LDS */) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < MSE_BLOCK / 64; ++k) t += part[k];
+    return t;                        // valid in thread 0
+}
+
+__global__ __launch_bounds__(MSE_BLOCK) void img2mse_kernel(const float *x, const float *y, int64_t n, float *out, float *partials) {
+    __shared__ float part[MSE_BLOCK / 64];
+    float acc = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * MSE_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * MSE_BLOCK + threadIdx.x; i < n; i += stride) {
+        const float d = x[i] - y[i];
+        acc += d * d;
+    }
+    const float t = block_sum_1024(acc, part);
+    if (threadIdx.x == 0) {
+        if (gridDim.x == 1) out[0] = t / (float)n;
+        else partials[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(MSE_MAX_BLOCKS) void img2mse_finish_kernel(const float *partials, int n_parts, int64_t n, float *out) {
+    __shared__ float part[MSE_MAX_BLOCKS];
+    part[threadIdx.x] = (int)threadIdx.x < n_parts ? partials[threadIdx.x] : 0.f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int k = 0; k < n_parts; ++k) t += part[k];        // fixed order: the result does not depend on scheduling
+        out[0] = t / (float)n;
+    }
+}
+
+__global__ __launch_bounds__(256) void img2mse_bwd_kernel(const float *x, const float *y, int64_t n, const float *g, float *gx, float *gy) {
+    const float s = g[0] * (2.0f / (float)n);
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float v = s * (x[i] - y[i]);
+        if (gx) gx[i] = v;
+        if (gy) gy[i] = -v;
+    }
+}
+
+int launch_img2mse(const float *x, const float *y, int64_t n, float *out, float *partials, hipStream_t s) {
+    int64_t blocks = (n + MSE_PER_BLOCK - 1) / MSE_PER_BLOCK;
+    if (blocks < 1) blocks = 1;
+    if (blocks > MSE_MAX_BLOCKS) blocks = MSE_MAX_BLOCKS;
+    if (blocks > 1 && !partials) return NERF_AMD_EINVAL;
+    hipLaunchKernelGGL(img2mse_kernel, dim3((unsigned)blocks), dim3(MSE_BLOCK), 0, s, x, y, n, out, partials);
+    if (blocks > 1) hipLaunchKernelGGL(img2mse_finish_kernel, dim3(1), dim3(MSE_MAX_BLOCKS), 0, s, partials, (int)blocks, n, out);
+    return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
+}
+
+int launch_img2mse_bwd(const float *x, const float *y, int64_t n, const float *g, float *gx, float *gy, hipStream_t s) {
+    if (n <= 0) return NERF_AMD_OK;
+    int64_t blocks = (n + 1023) / 1024;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(img2mse_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, y, n, g, gx, gy);
+    return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
+}
+
+// ---- Renderer.render(rays=...) batch assembly (render_utils.py:205-222): [o | d | near | far | v / |v|] per ray ------
+__global__ __launch_bounds__(256) void assemble_rays_kernel(const float *o, const float *d, const float *v, int64_t n, float near,
+                                                            float far, float *out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int ch = v ? 11 : 8;
+    float *r = out + i * ch;
+    r[0] = o[3 * i]; r[1] = o[3 * i + 1]; r[2] = o[3 * i + 2];
+    r[3] = d[3 * i]; r[4] = d[3 * i + 1]; r[5] = d[3 * i + 2];
+    r[6] = near; r[7] = far;
+    if (v) {
+        const float x = v[3 * i], y = v[3 * i + 1], z = v[3 * i + 2];
+        // torch.norm(v, dim=-1) of a 3-vector on this build (torch 2.10 / ROCm 7): the squares are rounded on their own and the
+        // reduction tree pairs elements 0 and 2 first -- sqrt((x^2 + z^2) + y^2), measured bit for bit on 1e5 vectors
+        // (tools/micro/norm_probe.py); sqrt and the division are correctly rounded (this file is built without contraction)
+        const float nrm = sqrtf((x * x + z * z) + y * y);
+        r[8] = x / nrm; r[9] = y / nrm; r[10] = z / nrm;
+    }
+}
+
+int launch_assemble_rays(const float *o, const float *d, const float *v, int64_t n, float near, float far, float *out, hipStream_t s) {
+    if (n <= 0) return NERF_AMD_OK;
+    hipLaunchKernelGGL(assemble_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, o, d, v, n, near, far, out);
+    return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
+}
+
 int launch_make_rays(int H, int W, const double *K4, const float *c2w, const float *c2w_static,
                      int64_t pix0, int64_t n, float near, float far, int use_viewdirs, int ndc,
                      float *rays_out, hipStream_t s) {

@@ -521,22 +521,38 @@ class Renderer(torch.nn.Module):
         else:
             rays_o, rays_d = rays
             _lib.require_device(rays_d, "rays")
-            viewdirs = None
-            if self.use_viewdirs:
-                viewdirs = rays_d
-                if c2w_staticcam is not None:
-                    rays_o, rays_d = utils.get_rays(H, W, K, c2w_staticcam)
-                viewdirs = viewdirs / torch.norm(viewdirs, dim=-1, keepdim=True)
-                viewdirs = torch.reshape(viewdirs, [-1, 3]).float()
             sh = rays_d.shape
-            if self.ndc:
-                rays_o, rays_d = utils.ndc_rays(H, W, K[0][0], 1., rays_o, rays_d)
-            rays_o = torch.reshape(rays_o, [-1, 3]).float()
-            rays_d = torch.reshape(rays_d, [-1, 3]).float()
-            near, far = self.near * torch.ones_like(rays_d[..., :1]), self.far * torch.ones_like(rays_d[..., :1])
-            batch = torch.cat([rays_o, rays_d, near, far], -1)
-            if self.use_viewdirs:
-                batch = torch.cat([batch, viewdirs], -1)
+            tracked = torch.is_grad_enabled() and (rays_o.requires_grad or rays_d.requires_grad)
+            if (not tracked and c2w_staticcam is None and rays_o.dtype == torch.float32 and rays_d.dtype == torch.float32
+                    and rays_o.is_cuda and rays_o.shape == rays_d.shape and rays_d.numel() > 0):
+                # no gradient flows into the rays: the ten small launches below as one (nerf_amd_assemble_rays)
+                src = rays_d.detach().reshape(-1, 3).contiguous() if self.use_viewdirs else None
+                o, d = rays_o.detach(), rays_d.detach()
+                if self.ndc:
+                    o, d = utils.ndc_rays(H, W, K[0][0], 1., o, d)
+                o, d = o.reshape(-1, 3).contiguous(), d.reshape(-1, 3).contiguous()
+                batch = torch.empty(o.shape[0], 11 if self.use_viewdirs else 8, device=o.device, dtype=torch.float32)
+                with torch.cuda.device(o.device):
+                    _lib.check(lib.nerf_amd_assemble_rays(o.data_ptr(), d.data_ptr(), _lib.ptr(src), o.shape[0], float(self.near),
+                                                          float(self.far), batch.data_ptr(), _lib.stream_of(o.device)),
+                               "nerf_amd_assemble_rays")
+            else:
+                viewdirs = None
+                if self.use_viewdirs:
+                    viewdirs = rays_d
+                    if c2w_staticcam is not None:
+                        rays_o, rays_d = utils.get_rays(H, W, K, c2w_staticcam)
+                    viewdirs = viewdirs / torch.norm(viewdirs, dim=-1, keepdim=True)
+                    viewdirs = torch.reshape(viewdirs, [-1, 3]).float()
+                sh = rays_d.shape
+                if self.ndc:
+                    rays_o, rays_d = utils.ndc_rays(H, W, K[0][0], 1., rays_o, rays_d)
+                rays_o = torch.reshape(rays_o, [-1, 3]).float()
+                rays_d = torch.reshape(rays_d, [-1, 3]).float()
+                near, far = self.near * torch.ones_like(rays_d[..., :1]), self.far * torch.ones_like(rays_d[..., :1])
+                batch = torch.cat([rays_o, rays_d, near, far], -1)
+                if self.use_viewdirs:
+                    batch = torch.cat([batch, viewdirs], -1)
 
         all_ret = self.render_batch(coarse_model, fine_model, batch, chunk, retraw)
         for k in all_ret:

@@ -129,3 +129,59 @@ def test_get_optimizer_returns_the_library_adam_and_models_repack(dev):
     with torch.no_grad():
         after = c(pts, vd)
     assert torch.equal(before, out0.detach()) and not torch.equal(before, after)
+
+
+# ---- the other small pieces of the training loop that run as one launch each ------------------------------------------
+@pytest.mark.parametrize("n", [1, 3072, 16384, 16385, 1_920_000])
+def test_img2mse_matches_the_reference_expression(dev, n):
+    """utils.img2mse (utils.py:24) through the library: value within fp32 summation error of torch.mean((x - y) ** 2)
+    (fp64 referee), gradients equal to autograd's on the expression to round-off; both launch shapes (one block / partials)."""
+    from nerf_shared_amd import utils
+    g = torch.Generator().manual_seed(n)
+    x = torch.rand(n, generator=g).to(dev).requires_grad_(True)
+    y = torch.rand(n, generator=g).to(dev).requires_grad_(True)
+    ours = utils.img2mse(x, y)
+    (3.0 * ours).backward()
+    gx, gy = x.grad.clone(), y.grad.clone()
+    x.grad = y.grad = None
+    ref = torch.mean((x - y) ** 2)
+    (3.0 * ref).backward()
+    exact = float(((x.detach().double() - y.detach().double()) ** 2).mean())
+    assert abs(float(ours) - exact) <= 2e-6 * exact + 1e-12, (float(ours), exact)
+    assert abs(float(ours) - exact) <= abs(float(ref) - exact) + 1e-6 * exact         # no worse than torch's own reduction
+    assert torch.allclose(gx, x.grad, rtol=1e-6, atol=1e-12) and torch.allclose(gy, y.grad, rtol=1e-6, atol=1e-12)
+    # shapes as the loop uses them, and the fall-through for what the kernel does not take
+    a, b = torch.rand(64, 3, device=dev), torch.rand(64, 3, device=dev)
+    assert float(utils.img2mse(a, b)) == pytest.approx(float(torch.mean((a - b) ** 2)), rel=1e-6)
+    assert float(utils.img2mse(a, b[:1])) == pytest.approx(float(torch.mean((a - b[:1]) ** 2)), rel=1e-6)   # broadcasting
+
+
+@pytest.mark.parametrize("use_viewdirs,ndc", [(True, False), (False, False), (True, True)])
+def test_render_rays_argument_batch_assembly(dev, use_viewdirs, ndc):
+    """Renderer.render(rays=...) assembles its [N, 8|11] batch in one launch when no gradient flows into the rays; the
+    reference's expression (render_utils.py:205-222: normalise, reshape, ones_like * near/far, two cats) is what runs when
+    one does.  Same batch bit for bit, unit view directions included (the kernel follows torch.norm's operation order on
+    this build, tools/micro/norm_probe.py)."""
+    from nerf_shared_amd import render_utils
+    captured = []
+
+    class Probe(render_utils.Renderer):
+        def render_batch(self, coarse_model, fine_model, rays_flat, chunk=1024 * 32, retraw=False):
+            captured.append(rays_flat.detach().clone())
+            n = rays_flat.shape[0]
+            z = torch.zeros(n, device=rays_flat.device)
+            return {"rgb_map": torch.zeros(n, 3, device=rays_flat.device), "disp_map": z, "acc_map": z}
+
+    r = Probe(use_viewdirs=use_viewdirs, ndc=ndc, near=2.0 if not ndc else 0.0, far=6.0 if not ndc else 1.0)
+    g = torch.Generator().manual_seed(3)
+    H, W = 13, 17
+    o = (torch.randn(H, W, 3, generator=g) * 2).to(dev)
+    d = torch.randn(H, W, 3, generator=g).to(dev)
+    d[..., 2] = -d[..., 2].abs() - 0.5
+    K = [[20.0, 0, W / 2], [0, 20.0, H / 2], [0, 0, 1]]
+    r.render(H, W, K, None, None, rays=(o, d))
+    d_tracked = d.clone().requires_grad_(True)
+    r.render(H, W, K, None, None, rays=(o, d_tracked))
+    fused, ref = captured
+    assert fused.shape == ref.shape == (H * W, 11 if use_viewdirs else 8)
+    assert torch.equal(fused, ref)

@@ -15,7 +15,7 @@ os.environ.setdefault("NERF_AMD_QUIET", "1")
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from nerf_shared_amd import nerf, render_utils, synth  # noqa: E402
+from nerf_shared_amd import nerf, render_utils, synth, utils  # noqa: E402
 
 ARCH = dict(D=8, W=256, output_ch=5, skips=[4], use_viewdirs=True, multires=10, multires_views=4)
 
@@ -56,7 +56,7 @@ def main():
     def step():
         opt.zero_grad(set_to_none=True)
         rgb, disp, acc, extras = r.render(400, 400, K, models[0], models[1], chunk=32768, rays=rays, retraw=True)
-        loss = ((rgb - target) ** 2).mean() + ((extras["rgb0"] - target) ** 2).mean()
+        loss = utils.img2mse(rgb, target) + utils.img2mse(extras["rgb0"], target)       # main.py:93-98
         loss.backward()
         opt.step()
         return loss
