@@ -59,7 +59,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char *img, int row_stride, int c
 
 // OT / IT: 16-wide tiles of the output / input feature axis; the 8 waves form a WO x WI grid.
 template <int OT, int IT, int WO, int WI>
-__global__ __launch_bounds__(512) void dw_kernel(DwArgs a) {
+__device__ __forceinline__ void dw_body(const DwArgs &a, const int wg, const int nwg) {
     static_assert(WO * WI == 8 && OT % WO == 0 && IT % WI == 0, "bad wave grid");
     constexpr int TO = OT / WO, TI = IT / WI;
     constexpr int RSG = OT * 32 + 32, RSX = IT * 32 + 32;          // padded LDS row strides (bytes)
@@ -100,9 +100,9 @@ __global__ __launch_bounds__(512) void dw_kernel(DwArgs a) {
         }
     };
     int buf = 0;
-    int64_t c = blockIdx.x;
+    int64_t c = wg;
     if (c < n_chunks) load_chunk(c);
-    for (; c < n_chunks; c += gridDim.x) {
+    for (; c < n_chunks; c += nwg) {
         char *gimg = smem + buf * BUF, *ximg = gimg + 32 * RSG;
 #pragma unroll
         for (int k = 0; k < NPG; ++k) {
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(512) void dw_kernel(DwArgs a) {
             if (pc < 32 * PX) *reinterpret_cast<u32x4 *>(ximg + row * RSX + col * 16) = rx[k];
         }
         __syncthreads();
-        if (c + gridDim.x < n_chunks) load_chunk(c + gridDim.x);     // next chunk's loads fly under the MFMAs
+        if (c + nwg < n_chunks) load_chunk(c + nwg);     // next chunk's loads fly under the MFMAs
         bf16x8 A[TO], B[TI];
 #pragma unroll
         for (int x = 0; x < TO; ++x) A[x] = tr_frag(gimg, RSG, (wo * TO + x) * 16, lane);
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(512) void dw_kernel(DwArgs a) {
     }
     // ---- this workgroup's partial tile, as a register dump (1 KiB per 16x16 tile, fully coalesced);
     //      dw_reduce_kernel sums the dumps of all workgroups and un-permutes the slot order
-    float *slab = a.slab + (int64_t)blockIdx.x * (OT * IT * 256 + OT * 16);
+    float *slab = a.slab + (int64_t)wg * (OT * IT * 256 + OT * 16);
 #pragma unroll
     for (int x = 0; x < TO; ++x)
 #pragma unroll
@@ -157,6 +157,11 @@ __global__ __launch_bounds__(512) void dw_kernel(DwArgs a) {
     }
     __syncthreads();
     for (int i = tid; i < OT * 16; i += 512) slab[OT * IT * 256 + i] = red[i];
+}
+
+template <int OT, int IT, int WO, int WI>
+__global__ __launch_bounds__(512) void dw_kernel(DwArgs a) {
+    dw_body<OT, IT, WO, WI>(a, blockIdx.x, gridDim.x);
 }
 
 // dW[feature(o_slot)][col_off + feature(i_slot)] = sum over workgroups of their register dumps.
@@ -206,9 +211,17 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(DwReduceArgs a) {
 // bytes all start at bank 0, so the eight rows need eight different piece pairs: XOR with 0, 2, .., 14.  Rows of 128 bytes
 // (PIECES == 8) alternate between the two halves of the banks, so the four even rows {0, 2, 8, 10} (and the four odd ones)
 // need four different pairs: XOR with 0, 2, 4, 6.  Both forms satisfy swz(r + 4) == swz(r).
+constexpr int DW2_NS(int OT, int IT) {
+    const int n = (128 * 1024) / (32 * 32 * (OT + IT));
+    return n < 4 ? 4 : (n > 12 ? 12 : n);
+}
+
 template <int PIECES>
 __device__ __forceinline__ int dw_swz(int r) {
-    static_assert(PIECES == 8 || (PIECES >= 16 && (PIECES & (PIECES - 1)) == 0), "unsupported row width");
+    static_assert(PIECES == 4 || PIECES == 8 || (PIECES >= 16 && (PIECES & (PIECES - 1)) == 0), "unsupported row width");
+    // 64-byte rows (PIECES == 4): four rows span the banks once, so rows {0..3} never collide and rows {8..11} take the
+    // other piece pair
+    if (PIECES == 4) return 2 * ((r >> 3) & 1);
     if (PIECES == 8) return 2 * (((r >> 1) & 1) | (((r >> 3) & 1) << 1));
     return 2 * ((r & 3) | (((r >> 3) & 1) << 2));
 }
@@ -278,13 +291,16 @@ __global__ __launch_bounds__(512) void dw_reduce8_kernel(DwReduceArgs a) {
 
 template <int OT, int IT, int WO, int WI>
 __device__ __forceinline__ void dw2_body(const DwArgs &a, const int wg, const int nwg) {
-    static_assert(WO * WI == 8 && OT % WO == 0 && IT % WI == 0 && OT >= 4 && IT >= 4, "bad shape");
+    static_assert(WO * WI == 8 && OT % WO == 0 && IT % WI == 0 && OT >= 4 && IT >= 2, "bad shape");
     constexpr int TO = OT / WO, TI = IT / WI;
     constexpr int RG = OT * 32, RX = IT * 32;                   // row bytes (unpadded)
     constexpr int PG = OT * 2, PX = IT * 2;                     // 16-byte pieces per row
     constexpr int IMG = 32 * (RG + RX);                         // one chunk's image
-    constexpr int NS = 4;                                       // ring slots
     constexpr int NI = OT + IT, CNT = (NI + 7) / 8;             // 1-KiB DMA instructions per chunk; per wave (the last ones may repeat)
+    // ring slots: what fits in 128 KiB, at least 4 and at most 12 -- a narrow product keeps as many BYTES in flight as a
+    // wide one (a workgroup's rate is bytes in flight / latency, and the one-launch path shares the CUs by bytes)
+    constexpr int NS = DW2_NS(OT, IT);
+    static_assert((NS - 2) * CNT <= 63, "vmcnt field is 6 bits");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -329,12 +345,13 @@ __device__ __forceinline__ void dw2_body(const DwArgs &a, const int wg, const in
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
 
     if (n_local > 0) {
-        issue_chunk(0); issue_chunk(1); issue_chunk(2);
+#pragma unroll
+        for (int i = 0; i < NS - 1; ++i) issue_chunk(i);
         for (int64_t i = 0; i < n_local; ++i) {
             // chunk i has landed (this wave's pieces; chunks i+1, i+2 stay in flight), everyone agrees, then the slot of
             // chunk i-1 -- which every wave finished reading before it came here -- is refilled with chunk i+3
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * CNT) : "memory");
-            issue_chunk(i + 3);
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * CNT) : "memory");
+            issue_chunk(i + NS - 1);
             const uint32_t gimg = ring + (uint32_t)(i % NS) * IMG, ximg = gimg + 32 * RG;
             const int64_t ch = wg + i * nwg;
             if (ch == n_chunks - 1 && (a.P & 31)) {             // the last chunk: rows past P hold the padding points' data
@@ -380,57 +397,15 @@ __global__ __launch_bounds__(512, 2) void dw2_kernel(DwArgs a) {
     dw2_body<OT, IT, WO, WI>(a, blockIdx.x, gridDim.x);
 }
 
-// Every streaming product of one model's backward pass in ONE launch, and their reductions in a second one: a job owns a
-// range of workgroups sized to its bytes per point, 256 workgroups in all -- one per CU from the first chunk to the last, all
-// products in flight together (no ramp and tail per product, ~23 slabs per product to reduce instead of 128-256, and 2
-// launches per model instead of 22 on a step that is host-bound at the reference's batch size).
-constexpr int DW_MAX_JOBS = 16;
-struct DwJob {
-    DwArgs a;
-    int shape;                           // 0: <16,16,4,2>  1: <8,16,4,2>  2: <16,4,8,1>
-    int first_block, n_blocks;
-};
-struct DwMulti {
-    DwJob job[DW_MAX_JOBS];
-    int n;
-};
-struct DwReduceMulti {
-    DwReduceArgs r[DW_MAX_JOBS];
-    int first_block[DW_MAX_JOBS + 1];
-    int n;
-};
-
-__global__ __launch_bounds__(512, 2) void dw_multi_kernel(DwMulti m) {
-    int j = 0;
-    while (j + 1 < m.n && (int)blockIdx.x >= m.job[j + 1].first_block) ++j;
-    j = __builtin_amdgcn_readfirstlane(j);
-    const DwJob &J = m.job[j];
-    const int wg = (int)blockIdx.x - J.first_block;
-    switch (J.shape) {
-    case 0: dw2_body<16, 16, 4, 2>(J.a, wg, J.n_blocks); break;
-    case 1: dw2_body<8, 16, 4, 2>(J.a, wg, J.n_blocks); break;
-    default: dw2_body<16, 4, 8, 1>(J.a, wg, J.n_blocks); break;
-    }
-}
-
-__global__ __launch_bounds__(512) void dw_reduce_multi_kernel(DwReduceMulti m) {
-    __shared__ float part[8 * 64];
-    int j = 0;
-    while (j + 1 < m.n && (int)blockIdx.x >= m.first_block[j + 1]) ++j;
-    j = __builtin_amdgcn_readfirstlane(j);
-    dw_reduce_block(m.r[j], (int)blockIdx.x - m.first_block[j], threadIdx.x, part);
-}
-
 // Heads (alpha_linear, rgb_linear): G = NO <= 4 natural-order columns of g_rawb [P, 4], X = [P, n_in]
 // slot-major.  A block walks 256-row tiles; a thread owns 8 consecutive X columns (one 16-byte load
 // per row) of every (256 / groups)-th row.  Partial sums meet in LDS and leave as one slab row per
 // block ([NO][n_in] weights, then NO biases); dw_small_reduce_kernel sums the rows.
-template <int NO>
-__global__ __launch_bounds__(256) void dw_small_kernel(const uint16_t *G, int g_col0, const uint16_t *X, int ldx, int n_in,
-                                                       int64_t P, float *slab) {
-    __shared__ float red[NO][256 + 1];
+template <int NO, int NT>
+__device__ __forceinline__ void dw_small_body(const uint16_t *G, int g_col0, const uint16_t *X, int ldx, int n_in, int64_t P,
+                                              float *slab, float (*red)[256 + 1] /* LDS [NO][257] */, const int wg, const int nwg) {
     const int groups = n_in / 8;                       // column groups per row (32 for 256 columns, 16 for 128)
-    const int rows_par = 256 / groups;                 // rows in flight per block
+    const int rows_par = NT / groups;                  // rows in flight per block
     const int cg = threadIdx.x % groups, ty = threadIdx.x / groups;
     float acc[NO][8], bs[NO];
 #pragma unroll
@@ -439,7 +414,7 @@ __global__ __launch_bounds__(256) void dw_small_kernel(const uint16_t *G, int g_
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
     }
-    for (int64_t r0 = (int64_t)blockIdx.x * 256; r0 < P; r0 += (int64_t)gridDim.x * 256) {
+    for (int64_t r0 = (int64_t)wg * 256; r0 < P; r0 += (int64_t)nwg * 256) {
         const int64_t r1 = r0 + 256 < P ? r0 + 256 : P;
 #pragma unroll 4
         for (int64_t p = r0 + ty; p < r1; p += rows_par) {
@@ -460,7 +435,8 @@ __global__ __launch_bounds__(256) void dw_small_kernel(const uint16_t *G, int g_
         }
     }
 #pragma unroll
-    for (int k = 0; k < NO; ++k) red[k][threadIdx.x] = 0.f;
+    for (int k = 0; k < NO; ++k)
+        if (threadIdx.x < 256) red[k][threadIdx.x] = 0.f;
     if (threadIdx.x < NO) red[threadIdx.x][256] = 0.f;
     __syncthreads();
 #pragma unroll
@@ -470,11 +446,18 @@ __global__ __launch_bounds__(256) void dw_small_kernel(const uint16_t *G, int g_
         if (cg == 0) atomicAdd(&red[k][256], bs[k]);
     }
     __syncthreads();
-    float *row = slab + (int64_t)blockIdx.x * (NO * n_in + NO);
+    float *row = slab + (int64_t)wg * (NO * n_in + NO);
     if ((int)threadIdx.x < n_in)
 #pragma unroll
         for (int k = 0; k < NO; ++k) row[k * n_in + threadIdx.x] = red[k][threadIdx.x];
     if (threadIdx.x < NO) row[NO * n_in + threadIdx.x] = red[threadIdx.x][256];
+}
+
+template <int NO>
+__global__ __launch_bounds__(256) void dw_small_kernel(const uint16_t *G, int g_col0, const uint16_t *X, int ldx, int n_in,
+                                                       int64_t P, float *slab) {
+    __shared__ float red[NO][256 + 1];
+    dw_small_body<NO, 256>(G, g_col0, X, ldx, n_in, P, slab, red, blockIdx.x, gridDim.x);
 }
 
 // dW[k][feature(slot)] / db[k] = sum of the slab rows dw_small_kernel left; 64 elements per block.
@@ -510,6 +493,66 @@ static void launch_dw_small(hipStream_t s, int64_t P, float *slab, const uint16_
     hipLaunchKernelGGL(dw_small_kernel<NO>, dim3((unsigned)g), dim3(256), 0, s, G, g_col0, X, n_in, n_in, P, slab);
     hipLaunchKernelGGL(dw_small_reduce_kernel, dim3((NO * n_in + NO + 63) / 64), dim3(256), 0, s, slab, (int)g, NO, n_in,
                        (int)PERM_ACC, dW, n_in, db);
+}
+
+// Every streaming product of one model's backward pass in ONE launch, and their reductions in a second one: a job owns a
+// range of workgroups sized to its bytes per point, 256 workgroups in all -- one per CU from the first chunk to the last, all
+// products in flight together (no ramp and tail per product, ~23 slabs per product to reduce instead of 128-256, and 2
+// launches per model instead of 22 on a step that is host-bound at the reference's batch size).
+constexpr int DW_MAX_JOBS = 16;
+struct DwJob {
+    DwArgs a;
+    int shape;                           // 0: <16,16,4,2>  1: <8,16,4,2>  2: <16,4,8,1>  3: <8,2,8,1>
+    int first_block, n_blocks;
+};
+struct DwMulti {
+    DwJob job[DW_MAX_JOBS];
+    int n;
+};
+struct DwReduceMulti {
+    DwReduceArgs r[DW_MAX_JOBS];
+    int first_block[DW_MAX_JOBS + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(512, 2) void dw_multi_kernel(DwMulti m) {
+    int j = 0;
+    while (j + 1 < m.n && (int)blockIdx.x >= m.job[j + 1].first_block) ++j;
+    j = __builtin_amdgcn_readfirstlane(j);
+    const DwJob &J = m.job[j];
+    const int wg = (int)blockIdx.x - J.first_block;
+    switch (J.shape) {
+    case 0: dw2_body<16, 16, 4, 2>(J.a, wg, J.n_blocks); break;
+    case 1: dw2_body<8, 16, 4, 2>(J.a, wg, J.n_blocks); break;
+    case 2: dw2_body<16, 4, 8, 1>(J.a, wg, J.n_blocks); break;
+    default: dw2_body<8, 2, 8, 1>(J.a, wg, J.n_blocks); break;
+    }
+}
+
+// A job's slabs are few here (~23), so one thread sums one element over all of them (512 elements per block, no LDS, no
+// barrier; 8x fewer blocks than the 64-element jobs of dw_reduce_block, whose count is what bounds that kernel).
+constexpr int DWR_BLOCK = 512;
+__global__ __launch_bounds__(DWR_BLOCK) void dw_reduce_multi_kernel(DwReduceMulti m) {
+    int j = 0;
+    while (j + 1 < m.n && (int)blockIdx.x >= m.first_block[j + 1]) ++j;
+    j = __builtin_amdgcn_readfirstlane(j);
+    const DwReduceArgs &a = m.r[j];
+    const int per = a.OT * a.IT * 256 + a.OT * 16;
+    const int e = ((int)blockIdx.x - m.first_block[j]) * DWR_BLOCK + (int)threadIdx.x;
+    if (e >= per) return;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int b = 0; b < a.n_slabs; ++b) acc += a.slab[(int64_t)b * per + e];
+    if (e < a.OT * a.IT * 256) {
+        const int r = e & 3, lane = (e >> 2) & 63, tile = e >> 8;
+        const int to = tile / a.IT, ti = tile - to * a.IT;
+        const int o = slot_to_feature(a.out_kind, to * 16 + 4 * (lane >> 4) + r, 0);
+        const int i = slot_to_feature(a.in_kind, ti * 16 + (lane & 15), a.in_L);
+        if (i >= 0 && o >= 0 && i < a.m_valid && o < a.n_valid) a.dW[(int64_t)o * a.ld_dw + a.col_off + i] = acc;
+    } else if (a.db) {
+        const int o = slot_to_feature(a.out_kind, e - a.OT * a.IT * 256, 0);
+        if (o >= 0 && o < a.n_valid) a.db[o] = acc;
+    }
 }
 
 namespace {
@@ -632,7 +675,7 @@ static int launch_dw2(const DwArgs &a, const DwReduceArgs &ra, DwSeq &q) {
         ++q.mj.n;
         return NERF_AMD_OK;
     }
-    const size_t lds = 4 * 32 * (OT * 32 + IT * 32);
+    const size_t lds = (size_t)DW2_NS(OT, IT) * 32 * (OT * 32 + IT * 32);
     static DynamicLdsOptIn opt_in;
     if (opt_in.ensure(reinterpret_cast<const void *>(dw2_kernel<OT, IT, WO, WI>), lds) != hipSuccess) return NERF_AMD_EHIP;
     // at least ~16 chunks (512 points) per workgroup so the partial tiles are worth their dump and reduction (measured at
@@ -654,6 +697,17 @@ static int launch_dw2(const DwArgs &a, const DwReduceArgs &ra, DwSeq &q) {
 
 template <int OT, int IT, int WO, int WI>
 static int launch_dw(const DwArgs &a, const DwReduceArgs &ra, DwSeq &q) {
+    if constexpr (OT == 8 && IT == 2) {
+        if (q.multi) {
+            if (q.mj.n >= DW_MAX_JOBS) return NERF_AMD_EINVAL;
+            DwJob &J = q.mj.job[q.mj.n];
+            J.a = a; J.shape = 3;
+            DwReduceArgs &r = q.mr.r[q.mj.n];
+            r = ra; r.OT = OT; r.IT = IT;
+            ++q.mj.n;
+            return NERF_AMD_OK;
+        }
+    }
     constexpr int RSG = OT * 32 + 32, RSX = IT * 32 + 32;
     const size_t lds = 2 * 32 * (RSG + RSX);
     static DynamicLdsOptIn opt_in;
@@ -681,10 +735,14 @@ int DwSeq::flush() {
     if (opt_in.ensure(reinterpret_cast<const void *>(dw_multi_kernel), lds) != hipSuccess) return NERF_AMD_EHIP;
     // workgroups in proportion to the bytes per point of a product, DW_GRID in all (never more than a product has
     // 8-chunk pieces); every product's slabs follow the previous product's
-    static const int OTs[3] = {16, 8, 16}, ITs[3] = {16, 16, 4};
+    // per shape: 16-column tiles of G and X (bytes per point / 32, the share of the workgroups) and floats per slab
     const int64_t n_chunks = (mj.job[0].a.P + 31) / 32;
-    int w[DW_MAX_JOBS], total_w = 0, nb[DW_MAX_JOBS], used = 0;
-    for (int j = 0; j < mj.n; ++j) { w[j] = OTs[mj.job[j].shape] + ITs[mj.job[j].shape]; total_w += w[j]; }
+    int w[DW_MAX_JOBS], total_w = 0, nb[DW_MAX_JOBS], per[DW_MAX_JOBS], used = 0;
+    for (int j = 0; j < mj.n; ++j) {
+        const DwReduceArgs &r = mr.r[j];
+        w[j] = r.OT + r.IT; per[j] = r.OT * r.IT * 256 + r.OT * 16;
+        total_w += w[j];
+    }
     for (int j = 0; j < mj.n; ++j) { nb[j] = DW_GRID * w[j] / total_w; if (nb[j] < 1) nb[j] = 1; used += nb[j]; }
     for (int j = 0; used < DW_GRID; j = (j + 1) % mj.n) { ++nb[j]; ++used; }
     const int cap = n_chunks / 8 < 1 ? 1 : (int)(n_chunks / 8 > DW_GRID ? DW_GRID : n_chunks / 8);
@@ -692,14 +750,13 @@ int DwSeq::flush() {
     int first = 0, rfirst = 0;
     for (int j = 0; j < mj.n; ++j) {
         if (nb[j] > cap) nb[j] = cap;
-        const int OT = OTs[mj.job[j].shape], IT = ITs[mj.job[j].shape];
         mj.job[j].a.slab = sl;
         mj.job[j].first_block = first; mj.job[j].n_blocks = nb[j];
         mr.r[j].slab = sl; mr.r[j].n_slabs = nb[j];
         mr.first_block[j] = rfirst;
-        sl += (size_t)nb[j] * (OT * IT * 256 + OT * 16);
+        sl += (size_t)nb[j] * per[j];
         first += nb[j];
-        rfirst += (OT * IT * 256 + OT * 16 + 63) / 64;
+        rfirst += (per[j] + DWR_BLOCK - 1) / DWR_BLOCK;
     }
     mr.first_block[mj.n] = rfirst;
     mr.n = mj.n;
@@ -803,6 +860,8 @@ int train_param_grads(const Program &p, int64_t P, void *workspace, float *const
     // views_linears.0: [feature | dirs]
     if (!rc) rc = weight_grad(s, P, w.slab, w.sv_feat, W, PERM_ACC, 0, W, w.g_hv, W / 2, W / 2, gw[D + 2], W + icv, 0, gb[D + 2]);
     if (!rc) rc = weight_grad(s, P, w.slab, w.sv_d, Dd, PERM_GEN, Ld, icv, w.g_hv, W / 2, W / 2, gw[D + 2], W + icv, W, nullptr);
+    // (the two head products as jobs of the one launch: 2.13 ms per step instead of 1.69 -- their fp32 FMA loops want a
+    // thousand small blocks in flight, not a twentieth of the CUs)
     if (heads_tail) heads(s.lane_s[0], w.slab + 2 * SLAB_FLOATS / s.lanes);    // behind lane 1's last reduction, same slab share
     if (!rc) rc = s.flush();
     s.join();
