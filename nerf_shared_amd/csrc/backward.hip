@@ -425,9 +425,14 @@ __device__ __forceinline__ void dw_small_body(const uint16_t *G, int g_col0, con
                 x[2 * j] = __builtin_bit_cast(float, xv[j] << 16);
                 x[2 * j + 1] = __builtin_bit_cast(float, xv[j] & 0xffff0000u);
             }
+            // the row's four gradient values as one 8-byte load (one VMEM instruction instead of NO)
+            typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+            const u32x2 gv = *reinterpret_cast<const u32x2 *>(G + p * 4);
 #pragma unroll
             for (int k = 0; k < NO; ++k) {
-                const float g = __builtin_bit_cast(float, (unsigned)G[p * 4 + g_col0 + k] << 16);
+                const int col = g_col0 + k;
+                const unsigned word = (col & 2) ? gv[1] : gv[0];
+                const float g = __builtin_bit_cast(float, (col & 1) ? (word & 0xffff0000u) : (word << 16));
                 if (cg == 0) bs[k] += g;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[k][j] += g * x[j];
@@ -461,21 +466,22 @@ __global__ __launch_bounds__(256) void dw_small_kernel(const uint16_t *G, int g_
 }
 
 // dW[k][feature(slot)] / db[k] = sum of the slab rows dw_small_kernel left; 64 elements per block.
-__global__ __launch_bounds__(256) void dw_small_reduce_kernel(const float *slab, int n_rows, int NO, int n_in, int in_kind,
-                                                              float *dW, int ld_dw, float *db) {
-    __shared__ float part[4][64];
+__global__ __launch_bounds__(1024) void dw_small_reduce_kernel(const float *slab, int n_rows, int NO, int n_in, int in_kind,
+                                                               float *dW, int ld_dw, float *db) {
+    __shared__ float part[16][64];
     const int per = NO * n_in + NO;
-    const int t = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int t = threadIdx.x & 63, grp = threadIdx.x >> 6;      // 64 elements x 16 row groups
     const int e = blockIdx.x * 64 + t;
     float acc = 0.f;
     if (e < per) {
 #pragma unroll 8
-        for (int b = grp; b < n_rows; b += 4) acc += slab[(int64_t)b * per + e];
+        for (int b = grp; b < n_rows; b += 16) acc += slab[(int64_t)b * per + e];
     }
     part[grp][t] = acc;
     __syncthreads();
     if (grp != 0 || e >= per) return;
-    acc = part[0][t] + part[1][t] + part[2][t] + part[3][t];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) acc += part[k][t];
     if (e < NO * n_in) {
         const int k = e / n_in, i = slot_to_feature(in_kind, e - k * n_in, 0);
         if (i >= 0) dW[(int64_t)k * ld_dw + i] = acc;
@@ -491,7 +497,7 @@ static void launch_dw_small(hipStream_t s, int64_t P, float *slab, const uint16_
     const int64_t cap = g_variant == 50 ? 256 : 1024;  // four 256-thread blocks per CU keep enough 16-byte loads in flight; 1024 * (3 * 256 + 3) floats fit the slab
     if (g > cap) g = cap;
     hipLaunchKernelGGL(dw_small_kernel<NO>, dim3((unsigned)g), dim3(256), 0, s, G, g_col0, X, n_in, n_in, P, slab);
-    hipLaunchKernelGGL(dw_small_reduce_kernel, dim3((NO * n_in + NO + 63) / 64), dim3(256), 0, s, slab, (int)g, NO, n_in,
+    hipLaunchKernelGGL(dw_small_reduce_kernel, dim3((NO * n_in + NO + 63) / 64), dim3(1024), 0, s, slab, (int)g, NO, n_in,
                        (int)PERM_ACC, dW, n_in, db);
 }
 

@@ -15,6 +15,12 @@ for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUS
   N=$(echo $C | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$N -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_$N.json 2> $OUT/pmc_$N.err || echo "pmc pass $N failed"
 done
+# the training step: the timed line, then the kernel stats and the timeline of two steps under the profiler
+python tools/train_bench.py --steps 300 > $OUT/train_bench.json 2> $OUT/train_bench.err || echo "train bench failed"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train -- python3 tools/train_bench.py --steps 50 > $OUT/train_under_rocprof.json 2> $OUT/train.err || echo "train profile failed"
+cp $OUT/train/*/*_kernel_stats.csv $OUT/train_kernel_stats.csv
+python tools/step_timeline.py $(find $OUT/train -name "*kernel_trace.csv" | head -1) > $OUT/train_timeline.txt
+rm -rf $OUT/train
 # keep what is judged (the summaries) and drop the per-dispatch tables: gpurun merges at most 64 MiB back
 python tools/pmc_summary.py $OUT $OUT/pmc_summary.json
 cp $OUT/stats/*/*_kernel_stats.csv $OUT/kernel_stats.csv
