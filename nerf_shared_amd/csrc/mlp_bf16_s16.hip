@@ -214,6 +214,9 @@ __device__ __forceinline__ void encode16(float x0, float x1, float x2, int h, in
 // the training arrays have rows for a workgroup's padding points (kernels.h pad_points).
 template <int NK, int ROW>
 __device__ __forceinline__ void save_frags(uint16_t *base, const bf16x8 *y, const int64_t (&pidx)[2], int q) {
+#ifdef NERF_AMD_X_NOSAVE
+    return;                                    // scratch builds: timing without the row stores (results unusable)
+#endif
     static_for<NK>([&](auto k_) {
         constexpr int k = k_;
         static_for<2>([&](auto cc_) {
@@ -744,6 +747,11 @@ static int launch_wg16(const MlpArgs &a, int n_frags_used, int n_tiles, hipStrea
 using Cfg16 = Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 8 + 64>;
 using Cfg16R1 = Ctx<8, 16, 4, 8, 2>;          // round-1 shape (A/B: nerf_amd_set_tuning(0, 40))
 using Cfg16P = Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 8 + 32 + 64>;   // the pipelined kernel: Cfg16 + continuous ring
+#ifdef NERF_AMD_X_SAVE_CFG
+using CfgSave = NERF_AMD_X_SAVE_CFG;           // scratch builds: shape of the training forward
+#else
+using CfgSave = Cfg16R1;                       // the training forward (Cfg16's read-ahead spills beside the saved rows)
+#endif
 
 int launch_mlp_bf16_s16(const MlpArgs &a, int multires, int multires_views, int use_viewdirs,
                         int n_frags_used, int n_tiles, hipStream_t s) {
@@ -818,8 +826,8 @@ extern "C" void nerf_amd_debug_set_stamp_buffer(void *p) { g_stamp_buf = static_
 
 int launch_mlp_bf16_s16_save(const MlpArgs &a, int multires, int multires_views, int n_frags_used, int n_tiles, hipStream_t s) {
     // the training forward keeps the round-1 pipeline shape: with its activation stores the pinned / split shape spills
-    if (multires == 10 && multires_views == 4) return launch_wg16<10, 4, true, Cfg16R1, true>(a, n_frags_used, n_tiles, s);
-    if (multires == 15 && multires_views == 6) return launch_wg16<15, 6, true, Cfg16R1, true>(a, n_frags_used, n_tiles, s);
+    if (multires == 10 && multires_views == 4) return launch_wg16<10, 4, true, CfgSave, true>(a, n_frags_used, n_tiles, s);
+    if (multires == 15 && multires_views == 6) return launch_wg16<15, 6, true, CfgSave, true>(a, n_frags_used, n_tiles, s);
     return NERF_AMD_EUNSUPPORTED;
 }
 
