@@ -822,12 +822,16 @@ int train_param_grads(const Program &p, int64_t P, void *workspace, float *const
     case 55: multi = false; heads_tail = false; heads_first = true; break;
     default: break;
     }
+    // A/B 58: a side stream per head product, both beside the one launch from its start -- 1.683 ms per step against 1.653
+    // with one side stream (four interleaved rounds of 500 steps): the heads' blocks take CU slots from the streaming jobs
+    const bool two_side = multi && g_variant == 58;
+    if (two_side) n_lanes = 3;
     if (n_lanes > 0 && lane_acquire(device, n_lanes, &s.side, &s.ev) == NERF_AMD_OK) {
         if (lane_streams(device, n_lanes - 1, s.lane_s) == NERF_AMD_OK) s.lanes = n_lanes;
         else lane_release(device, s.ev);
     }
     if (!s.lanes) s.grid_cap = DW_GRID;
-    s.multi = multi && s.lanes == 2;
+    s.multi = multi && s.lanes >= 2;
     s.mj.n = 0;
     if (s.multi) s.grid_cap = DW_GRID;
     if (s.lanes) {                                     // the other lanes start behind the backward-chain kernel
@@ -868,7 +872,14 @@ int train_param_grads(const Program &p, int64_t P, void *workspace, float *const
     if (!rc) rc = weight_grad(s, P, w.slab, w.sv_d, Dd, PERM_GEN, Ld, icv, w.g_hv, W / 2, W / 2, gw[D + 2], W + icv, W, nullptr);
     // (the two head products as jobs of the one launch: 2.13 ms per step instead of 1.69 -- their fp32 FMA loops want a
     // thousand small blocks in flight, not a twentieth of the CUs)
-    if (heads_tail) heads(s.lane_s[0], w.slab + 2 * SLAB_FLOATS / s.lanes);    // behind lane 1's last reduction, same slab share
+    if (s.multi && s.lanes == 3) {
+        // both heads start with the one launch and run beside it on a stream each (their blocks are small enough to share a
+        // CU with a streaming workgroup); second half of the slab buffer, a quarter each
+        launch_dw_small<1>(s.lane_s[0], P, w.slab + SLAB_FLOATS, w.g_rawb, 3, w.sv_h + (D - 1) * HS, W, gw[D + 1], gb[D + 1]);
+        launch_dw_small<3>(s.lane_s[1], P, w.slab + SLAB_FLOATS + SLAB_FLOATS / 2, w.g_rawb, 0, w.sv_hv, W / 2, gw[D + 3], gb[D + 3]);
+    } else if (heads_tail) {
+        heads(s.lane_s[0], w.slab + (s.multi ? SLAB_FLOATS : 2 * SLAB_FLOATS / s.lanes));    // behind lane 1's last reduction, same slab share
+    }
     if (!rc) rc = s.flush();
     s.join();
     if (s.overlap || s.lanes) lane_release(device, s.ev);
