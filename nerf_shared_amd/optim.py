@@ -49,7 +49,7 @@ class Adam(torch.optim.Adam):
         for k, c in list(self._together.items()):
             if gi is not None and k != gi:
                 continue
-            for p in self.param_groups[k]["params"]:
+            for p in c["params"]:
                 self.state[p]["step"].fill_(float(c["step"]))
 
     @torch.no_grad()
@@ -68,12 +68,15 @@ class Adam(torch.optim.Adam):
                                         "param_group['lr'] to a float, main.py:109-112)")
             params = group["params"]
             grads = [p.grad for p in params]
+            mask = tuple(g is not None for g in grads)
             c = self._together.get(gi)
-            if c is not None and not any(g is None for g in grads):
+            if c is not None and c["mask"] == mask:
+                # the same parameters as last time got gradients (a model's unused tensors never do -- the reference's
+                # NeRF(use_viewdirs=False) keeps an idle views_linears.0): one counter, cached tables, one launch
                 c["step"] += 1
-                self._launch(params, grads, c["tables"], c["step"], group)
+                self._launch(c["params"], [g for g in grads if g is not None], c["tables"], c["step"], group)
                 continue
-            # general path: parameters step individually (first step, or some parameter got no gradient)
+            # general path: parameters step individually (first step, or the set with gradients changed)
             if c is not None:
                 self._sync_steps(gi)
                 del self._together[gi]
@@ -93,8 +96,8 @@ class Adam(torch.optim.Adam):
                 ps, gs = [p for p, _ in pg], [g for _, g in pg]
                 tables = self._tables(ps)
                 self._launch(ps, gs, tables, step, group)
-                if len(ps) == len(params):
-                    self._together[gi] = {"step": step, "tables": tables}
+                if len(by_step) == 1:
+                    self._together[gi] = {"mask": mask, "step": step, "tables": tables, "params": ps}
         return loss
 
     @staticmethod

@@ -99,6 +99,26 @@ def test_adam_state_moves_between_implementations(dev):
     assert float(ob.state_dict()["state"][2]["step"]) == 6.0 and float(ob.state_dict()["state"][0]["step"]) == 7.0
 
 
+def test_adam_with_a_parameter_that_never_gets_a_gradient(dev):
+    """The reference's NeRF(use_viewdirs=False) carries an unused views_linears.0 (nerf.py:83): its .grad stays None on
+    every step.  The optimizer leaves it alone (no state, like torch) and still steps the others together."""
+    from nerf_shared_amd import optim
+    ours, ref = make_params(dev, 4), make_params(dev, 4)
+    o1 = optim.Adam(ours, lr=1e-3)
+    o2 = torch.optim.Adam(ref, lr=1e-3, foreach=False, fused=False)
+    for step in range(5):
+        set_grads(ours, step, skip=(3,))
+        set_grads(ref, step, skip=(3,))
+        o1.step()
+        o2.step()
+    assert 0 in o1._together and o1._together[0]["step"] == 5            # the cached one-launch path was taken
+    for i, (a, b) in enumerate(zip(ours, ref)):
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), i
+    sd1, sd2 = o1.state_dict(), o2.state_dict()
+    assert sorted(sd1["state"]) == sorted(sd2["state"]) and 3 not in sd1["state"]
+    assert all(float(v["step"]) == 5.0 for v in sd1["state"].values())
+
+
 def test_adam_refuses_what_it_does_not_cover(dev):
     from nerf_shared_amd import _lib, optim
     with pytest.raises(_lib.NerfAmdError):
