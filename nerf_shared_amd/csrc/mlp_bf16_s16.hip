@@ -747,10 +747,32 @@ static int launch_wg16(const MlpArgs &a, int n_frags_used, int n_tiles, hipStrea
 using Cfg16 = Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 8 + 64>;
 using Cfg16R1 = Ctx<8, 16, 4, 8, 2>;          // round-1 shape (A/B: nerf_amd_set_tuning(0, 40))
 using Cfg16P = Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 8 + 32 + 64>;   // the pipelined kernel: Cfg16 + continuous ring
-#ifdef NERF_AMD_X_SAVE_CFG
-using CfgSave = NERF_AMD_X_SAVE_CFG;           // scratch builds: shape of the training forward
+// Row stores of the training forward issued before fragment n (pipeline.h LEDGER): the encodings in front of fragment 0,
+// 16 rows + 2 mask words per finished hidden layer, 16 for the feature layer, 8 + 2 for the view layer.  Scratch builds
+// only (-DNERF_AMD_X_SAVE_LEDGER, -DNERF_AMD_X_SAVE_NS=n): measured 200.7 us against 201.6 without it at 4 ring slots,
+// 212.5 / 258.4 us with 6 / 8 slots -- the default stays the round-1 shape without a ledger.
+template <int LX, int LD>
+struct FwdLedger {
+    using L = Layout16<LX, LD, true>;
+    static constexpr int stores_before(int n) {
+        int s = 2 * L::KE + 2 * L::KD;
+        if (n >= L::F_L1) s += 18;                                        // pts_linears.0
+        for (int k = 1; k <= 4; ++k) if (n >= L::F_L1 + 128 * k) s += 18; // .1-.4 (the last one ends at F_L5)
+        if (n >= L::F_L6) s += 18;                                        // .5
+        if (n >= L::F_L6 + 128) s += 18;                                  // .6
+        if (n >= L::F_FEAT) s += 18;                                      // .7
+        if (n >= L::F_ALPHA) s += 16;                                     // feature_linear
+        if (n >= L::F_RGB) s += 10;                                       // views_linears.0
+        return s;
+    }
+};
+#ifndef NERF_AMD_X_SAVE_NS
+#define NERF_AMD_X_SAVE_NS 4
+#endif
+#ifdef NERF_AMD_X_SAVE_LEDGER
+template <int LX, int LD> using CfgSaveT = Ctx<8, 16, NERF_AMD_X_SAVE_NS, 8, 2, 0, 1, 0, FwdLedger<LX, LD>>;
 #else
-using CfgSave = Cfg16R1;                       // the training forward (Cfg16's read-ahead spills beside the saved rows)
+template <int LX, int LD> using CfgSaveT = Ctx<8, 16, NERF_AMD_X_SAVE_NS, 8, 2>;   // the training forward (Cfg16's read-ahead spills beside the saved rows)
 #endif
 
 int launch_mlp_bf16_s16(const MlpArgs &a, int multires, int multires_views, int use_viewdirs,
@@ -826,8 +848,8 @@ extern "C" void nerf_amd_debug_set_stamp_buffer(void *p) { g_stamp_buf = static_
 
 int launch_mlp_bf16_s16_save(const MlpArgs &a, int multires, int multires_views, int n_frags_used, int n_tiles, hipStream_t s) {
     // the training forward keeps the round-1 pipeline shape: with its activation stores the pinned / split shape spills
-    if (multires == 10 && multires_views == 4) return launch_wg16<10, 4, true, CfgSave, true>(a, n_frags_used, n_tiles, s);
-    if (multires == 15 && multires_views == 6) return launch_wg16<15, 6, true, CfgSave, true>(a, n_frags_used, n_tiles, s);
+    if (multires == 10 && multires_views == 4) return launch_wg16<10, 4, true, CfgSaveT<10, 4>, true>(a, n_frags_used, n_tiles, s);
+    if (multires == 15 && multires_views == 6) return launch_wg16<15, 6, true, CfgSaveT<15, 6>, true>(a, n_frags_used, n_tiles, s);
     return NERF_AMD_EUNSUPPORTED;
 }
 

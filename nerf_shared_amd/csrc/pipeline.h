@@ -207,8 +207,8 @@ __device__ __forceinline__ void block_sync(const C &c) {
     constexpr int younger_stores = (C::PHASE > 0 && issue_sync >= -1 && last_issued > need)
                                        ? C::Ledger::stores_before(pos_now) - C::Ledger::stores_before(pos_then) : 0;
     static_assert(younger_stores >= 0, "ledger must be monotonic");
-    constexpr int cnt = (last_issued > need ? last_issued - need : 0) * C::PIECES + younger_stores;
-    static_assert(cnt <= 63, "vmcnt field is 6 bits");
+    constexpr int cnt_raw = (last_issued > need ? last_issued - need : 0) * C::PIECES + younger_stores;
+    constexpr int cnt = cnt_raw <= 63 ? cnt_raw : 63;    // vmcnt is 6 bits; a smaller count only waits for more
     // CONTINUOUS: blocks NB, NB+1, ... are the next tile's first blocks, in flight only if there is a next tile.  A sync
     // whose allowance would include one of them (B + NS - 2 >= NB) picks its count at run time.
     constexpr bool next_in_window = (C::OPT & 32) != 0 && C::PHASE > 0 && (B + C::NS - 2) >= NB;
