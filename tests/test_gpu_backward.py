@@ -202,21 +202,27 @@ def test_training_step_gradients(dev, monkeypatch):
             assert eb < 8e-2 and cos > 0.97, (tag, name, eb, cos)
 
 
-def test_adam_steps_reduce_the_loss(dev):
-    """A few optimizer steps on a fixed batch (the loop of main.py:67-112 without the data loader)."""
-    from nerf_shared_amd import render_utils
+@pytest.mark.parametrize("which", ["torch", "library"])
+def test_adam_steps_reduce_the_loss(dev, which):
+    """A few optimizer steps on a fixed batch (the loop of main.py:67-112 without the data loader), with torch.optim.Adam and
+    with the library's one-launch Adam + utils.img2mse (what utils.get_optimizer / the loop's loss use on the GPU)."""
+    from nerf_shared_amd import optim, render_utils, utils
     batch, _ = _batch(256, 4)
     target = torch.full((256, 3), 0.25)
     r = render_utils.Renderer(**dict(BASE, N_samples=32, N_importance=32))
     mc, _ = _models(dev, 0, 1.0)
     mf, _ = _models(dev, 10, 1.0)
-    opt = torch.optim.Adam(list(mc.parameters()) + list(mf.parameters()), lr=5e-4, betas=(0.9, 0.999))
+    params = list(mc.parameters()) + list(mf.parameters())
+    opt = (optim.Adam if which == "library" else torch.optim.Adam)(params, lr=5e-4, betas=(0.9, 0.999))
     losses = []
     b, t = batch.to(dev), target.to(dev)
     for _ in range(12):
         opt.zero_grad()
         rgb, disp, acc, extras = r.render(400, 400, None, mc, mf, chunk=128, rays=(b[:, 0:3], b[:, 3:6]), retraw=True)
-        loss = ((rgb - t) ** 2).mean() + ((extras["rgb0"] - t) ** 2).mean()
+        if which == "library":
+            loss = utils.img2mse(rgb, t) + utils.img2mse(extras["rgb0"], t)
+        else:
+            loss = ((rgb - t) ** 2).mean() + ((extras["rgb0"] - t) ** 2).mean()
         loss.backward()
         opt.step()
         losses.append(float(loss))
