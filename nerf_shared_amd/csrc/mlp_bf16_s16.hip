@@ -726,8 +726,8 @@ static int launch_wg16(const MlpArgs &a, int n_frags_used, int n_tiles, hipStrea
     if (groups <= 0) return NERF_AMD_OK;
     if (a.P >= (int64_t)1 << 31) return NERF_AMD_EINVAL;
     if (g_variant != 31) {                 // one workgroup per CU walks the tiles (+1 %: no per-tile dispatch); 31 = A/B off
-        const int n_cu = device_cu_count();
-        if (groups > n_cu) groups = n_cu;
+        const int n_wg = device_cu_count() * (8 / C::WAVES);     // 4-wave workgroups: two per CU
+        if (groups > n_wg) groups = n_wg;
     }
 #ifdef NERF_AMD_STAMPS
     MlpArgs a2 = a;
@@ -769,10 +769,13 @@ struct FwdLedger {
 #ifndef NERF_AMD_X_SAVE_NS
 #define NERF_AMD_X_SAVE_NS 4
 #endif
+#ifndef NERF_AMD_X_SAVE_WAVES
+#define NERF_AMD_X_SAVE_WAVES 8
+#endif
 #ifdef NERF_AMD_X_SAVE_LEDGER
-template <int LX, int LD> using CfgSaveT = Ctx<8, 16, NERF_AMD_X_SAVE_NS, 8, 2, 0, 1, 0, FwdLedger<LX, LD>>;
+template <int LX, int LD> using CfgSaveT = Ctx<NERF_AMD_X_SAVE_WAVES, 16, NERF_AMD_X_SAVE_NS, 8, 2, 0, 1, 0, FwdLedger<LX, LD>>;
 #else
-template <int LX, int LD> using CfgSaveT = Ctx<8, 16, NERF_AMD_X_SAVE_NS, 8, 2>;   // the training forward (Cfg16's read-ahead spills beside the saved rows)
+template <int LX, int LD> using CfgSaveT = Ctx<NERF_AMD_X_SAVE_WAVES, 16, NERF_AMD_X_SAVE_NS, 8, 2>;   // the training forward (Cfg16's read-ahead spills beside the saved rows)
 #endif
 
 int launch_mlp_bf16_s16(const MlpArgs &a, int multires, int multires_views, int use_viewdirs,
