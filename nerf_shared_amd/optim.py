@@ -33,6 +33,14 @@ class Adam(torch.optim.Adam):
         self._together = {}
 
     # -- torch.optim.Optimizer surface -------------------------------------------
+    def __getstate__(self):
+        self._sync_steps()                 # copies and pickles carry the state tensors only (torch's own __getstate__)
+        return super().__getstate__()
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._together = {}
+
     def state_dict(self):
         self._sync_steps()
         return super().state_dict()

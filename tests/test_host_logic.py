@@ -381,3 +381,26 @@ def test_packed_weights_go_stale_after_optimizer_steps_and_copies_get_their_own_
     assert c._packed_key is None                      # the copy is tracked too
     m._handle = None
     assert torch.equal(c.pts_linears[3].weight, m.pts_linears[3].weight)
+
+
+def test_library_adam_is_a_torch_adam_and_survives_copies():
+    """nerf_shared_amd.optim.Adam keeps torch.optim.Adam's surface (constructor, param_groups, state_dict keys, pickling);
+    what its kernel does not cover is refused at construction or at step time, never silently handled elsewhere."""
+    import copy
+    import pickle
+
+    from nerf_shared_amd import _lib, optim
+    p = [torch.nn.Parameter(torch.zeros(4)), torch.nn.Parameter(torch.ones(2, 3))]
+    o = optim.Adam(p, lr=5e-4, betas=(0.9, 0.999))
+    assert isinstance(o, torch.optim.Adam)
+    ref = torch.optim.Adam([torch.nn.Parameter(t.detach().clone()) for t in p], lr=5e-4, betas=(0.9, 0.999))
+    assert {k: v for k, v in o.param_groups[0].items() if k not in ("params", "foreach", "fused")} == \
+           {k: v for k, v in ref.param_groups[0].items() if k not in ("params", "foreach", "fused")}
+    assert sorted(o.state_dict()) == sorted(ref.state_dict())
+    for clone in (copy.deepcopy(o), pickle.loads(pickle.dumps(o))):
+        assert isinstance(clone, optim.Adam) and clone._together == {} and clone.param_groups[0]["lr"] == 5e-4
+    with pytest.raises(_lib.NerfAmdError):
+        optim.Adam(p, amsgrad=True)
+    p[0].grad = torch.ones(4)
+    with pytest.raises(_lib.NerfAmdError):            # host tensors: no CPU path behind the library optimizer
+        o.step()
