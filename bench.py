@@ -85,22 +85,28 @@ def camera(w, synth):
     return K, poses
 
 
+FIELD_KERNEL_SOURCES = ("mlp_bf16_s16.hip", "mlp_bf16.hip", "mlp_fp32.hip", "mlp_split.hip", "pipeline.h", "program.h", "program.cpp",
+                        "pack.hip", "kernels.h", "launch_util.h", "Makefile")
+
+
 def csrc_hash():
-    """Identity of the kernel sources a profile was made from (profiles/*pmc_summary*.json carry it)."""
+    """Identity of the field-kernel sources a profile was made from (profiles/*pmc_summary*.json carry it): the
+    translation units and headers the inference field kernels and their weight packing are compiled from."""
     h = hashlib.sha256()
     root = os.path.join(REPO, "nerf_shared_amd", "csrc")
-    for path in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h")) +
-                       glob.glob(os.path.join(root, "*.cpp")) + [os.path.join(root, "Makefile")]):
-        with open(path, "rb") as f:
-            h.update(os.path.basename(path).encode() + b"\0" + f.read())
+    for name in FIELD_KERNEL_SOURCES:
+        path = os.path.join(root, name)
+        if os.path.exists(path):
+            with open(path, "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
 
 
-def measured_traffic(kernel_tag):
-    """HBM bytes per launch of the dominant kernel from committed rocprofv3 --pmc passes
-    (tools/pmc_summary.py: FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md), only if that summary was
-    made from the kernels this process runs (same csrc hash).  PMC counters cannot be read inside the
-    timed run.  Returns (bytes, file) or None."""
+def measured_pmc(kernel_tag):
+    """Counters of the dominant kernel from committed rocprofv3 --pmc passes (tools/pmc_summary.py), only if that
+    summary was made from the kernels this process runs (same csrc hash) -- PMC counters cannot be read inside the
+    timed run.  Returns {"traffic": HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md),
+    "mfma_util": MfmaUtil in percent, "file": ...} averaged over the kernel's launches, or None."""
     want = csrc_hash()
     for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_summary*.json")), reverse=True):
         try:
@@ -114,13 +120,18 @@ def measured_traffic(kernel_tag):
             if name == "_meta" or kernel_tag not in name:
                 continue
             tot = n = 0
+            util = un = 0
             for g in grids.values():
                 if "hbm_bytes_per_launch" in g:
                     k = g["FETCH_SIZE"]["launches"]
                     tot += g["hbm_bytes_per_launch"]["total"] * k
                     n += k
+                if "MfmaUtil" in g:
+                    k = g["MfmaUtil"]["launches"]
+                    util += g["MfmaUtil"]["mean_per_launch"] * k
+                    un += k
             if n:
-                return tot / n, os.path.basename(path)
+                return {"traffic": tot / n, "mfma_util": (util / un) if un else None, "file": os.path.basename(path)}
     return None
 
 
@@ -135,14 +146,33 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(torch, synth, w):
-    """The oracle on host cores (rank 0, N=1).  C2: one 4096-ray 64+128 batch on all granted cores (1 warm-up +
-    best of 2) and a 512-ray batch on 1 thread; C1: the full 400x400 coarse-only view, chunk 32768, wall clock
-    (BASELINE.md "CPU-baseline plan").  Bounded to roughly 20-40 s."""
+def granted_cores():
+    """Host cores this process may actually use: the scheduler affinity, capped by a cgroup CPU quota if there is one.
+    Returns (cores, {"affinity": .., "cgroup_quota": .., "visible": ..})."""
+    import math
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: None if t.split()[0] == "max" else float(t.split()[0]) / float(t.split()[1])),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: None if int(t) <= 0 else int(t) / 100000.0)):
+        try:
+            with open(path) as f:
+                quota = parse(f.read().strip())
+            break
+        except (OSError, ValueError, IndexError, ZeroDivisionError):
+            continue
+    cores = aff if not quota else max(1, min(aff, int(math.ceil(quota))))
+    return cores, {"affinity": aff, "cgroup_quota": quota, "visible": os.cpu_count()}
+
+
+def cpu_baseline(torch, synth, w, full_c1=True):
+    """The oracle on host cores (rank 0, N=1), bounded to about a minute.  C2: one 4096-ray 64+128 batch on ALL cores
+    granted to the process (1 warm-up + best of 2; when more than 16 are granted the same batch is also timed on 16
+    threads and the better rate is the value, with the thread count that produced it in `cores`), and a 512-ray
+    batch on 1 thread.  `c1` = BASELINE.json configs[0], the reference's own CPU-runnable case: the full 400x400
+    coarse-only view, chunk 32768, wall clock (BASELINE.md "CPU-baseline plan")."""
     from oracle import nerf_oracle as O
     import numpy as np
-    # the GPU box reports every host core but grants a 16-core share per GPU
-    threads = min(len(os.sched_getaffinity(0)), 16)
+    granted, info = granted_cores()
     K, poses = camera(w, synth)
     H, W = w["H"], w["W"]
     models = []
@@ -151,16 +181,24 @@ def cpu_baseline(torch, synth, w):
         models.append((O.state_dict_to_torch(sd), O.Arch(**ARCH)))
     cfg = O.RenderCfg(**renderer_cfg(w, 0.0))
     fine = models[1] if w["Ni"] > 0 else None
-    out = {"unit": "rays/s", "kind": "port", "cpu_model": cpu_model_name(), "host_cores_visible": os.cpu_count()}
+    out = {"unit": "rays/s", "kind": "port", "cpu_model": cpu_model_name(), "host_cores_visible": os.cpu_count(),
+           "cores_granted": granted, "cores_detail": info}
+
+    def full_view_c1(threads):
+        wc = WORKLOADS["c1"]
+        Kc, pc = camera(wc, synth)
+        torch.set_num_threads(threads)
+        t0 = time.perf_counter()
+        O.render(O.RenderCfg(**renderer_cfg(wc, 0.0)), wc["H"], wc["W"], Kc, models[0], None, chunk=wc["chunk"],
+                 c2w=torch.from_numpy(pc[0]), retraw=False)
+        dt = time.perf_counter() - t0
+        return {"value": wc["H"] * wc["W"] / dt, "unit": "rays/s", "cores": threads, "workload": wc["name"],
+                "sample": "one full %dx%d coarse-only view (64 samples), chunk %d, torch-CPU oracle fp32, wall clock %.2f s"
+                          % (wc["H"], wc["W"], wc["chunk"], dt)}
+
     with torch.no_grad():
-        if w["Ni"] == 0:          # C1: one whole coarse-only view
-            torch.set_num_threads(threads)
-            t0 = time.perf_counter()
-            O.render(cfg, H, W, K, models[0], None, chunk=w["chunk"], c2w=torch.from_numpy(poses[0]), retraw=False)
-            dt = time.perf_counter() - t0
-            out.update(value=H * W / dt, cores=threads,
-                       sample="one full %dx%d coarse-only view (64 samples), chunk %d, torch-CPU oracle fp32, wall clock %.2f s"
-                              % (H, W, w["chunk"], dt))
+        if w["Ni"] == 0:          # C1 as the workload: one whole coarse-only view
+            out.update(full_view_c1(granted))
             return out
 
         def timed(n_rays, n_threads, reps):
@@ -174,17 +212,24 @@ def cpu_baseline(torch, synth, w):
                 if i > 0:
                     best = min(best, time.perf_counter() - t0)
             return n_rays / best, best
-        v, best = timed(w["chunk"] if w["chunk"] <= 4096 else 4096, threads, 2)
-        out.update(value=v, cores=threads,
-                   sample="one 4096-ray batch, %d+%d samples, torch-CPU oracle fp32, best of 2 after warm-up (%.2f s)" % (w["Nc"], w["Ni"], best))
+        tries = {}
+        for threads in sorted({granted, min(granted, 16)}, reverse=True):
+            v, best = timed(4096, threads, 2)
+            tries[threads] = {"value": v, "seconds": best}
+        best_threads = max(tries, key=lambda t: tries[t]["value"])
+        out.update(value=tries[best_threads]["value"], cores=best_threads, tried={str(k): v for k, v in tries.items()},
+                   sample="one 4096-ray batch, %d+%d samples, torch-CPU oracle fp32, best of 2 after warm-up (%.2f s)"
+                          % (w["Nc"], w["Ni"], tries[best_threads]["seconds"]))
         v1, best1 = timed(512, 1, 1)
         out["single_thread"] = {"value": v1, "cores": 1,
                                 "sample": "one 512-ray batch, same workload, 1 torch thread, after warm-up (%.2f s)" % best1}
-        torch.set_num_threads(threads)
+        if full_c1:
+            out["c1"] = full_view_c1(best_threads)
+        torch.set_num_threads(best_threads)
     return out
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -194,7 +239,50 @@ def main():
     ap.add_argument("--no-subrecords", action="store_true")
     ap.add_argument("--perturb", type=float, default=1.0)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` started plainly (no RANK in the environment): this process becomes a launcher that never
+    touches the GPU.  It starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` on this same file as a
+    fresh child (one rank per GPU, RCCL), relays rank 0's single JSON line, and returns the child's exit status
+    (non-zero if any rank failed).  Nothing is re-executed in a process that has initialised the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as s:               # a free rendezvous port on the loopback
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = 0
+    for line in proc.stdout:                 # rank 0 prints exactly one JSON line; anything else goes to stderr untouched
+        if line.startswith("{") and '"metric"' in line:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+            lines += 1
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if rc == 0 and lines != 1:
+        sys.stderr.write("bench.py: the ranks exited cleanly but printed %d result lines\n" % lines)
+        rc = 1
+    if rc != 0:
+        sys.stderr.write("bench.py: the %d-rank run failed (torch.distributed.run exit status %d)\n" % (args.gpus, rc))
+    return rc
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    # Under torch.distributed.run RANK/WORLD_SIZE are set and this process is one rank.  Started plainly with
+    # --gpus N > 1 (how the driver records its command), or with NERF_AMD_FORCE_COLLECTIVE=1 at N = 1 (the RCCL
+    # world-1 smoke of the C5 path), this process only launches the ranks -- before anything touches the GPU.
+    if "RANK" not in os.environ and (args.gpus > 1 or os.environ.get("NERF_AMD_FORCE_COLLECTIVE") == "1"):
+        sys.exit(spawn_ranks(args))
     from nerf_shared_amd import render_utils as _ru
     if os.environ.get("NERF_AMD_OVERLAP_CHUNKS") == "1":      # A/B knob: two-stream chunk pipeline of render_batch
         _ru.Renderer.overlap_chunks = True
@@ -208,20 +296,31 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d (WORLD_SIZE=%d)"
-                         % (args.gpus, args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("bench.py rank %d: --gpus %d but WORLD_SIZE=%d (start it plainly, or under torch.distributed.run "
+                         "with --nproc-per-node %d)" % (rank, args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm device; there is no CPU path")
+        raise SystemExit("bench.py rank %d/%d: needs a ROCm device; there is no CPU path" % (rank, world))
     key = args.workload or ("c5" if world > 1 else "c2")
     w = WORKLOADS[key]
     # NERF_AMD_DIST_BACKEND=gloo rehearses the N>1 path with several ranks on one GPU (no RCCL)
     backend = os.environ.get("NERF_AMD_DIST_BACKEND", "nccl")
-    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and world > n_dev:
+        raise SystemExit("bench.py rank %d/%d: %d ranks over RCCL need %d GPUs, %d visible (NERF_AMD_DIST_BACKEND=gloo "
+                         "rehearses with the ranks sharing a GPU)" % (rank, world, world, world, n_dev))
+    dev = torch.device("cuda", local_rank % n_dev)
     torch.cuda.set_device(dev)
     if world > 1 or "RANK" in os.environ:        # under torch.distributed.run also with one rank (RCCL smoke of the C5 path)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+    # what the process group actually is: the world size the backend initialised and the device of every rank
+    dist_info = {"backend": None, "rccl_world": None, "rank_devices": [str(dev)]}
+    if dist.is_initialized():
+        devs = [None] * world
+        dist.all_gather_object(devs, "%s %s" % (torch.cuda.get_device_properties(dev).name, dev))
+        dist_info.update(backend=dist.get_backend(), rank_devices=devs,
+                         rccl_world=dist.get_world_size() if dist.get_backend() == "nccl" else None)
 
     models = []
     for seed in (0, 10):
@@ -271,6 +370,7 @@ def main():
             if profile:
                 collect_profile()
                 _lib.lib.nerf_amd_profile_enable(1)
+                nd.gather_stats(reset=True)
             t0 = time.perf_counter()
             frames(warmup, steps)
             fence()
@@ -285,6 +385,7 @@ def main():
         return float(t.item()), H * W, prof
 
     dt, rays_per_step, prof = run(w, args.perturb, args.steps, args.warmup, profile=True)
+    dist_info.update(nd.gather_stats())          # per-frame gathers issued inside the timed region, and by which path
     cls = 1 if args.precision == "bf16" else 0
     launches, kern_ms, kern_pts = prof[cls]
 
@@ -307,6 +408,11 @@ def main():
             sub["c5_n1"] = {"value": r5 * n5 / d5, "unit": "rays/s", "ms_per_step": d5 / n5 * 1e3, "steps": n5,
                             "workload": WORKLOADS["c5"]["name"],
                             "note": "the N>1 workload on one GPU: the N=1 point of the strong-scaling curve"}
+            n1 = max(3, args.steps // 4)
+            d1, r1, _ = run(WORKLOADS["c1"], args.perturb, n1, 1)
+            sub["c1"] = {"value": r1 * n1 / d1, "unit": "rays/s", "ms_per_step": d1 / n1 * 1e3, "steps": n1,
+                         "workload": WORKLOADS["c1"]["name"],
+                         "note": "BASELINE configs[0] (the reference's CPU-runnable case) on the GPU; its CPU figure is cpu_baseline.c1"}
         if world > 1:
             k_rr = -(-args.steps // world) * world          # whole rounds, so that every rank renders the same number of frames
             drr, rrr, _ = run(w, args.perturb, k_rr, min(args.warmup, 1), mode="frames_round_robin")
@@ -321,13 +427,25 @@ def main():
         achieved = (kern_pts * FLOP_PER_POINT / kern_s / 1e12) if kern_s > 0 else 0.0
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_FP32_TFLOPS
         kernel = "mlp_bf16_s16p_kernel" if cls == 1 else "mlp_f32_kernel"
-        traffic = measured_traffic(kernel) if key == "c2" else None
+        pmc = measured_pmc(kernel) if key == "c2" else None
         # launches are per 32768-ray group (nerf_amd_render_batch), whatever the API chunk: coarse and fine launch alternate
         chunk_rays = min(32768, rays_per_step)
+        launches_per_group = 2 if w["Ni"] else 1
+        avg_launch_s = (kern_s / launches) if launches else None
+        # 44 B in + 44 B out per ray, shared by the field launches of a ray group
+        algorithmic_bytes = chunk_rays * 88 / launches_per_group
+        # what this design moves per launch on top of that: raw [P,4] out (16 B/point) + z in (4 B/point) + the rays,
+        # because the field kernel and the per-ray kernels are separate launches
+        design_bytes = chunk_rays * 44 + (chunk_rays * (2 * w["Nc"] + w["Ni"]) // launches_per_group) * 20
         out = {
             "metric": "rays_per_sec", "value": value, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+            "higher_is_better": True,
+            # N > 1 is BASELINE configs[4] (a fixed 200-pose 800x800 test set sharded over the ranks): strong scaling.
+            # N = 1 is configs[1], the configuration the metric is quoted on; the N = 1 point of the configs[4] curve is
+            # the `c5_n1` sub-record of this line (same rays/s per GPU to within the run-to-run spread).
+            "scaling": "strong", "scaling_curve_workload": WORKLOADS["c5"]["name"],
+            "vs_baseline": None,
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": w["name"], "entry": "Renderer.render(c2w=pose, retraw=False)",
                        "rays_per_step": rays_per_step, "chunk": w["chunk"], "perturb": args.perturb,
@@ -335,19 +453,24 @@ def main():
                        "parallelism": ("flat pixel-range shards x%d of every frame, gather of [rays,5] rows to rank 0 "
                                        "overlapped with the next frame (strong scaling over a fixed %d-pose list)" % (world, N_POSES_C5))
                        if world > 1 else "single GPU"},
+            "dist": dist_info,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic[0] if traffic else None,
+                         "frac": achieved / peak, "traffic": pmc["traffic"] if pmc else None,
                          "traffic_unit": "bytes per launch (HBM, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)",
-                         "traffic_source": ("profiles/" + traffic[1]) if traffic else None,
+                         "traffic_source": ("profiles/" + pmc["file"]) if pmc else None,
+                         "mfma_util": pmc["mfma_util"] if pmc else None,
+                         "hbm_gbps": (pmc["traffic"] / avg_launch_s / 1e9) if (pmc and avg_launch_s) else None,
                          "csrc_hash": csrc_hash(),
-                         "algorithmic_bytes_per_launch": chunk_rays * 44 + (chunk_rays * (2 * w["Nc"] + w["Ni"]) // (2 if w["Ni"] else 1)) * 20,
+                         "algorithmic_bytes_per_launch": algorithmic_bytes,
+                         "design_bytes_per_launch": design_bytes,
+                         "traffic_over_algorithmic": (pmc["traffic"] / algorithmic_bytes) if pmc else None,
                          "kernel": kernel, "launches": launches,
                          "avg_launch_ms": (kern_ms / launches) if launches else None,
                          "flop_per_point": FLOP_PER_POINT, "points": kern_pts, "rank": 0},
         }
         out.update(sub)
         if world == 1 and not args.no_cpu_baseline and key in ("c1", "c2"):
-            out["cpu_baseline"] = cpu_baseline(torch, synth, w)
+            out["cpu_baseline"] = cpu_baseline(torch, synth, w, full_c1=not args.no_subrecords)
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

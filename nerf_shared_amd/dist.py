@@ -14,6 +14,19 @@ import torch
 import torch.distributed as dist
 
 
+# what OverlappedGather did in this process: how many per-frame gathers it issued, and by which path
+# ("collective on a side stream" = RCCL, "async collective" = gloo on CPU tensors, "host-staged" = the gloo rehearsal
+# with GPU tensors, "local" = a world of one without a forced collective).  bench.py reports it.
+_STATS = {"gathers": 0, "gather_path": None}
+
+
+def gather_stats(reset=False):
+    out = dict(_STATS)
+    if reset:
+        _STATS.update(gathers=0, gather_path=None)
+    return out
+
+
 def shard_range(n, rank, world):
     """Contiguous [lo, hi) share of n items for `rank` of `world` (sizes differ by at most 1)."""
     lo = (n * rank) // world
@@ -48,7 +61,16 @@ def _start_gather(local, n_total, dst, group, async_op):
     pad[:local.shape[0]] = local
     bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
     work = dist.gather(pad, bufs, dst=dst, group=group, async_op=async_op)
-    return work, (lambda: torch.cat([b[:s] for b, s in zip(bufs, sizes)], 0) if rank == dst else None)
+
+    def finish():
+        if rank != dst:
+            return None
+        if pad.is_cuda:             # allocated under the gather's stream, read by the cat on the caller's current stream
+            cur = torch.cuda.current_stream(pad.device)
+            for b in bufs:
+                b.record_stream(cur)
+        return torch.cat([b[:s] for b, s in zip(bufs, sizes)], 0)
+    return work, finish
 
 
 def gather_rows(local, n_total, dst=0, group=None):
@@ -98,14 +120,29 @@ class OverlappedGather:
             res.record_stream(torch.cuda.current_stream(res.device))
         self._ready.append(res)
 
+    def ready_count(self):
+        return len(self._ready)
+
+    def poll_ready(self):
+        """Frames whose gather has already been completed by an earlier submit (oldest first), without waiting for
+        the ones still in flight."""
+        out, self._ready = self._ready, []
+        return out
+
+    def _count(self, path):
+        _STATS["gathers"] += 1
+        _STATS["gather_path"] = path
+
     def submit(self, rows):
         self.submitted += 1
         if self.single:
+            self._count("local")
             self._ready.append(rows)
             return
         while len(self._pending) >= self.depth:
             self._complete_oldest()
         if rows.is_cuda and dist.get_backend(self.group) == "gloo":     # rehearsal only: synchronous, through the host
+            self._count("host-staged")
             self._ready.append(gather_rows(rows, self.n_total, self.dst, self.group))
             return
         if rows.is_cuda:
@@ -120,8 +157,10 @@ class OverlappedGather:
                 done = torch.cuda.Event()
                 done.record(self._side)
             rows.record_stream(self._side)
+            self._count("collective on a side stream")
             self._pending.append((finish, work, done, rows))
         else:
+            self._count("async collective")
             work, finish = _start_gather(rows, self.n_total, self.dst, self.group, True)
             self._pending.append((finish, work, None, rows))
 
@@ -232,9 +271,8 @@ def render_poses_gathered(renderer, H, W, K, chunk, batch_c2w, coarse_model, fin
                                      device=dev, pix0=lo, n=hi - lo)
         ret = renderer.render_batch(coarse_model, fine_model, batch, chunk, False)
         gatherer.submit(pack_maps(ret))
-        if len(gatherer._ready) >= 4:              # hand finished frames on without waiting for the ones in flight
-            ready, gatherer._ready = gatherer._ready, []
-            drain(ready)
+        if gatherer.ready_count() >= 4:            # hand finished frames on without waiting for the ones in flight
+            drain(gatherer.poll_ready())
     drain(gatherer.collect())
     if on_frame is not None:
         return n_done

@@ -1,0 +1,64 @@
+"""bench.py as the driver starts it (-m gpu): `python bench.py --gpus N`, a plain process that launches its own ranks.
+
+  * N = 1 with NERF_AMD_FORCE_COLLECTIVE=1: one rank under torch.distributed.run on the `nccl` backend (RCCL), the C5
+    workload, so the side-stream gather of dist.OverlappedGather (async collective under a stream context, stream-level
+    wait, events) executes on real hardware every round -- with a world of one, which is all a 1-GPU box offers.
+  * N = 2 with NERF_AMD_DIST_BACKEND=gloo: two ranks time-sharing this GPU (gloo stands in for RCCL, which refuses two
+    ranks on one device): the launcher, the rendezvous, the pixel-range shards, the gather and the max-over-ranks timing.
+  * N = 2 on RCCL with one visible GPU: refused by every rank before any collective, launcher exits non-zero.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(extra_env, *argv, timeout=420):
+    env = dict(os.environ, NERF_AMD_QUIET="1", **extra_env)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + list(argv), env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    return p
+
+
+def result_line(p):
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_self_launched_rccl_world_of_one_runs_the_c5_gather():
+    assert torch.cuda.is_available()
+    p = run_bench({"NERF_AMD_FORCE_COLLECTIVE": "1"}, "--gpus", "1", "--workload", "c5", "--steps", "3", "--warmup", "1",
+                  "--no-subrecords", "--no-cpu-baseline")
+    out = result_line(p)
+    assert out["n_gpus"] == 1 and out["dist"]["backend"] == "nccl" and out["dist"]["rccl_world"] == 1
+    assert len(out["dist"]["rank_devices"]) == 1 and "cuda:0" in out["dist"]["rank_devices"][0]
+    assert out["config"]["workload"].startswith("lego_fullres_800x800") and out["config"]["rays_per_step"] == 640000
+    assert out["value"] > 1e6 and out["roofline"]["launches"] > 0
+    assert out["dist"]["gathers"] == 3 and out["dist"]["gather_path"] == "collective on a side stream"
+
+
+def test_self_launched_two_ranks_share_the_gpu_over_gloo():
+    p = run_bench({"NERF_AMD_DIST_BACKEND": "gloo"}, "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-cpu-baseline")
+    out = result_line(p)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong"
+    assert out["dist"]["backend"] == "gloo" and out["dist"]["rccl_world"] is None and len(out["dist"]["rank_devices"]) == 2
+    assert out["config"]["rays_per_step"] == 640000 and out["value"] > 1e6
+    assert out["frames_round_robin"]["steps"] == 4 and out["frames_round_robin"]["value"] > 1e6
+
+
+def test_more_rccl_ranks_than_gpus_is_refused_before_any_collective():
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer GPUs than ranks")
+    p = run_bench({}, "--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert p.returncode != 0 and p.stdout.strip() == ""
+    assert "2 ranks over RCCL need 2 GPUs, 1 visible" in p.stderr

@@ -299,15 +299,45 @@ def test_bench_reports_traffic_only_for_the_build_it_was_measured_on(tmp_path, m
     prof = tmp_path / "profiles"
     prof.mkdir()
     grids = {"131072": {"FETCH_SIZE": {"launches": 4, "mean_per_launch": 100.0}, "WRITE_SIZE": {"launches": 4, "mean_per_launch": 50.0},
+                        "MfmaUtil": {"launches": 2, "mean_per_launch": 70.0},
                         "hbm_bytes_per_launch": {"read_corrected_x2": 204800.0, "write": 51200.0, "total": 256000.0}}}
     import json
     (prof / "r99_pmc_summary_x.json").write_text(json.dumps({"_meta": {"csrc_hash": h}, "void na::mlp_bf16_s16p_kernel<10>": grids}))
     monkeypatch.setattr(bench, "REPO", str(tmp_path))
     monkeypatch.setattr(bench, "csrc_hash", lambda: h)
-    got = bench.measured_traffic("mlp_bf16_s16p_kernel")
-    assert got is not None and got[0] == 256000.0 and got[1] == "r99_pmc_summary_x.json"
+    got = bench.measured_pmc("mlp_bf16_s16p_kernel")
+    assert got == {"traffic": 256000.0, "mfma_util": 70.0, "file": "r99_pmc_summary_x.json"}
     monkeypatch.setattr(bench, "csrc_hash", lambda: "0" * 16)           # the kernels changed: the stale figure is dropped
-    assert bench.measured_traffic("mlp_bf16_s16p_kernel") is None
+    assert bench.measured_pmc("mlp_bf16_s16p_kernel") is None
+
+
+def test_bench_launches_its_own_ranks_and_fails_cleanly_without_a_gpu():
+    """`python bench.py --gpus 2` started plainly (the form the driver records) must itself start two ranks under
+    torch.distributed.run -- from a parent that never touches the GPU -- and, with no ROCm device visible, every
+    rank refuses loudly and the launcher's exit status is non-zero with no result line on stdout."""
+    import subprocess
+    env = dict(os.environ, NERF_AMD_DIST_BACKEND="gloo", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert p.stdout.strip() == ""                                   # no JSON line from a failed run
+    assert "rank 0/2: needs a ROCm device" in p.stderr or "rank 1/2: needs a ROCm device" in p.stderr, p.stderr[-2000:]
+    assert "the 2-rank run failed" in p.stderr
+    # a rank count that contradicts the environment is refused as well (a stale WORLD_SIZE, a wrong --nproc-per-node)
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"],
+                       env=dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr
+
+
+def test_bench_counts_the_cores_it_is_granted(monkeypatch):
+    """cpu_baseline uses every core granted to the process: the affinity mask capped by a cgroup quota."""
+    sys.path.insert(0, REPO)
+    import bench
+    cores, info = bench.granted_cores()
+    assert 1 <= cores <= info["affinity"] == len(os.sched_getaffinity(0))
+    assert info["cgroup_quota"] is None or cores <= info["cgroup_quota"] + 1
 
 
 def test_png_codec_roundtrip_and_async_writer(tmp_path):
