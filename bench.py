@@ -234,7 +234,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp32_split"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-subrecords", action="store_true")
     ap.add_argument("--perturb", type=float, default=1.0)
@@ -337,9 +337,9 @@ def main():
         torch.cuda.synchronize()
 
     def collect_profile():
-        launches, ms, pts = (ctypes.c_int64 * 2)(), (ctypes.c_double * 2)(), (ctypes.c_double * 2)()
-        _lib.lib.nerf_amd_profile_collect(launches, ms, pts)
-        return [(int(launches[c]), float(ms[c]), float(pts[c])) for c in range(2)]
+        launches, ms, pts = (ctypes.c_int64 * 3)(), (ctypes.c_double * 3)(), (ctypes.c_double * 3)()
+        _lib.lib.nerf_amd_profile_collect(launches, ms, pts)      # classes: 0 exact fp32, 1 bf16, 2 split precision
+        return [(int(launches[c]), float(ms[c]), float(pts[c])) for c in range(3)]
 
     def run(wk, perturb, steps, warmup, precision=None, mode="pixel_ranges", profile=False):
         """Time `steps` steps of workload wk.  Returns (seconds [max over ranks], rays per step, profile)."""
@@ -386,7 +386,7 @@ def main():
 
     dt, rays_per_step, prof = run(w, args.perturb, args.steps, args.warmup, profile=True)
     dist_info.update(nd.gather_stats())          # per-frame gathers issued inside the timed region, and by which path
-    cls = 1 if args.precision == "bf16" else 0
+    cls = {"fp32": 0, "bf16": 1, "fp32_split": 2}[args.precision]
     launches, kern_ms, kern_pts = prof[cls]
 
     sub = {}
@@ -396,13 +396,22 @@ def main():
             sub["perturb0"] = {"value": n0 * max(2, args.steps // 4) / d0, "unit": "rays/s",
                                "ms_per_step": d0 / max(2, args.steps // 4) * 1e3, "steps": max(2, args.steps // 4)}
             if args.precision == "bf16":
-                d32, n32, p32 = run(w, args.perturb, 2, 1, precision="fp32", profile=True)
-                l32, ms32, pts32 = p32[0]
-                sub["fp32"] = {"value": n32 * 2 / d32, "unit": "rays/s", "ms_per_step": d32 / 2 * 1e3, "steps": 2, "dtype": "f32",
-                               "roofline": {"bound": "mfma", "achieved": pts32 * FLOP_PER_POINT / (ms32 / 1e3) / 1e12 if ms32 else 0.0,
-                                            "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                                            "frac": (pts32 * FLOP_PER_POINT / (ms32 / 1e3) / 1e12 / PEAK_FP32_TFLOPS) if ms32 else 0.0,
-                                            "kernel": "mlp_f32_kernel", "launches": l32, "avg_launch_ms": ms32 / l32 if l32 else None}}
+                # the two modes at the reference's precision: the exact fp32 MFMA kernel and the split-precision kernel
+                # (fp16 operand pairs, 3 MFMAs per product: its roofline is a third of the dense 16-bit peak)
+                for name, kern, ci, peak, nsteps in (("fp32", "mlp_f32_kernel", 0, PEAK_FP32_TFLOPS, 2),
+                                                      ("fp32_split", "mlp_split_kernel", 2, PEAK_BF16_TFLOPS / 3.0, 4)):
+                    dd, nn, pp = run(w, args.perturb, nsteps, 1, precision=name, profile=True)
+                    ll, mss, ptss = pp[ci]
+                    ach = ptss * FLOP_PER_POINT / (mss / 1e3) / 1e12 if mss else 0.0
+                    pm = measured_pmc(kern)
+                    sub[name] = {"value": nn * nsteps / dd, "unit": "rays/s", "ms_per_step": dd / nsteps * 1e3, "steps": nsteps,
+                                 "dtype": "f32" if name == "fp32" else "f16x2 (fp32-class: hi/lo fp16 operand pairs, fp32 accumulate)",
+                                 "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                                              "peak_note": "fp32 MFMA peak" if name == "fp32" else
+                                                           "dense fp16 MFMA peak / 3 (three MFMAs per algorithmic product)",
+                                              "mfma_util": pm["mfma_util"] if pm else None,
+                                              "traffic": pm["traffic"] if pm else None,
+                                              "kernel": kern, "launches": ll, "avg_launch_ms": mss / ll if ll else None}}
             n5 = max(3, args.steps // 4)
             d5, r5, _ = run(WORKLOADS["c5"], args.perturb, n5, 1)
             sub["c5_n1"] = {"value": r5 * n5 / d5, "unit": "rays/s", "ms_per_step": d5 / n5 * 1e3, "steps": n5,
@@ -425,8 +434,8 @@ def main():
         value = rays_per_step * args.steps / dt
         kern_s = kern_ms / 1e3
         achieved = (kern_pts * FLOP_PER_POINT / kern_s / 1e12) if kern_s > 0 else 0.0
-        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_FP32_TFLOPS
-        kernel = "mlp_bf16_s16p_kernel" if cls == 1 else "mlp_f32_kernel"
+        peak = {"bf16": PEAK_BF16_TFLOPS, "fp32": PEAK_FP32_TFLOPS, "fp32_split": PEAK_BF16_TFLOPS / 3.0}[args.precision]
+        kernel = {"bf16": "mlp_bf16_s16p_kernel", "fp32": "mlp_f32_kernel", "fp32_split": "mlp_split_kernel"}[args.precision]
         pmc = measured_pmc(kernel) if key == "c2" else None
         # launches are per 32768-ray group (nerf_amd_render_batch), whatever the API chunk: coarse and fine launch alternate
         chunk_rays = min(32768, rays_per_step)
@@ -446,7 +455,7 @@ def main():
             # the `c5_n1` sub-record of this line (same rays/s per GPU to within the run-to-run spread).
             "scaling": "strong", "scaling_curve_workload": WORKLOADS["c5"]["name"],
             "vs_baseline": None,
-            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "dtype": {"bf16": "bf16", "fp32": "f32", "fp32_split": "f16x2"}[args.precision], "data": "synthetic",
             "config": {"workload": w["name"], "entry": "Renderer.render(c2w=pose, retraw=False)",
                        "rays_per_step": rays_per_step, "chunk": w["chunk"], "perturb": args.perturb,
                        "N_samples": w["Nc"], "N_importance": w["Ni"], "weights": "random-init seeds 0/10",

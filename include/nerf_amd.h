@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NERF_AMD_ABI_VERSION 4
+#define NERF_AMD_ABI_VERSION 5
 
 #define NERF_AMD_OK            0
 #define NERF_AMD_EINVAL       -1   /* bad argument / unsupported shape        */
@@ -47,6 +47,10 @@ extern "C" {
 #define NERF_AMD_PREC_FP32 0       /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32): parity mode       */
 #define NERF_AMD_PREC_BF16 1       /* bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16;   */
                                    /* 32x32x16 for output_ch > 16 without a view branch)          */
+#define NERF_AMD_PREC_FP32_SPLIT 2 /* fp32-class results on the 16-bit matrix pipe: operands as   */
+                                   /* fp16 (hi, lo) pairs, three v_mfma_f32_16x16x32_f16 per      */
+                                   /* product, fp32 accumulate (csrc/mlp_split.hip); needs        */
+                                   /* |activation| < 65504                                        */
 
 #define NERF_AMD_MAX_SKIPS 8
 
@@ -87,6 +91,8 @@ int  nerf_amd_model_update(nerf_amd_model *m, const float *const *weights, const
 void nerf_amd_model_destroy(nerf_amd_model *m);
 /* 1 when the fused bf16 kernel supports this architecture (D=8, W=256, skips=[4]). */
 int  nerf_amd_model_supports_bf16(const nerf_amd_model *m);
+/* 1 when the split-precision kernel (NERF_AMD_PREC_FP32_SPLIT) supports this architecture: the same set. */
+int  nerf_amd_model_supports_split(const nerf_amd_model *m);
 int  nerf_amd_model_out_ch(const nerf_amd_model *m);       /* 4 with viewdirs, else output_ch */
 
 /* Host-side packing of one model into the bf16 fragment stream (test hook: lets
@@ -321,14 +327,14 @@ int nerf_amd_adam_step(int32_t n, float *const *params, const float *const *grad
  * Measurement hook (bench.py): while enabled, every field-MLP launch is
  * bracketed by hipEvents on its own stream.  nerf_amd_profile_collect waits for
  * the recorded events and returns, per class (0 = fp32 kernel, 1 = fused bf16
- * kernel), the number of launches, the summed device time in milliseconds and
+ * kernel, 2 = split-precision kernel), the number of launches, the summed device time in milliseconds and
  * the summed number of points, then forgets them.
  * ------------------------------------------------------------------------ */
 int nerf_amd_profile_enable(int on);
 /* Tuning knobs for A/B measurements (results are identical for every setting).
  * key 0: weight-pipeline shape of the fused bf16 kernel (0 = default; see mlp_bf16.hip launch_one). */
 int nerf_amd_set_tuning(int key, int value);
-int nerf_amd_profile_collect(int64_t launches[2], double total_ms[2], double total_points[2]);
+int nerf_amd_profile_collect(int64_t launches[3], double total_ms[3], double total_points[3]);
 
 #ifdef __cplusplus
 }

@@ -62,8 +62,8 @@ struct nerf_amd_model {
     TileDesc *d_tiles = nullptr;
     LayerF32 *d_layers = nullptr;
     TensorDesc *d_tensors = nullptr;
-    uint16_t *stream_bf16 = nullptr, *stream_s16 = nullptr, *stream_bwd = nullptr;
-    FragDesc *d_frags_bwd = nullptr;
+    uint16_t *stream_bf16 = nullptr, *stream_s16 = nullptr, *stream_bwd = nullptr, *stream_split = nullptr;
+    FragDesc *d_frags_bwd = nullptr, *d_frags_split = nullptr;
     float *bias_bf16 = nullptr, *stream_f32 = nullptr, *bias_f32 = nullptr, *bias_s16 = nullptr;
     FragDesc *d_frags16 = nullptr;
     TileDesc *d_tiles16 = nullptr;
@@ -94,7 +94,7 @@ int nerf_amd_model_create(const nerf_amd_arch *arch, int device, nerf_amd_model 
     int rc;
     if ((rc = upload(&m->d_frags, p.frags)) || (rc = upload(&m->d_tiles, p.tiles)) ||
         (rc = upload(&m->d_frags16, p.frags16)) || (rc = upload(&m->d_tiles16, p.tiles16)) ||
-        (rc = upload(&m->d_frags_bwd, p.frags_bwd)) ||
+        (rc = upload(&m->d_frags_bwd, p.frags_bwd)) || (rc = upload(&m->d_frags_split, p.frags_split)) ||
         (rc = upload(&m->d_layers, p.layers)) || (rc = upload(&m->d_tensors, p.tensors))) {
         nerf_amd_model_destroy(m);
         return rc;
@@ -107,6 +107,7 @@ int nerf_amd_model_create(const nerf_amd_arch *arch, int device, nerf_amd_model 
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->bias_s16), p.tiles16.size() * 16 * sizeof(float));
         if (e == hipSuccess && !p.frags_bwd.empty())
             e = hipMalloc(reinterpret_cast<void **>(&m->stream_bwd), p.frags_bwd.size() * 1024);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->stream_split), p.frags_split.size() * 1024);
     }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->stream_f32), (size_t)p.f32_stream_floats * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->bias_f32), (size_t)p.f32_bias_floats * sizeof(float));
@@ -134,7 +135,8 @@ int nerf_amd_model_update(nerf_amd_model *m, const float *const *weights, const 
     for (int i = 0; i < n_tensors; ++i) { wt.p[i] = weights[i]; bt.p[i] = biases[i]; }
     int rc = launch_pack(p, m->d_frags, m->d_tiles, m->d_layers, m->d_tensors, wt, bt,
                          m->stream_bf16, m->bias_bf16, m->stream_f32, m->bias_f32,
-                         m->d_frags16, m->d_tiles16, m->stream_s16, m->bias_s16, m->d_frags_bwd, m->stream_bwd, s);
+                         m->d_frags16, m->d_tiles16, m->stream_s16, m->bias_s16, m->d_frags_bwd, m->stream_bwd,
+                         m->d_frags_split, m->stream_split, s);
     if (rc) return fail(rc, "pack launch failed");
     m->packed = true;
     return NERF_AMD_OK;
@@ -143,7 +145,7 @@ int nerf_amd_model_update(nerf_amd_model *m, const float *const *weights, const 
 void nerf_amd_model_destroy(nerf_amd_model *m) {
     if (!m) return;
     (void)hipFree(m->d_frags); (void)hipFree(m->d_tiles); (void)hipFree(m->d_layers); (void)hipFree(m->d_tensors);
-    (void)hipFree(m->d_frags_bwd); (void)hipFree(m->stream_bwd);
+    (void)hipFree(m->d_frags_bwd); (void)hipFree(m->stream_bwd); (void)hipFree(m->d_frags_split); (void)hipFree(m->stream_split);
     (void)hipFree(m->d_frags16); (void)hipFree(m->d_tiles16); (void)hipFree(m->stream_s16); (void)hipFree(m->bias_s16);
     (void)hipFree(m->stream_bf16); (void)hipFree(m->bias_bf16); (void)hipFree(m->stream_f32); (void)hipFree(m->bias_f32);
     delete m;
@@ -154,19 +156,24 @@ int nerf_amd_model_supports_bf16(const nerf_amd_model *m) {
     const nerf_amd_arch &a = m->prog.arch;
     return m->prog.bf16_ok && a.i_embed == 0 && mlp_bf16_supported(a.multires, a.multires_views, a.use_viewdirs);
 }
+int nerf_amd_model_supports_split(const nerf_amd_model *m) {
+    if (!m) return 0;
+    const nerf_amd_arch &a = m->prog.arch;
+    return m->prog.bf16_ok && a.i_embed == 0 && mlp_split_supported(a.multires, a.multires_views, a.use_viewdirs, m->prog.out_ch);
+}
 int nerf_amd_model_out_ch(const nerf_amd_model *m) { return m ? m->prog.out_ch : 0; }
 
 int nerf_amd_pack_bf16_host(const nerf_amd_arch *arch, int shape, const float *const *weights, const float *const *biases,
                             int n_tensors, uint16_t *stream_out, int64_t *n_frags, float *bias_out, int64_t *n_bias) {
-    if (shape != 16 && shape != 32 && shape != 17)
-        return fail(NERF_AMD_EINVAL, "shape must be 32 (32x32x16 stream), 16 (16x16x32 stream) or 17 (backward stream)");
+    if (shape != 16 && shape != 32 && shape != 17 && shape != 18)
+        return fail(NERF_AMD_EINVAL, "shape must be 32 (32x32x16 stream), 16 (16x16x32 stream), 17 (backward stream) or 18 (split-precision stream)");
     if (!arch) return fail(NERF_AMD_EINVAL, "null argument");
     Program p;
     const char *err = "";
     if (build_program(*arch, p, &err) != 0) return fail(NERF_AMD_EINVAL, err);
     if (!p.bf16_ok) return fail(NERF_AMD_EUNSUPPORTED, "architecture has no fused bf16 program (needs D=8, W=256, skips=[4])");
-    if (n_frags) *n_frags = (int64_t)(shape == 17 ? p.frags_bwd.size() : shape == 16 ? p.frags16.size() : p.frags.size());
-    if (n_bias) *n_bias = shape == 17 ? 0 : shape == 16 ? (int64_t)p.tiles16.size() * 16 : (int64_t)p.tiles.size() * 32;
+    if (n_frags) *n_frags = (int64_t)(shape == 18 ? p.frags_split.size() : shape == 17 ? p.frags_bwd.size() : shape == 16 ? p.frags16.size() : p.frags.size());
+    if (n_bias) *n_bias = (shape == 17 || shape == 18) ? 0 : shape == 16 ? (int64_t)p.tiles16.size() * 16 : (int64_t)p.tiles.size() * 32;
     if (stream_out || bias_out) {
         if (!weights || !biases || n_tensors != (int)p.tensors.size()) return fail(NERF_AMD_EINVAL, "bad parameter list");
         pack_bf16_host(p, shape, weights, biases, stream_out, bias_out);
@@ -189,6 +196,7 @@ int run_field(const nerf_amd_model *m, MlpArgs a, int precision, hipStream_t s) 
     if (!m->packed) return fail(NERF_AMD_EINVAL, "model has no parameters yet (call nerf_amd_model_update)");
     a.stream_bf16 = m->stream_bf16; a.bias_bf16 = m->bias_bf16;
     a.stream_s16 = m->stream_s16; a.bias_s16 = m->bias_s16;
+    a.stream_split = m->stream_split;
     a.stream_f32 = m->stream_f32; a.bias_f32 = m->bias_f32;
     a.layers = m->d_layers; a.n_layers = (int)p.layers.size();
     a.input_ch = p.input_ch; a.input_ch_views = p.input_ch_views; a.W = p.arch.W; a.lds_rows = p.lds_rows;
@@ -197,7 +205,7 @@ int run_field(const nerf_amd_model *m, MlpArgs a, int precision, hipStream_t s) 
     if (p.arch.use_viewdirs && !a.viewdirs) return fail(NERF_AMD_EINVAL, "model has a view branch but no viewdirs were given");
     if (!p.arch.use_viewdirs) a.viewdirs = nullptr;
     int rc;
-    ProfRec rec{nullptr, nullptr, precision == NERF_AMD_PREC_BF16 ? 1 : 0, (double)a.P};
+    ProfRec rec{nullptr, nullptr, precision == NERF_AMD_PREC_BF16 ? 1 : precision == NERF_AMD_PREC_FP32_SPLIT ? 2 : 0, (double)a.P};
     bool prof = false;
     {
         std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -233,6 +241,10 @@ int run_field(const nerf_amd_model *m, MlpArgs a, int precision, hipStream_t s) 
         }
     } else if (precision == NERF_AMD_PREC_FP32) {
         rc = launch_mlp_f32(a, s);
+    } else if (precision == NERF_AMD_PREC_FP32_SPLIT) {
+        if (!nerf_amd_model_supports_split(m))
+            return fail(NERF_AMD_EUNSUPPORTED, "split-precision kernel needs D=8, W=256, skips=[4], multires/views in {(10,4),(15,6)} (or 10 / 15 without a view branch, output_ch <= 16); use NERF_AMD_PREC_FP32");
+        rc = launch_mlp_split(a, p.arch.multires, p.arch.multires_views, p.arch.use_viewdirs, p.n_frags_split_used, (int)p.tiles16.size(), s);
     } else {
         return fail(NERF_AMD_EINVAL, "unknown precision");
     }
@@ -751,9 +763,9 @@ int nerf_amd_profile_enable(int on) {
     return NERF_AMD_OK;
 }
 
-int nerf_amd_profile_collect(int64_t launches[2], double total_ms[2], double total_points[2]) {
+int nerf_amd_profile_collect(int64_t launches[3], double total_ms[3], double total_points[3]) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    for (int c = 0; c < 2; ++c) { launches[c] = 0; total_ms[c] = 0.0; total_points[c] = 0.0; }
+    for (int c = 0; c < 3; ++c) { launches[c] = 0; total_ms[c] = 0.0; total_points[c] = 0.0; }
     for (const ProfRec &r : g_prof_recs) {
         float ms = 0.f;
         if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {

@@ -15,6 +15,7 @@ struct MlpArgs {
     const float *bias_bf16;        // [n_tiles][2][16]
     const uint16_t *stream_s16;    // bf16 A-fragment stream for the 16x16x32 kernel
     const float *bias_s16;         // [n_tiles16][16]
+    const uint16_t *stream_split;  // fp16 (hi, lo) A-fragment stream of the split-precision kernel (mlp_split.hip)
     const float *stream_f32;       // fp32 fragment stream
     const float *bias_f32;
     const LayerF32 *layers;        // device copy of the fp32 program
@@ -68,6 +69,10 @@ bool mlp_bf16_supported(int multires, int multires_views, int use_viewdirs);
 int launch_mlp_bf16(const MlpArgs &a, int multires, int multires_views, int use_viewdirs,
                     int n_frags_used, int n_tiles, hipStream_t s);
 int launch_mlp_f32(const MlpArgs &a, hipStream_t s);
+// mlp_split.hip: fp32-class results from fp16 operand pairs, three MFMAs per product
+bool mlp_split_supported(int multires, int multires_views, int use_viewdirs, int out_ch);
+int launch_mlp_split(const MlpArgs &a, int multires, int multires_views, int use_viewdirs, int n_frags_used, int n_tiles,
+                     hipStream_t s);
 int launch_embed(const float *x, int64_t n, int multires, float *out, hipStream_t s);
 
 // Parameter pointers of one model, passed to the pack kernels by value (no host->device copy).
@@ -79,7 +84,8 @@ int launch_pack(const Program &p, const FragDesc *d_frags, const TileDesc *d_til
                 const TensorDesc *d_tensors, const PtrTable &d_weight_ptrs, const PtrTable &d_bias_ptrs,
                 uint16_t *stream_bf16, float *bias_bf16, float *stream_f32, float *bias_f32,
                 const FragDesc *d_frags16, const TileDesc *d_tiles16, uint16_t *stream_s16, float *bias_s16,
-                const FragDesc *d_frags_bwd, uint16_t *stream_bwd, hipStream_t s);
+                const FragDesc *d_frags_bwd, uint16_t *stream_bwd, const FragDesc *d_frags_split, uint16_t *stream_split,
+                hipStream_t s);
 void pack_bf16_host(const Program &p, int shape, const float *const *w, const float *const *b, uint16_t *stream, float *bias);
 int launch_mlp_bf16_s16(const MlpArgs &a, int multires, int multires_views, int use_viewdirs,
                         int n_frags_used, int n_tiles, hipStream_t s);

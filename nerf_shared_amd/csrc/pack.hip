@@ -17,6 +17,56 @@ NA_HD inline uint16_t f32_to_bf16_rne(float f) {
     return (uint16_t)(u >> 16);
 }
 
+// fp32 -> IEEE fp16 bits, round to nearest even (overflow -> inf), by hand: shared by the host twin, whose toolchain
+// may lack the _Float16 conversion routines.
+NA_HD inline uint16_t f32_to_f16_rne(float f) {
+    uint32_t u;
+    __builtin_memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    u &= 0x7fffffffu;
+    if (u > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);                 // NaN
+    if (u >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                // rounds to >= 65520: inf
+    if (u < 0x38800000u) {                                                  // |f| < 2^-14: fp16 denormal or zero
+        if (u < 0x33000000u) return (uint16_t)sign;                         // < 2^-25: zero
+        const int e = (int)(u >> 23);                                       // biased fp32 exponent, 102..112
+        uint32_t m = (u & 0x7fffffu) | 0x800000u;                           // 24-bit significand
+        const int shift = 126 - e;                                          // 14..24: significand >> shift = multiples of 2^-24
+        const uint32_t half = 1u << (shift - 1), rest = m & ((1u << shift) - 1u);
+        m >>= shift;
+        if (rest > half || (rest == half && (m & 1u))) ++m;
+        return (uint16_t)(sign | m);
+    }
+    u += 0xc8000000u;                                                       // re-bias the exponent: -(127 - 15) << 23
+    u += 0x0fffu + ((u >> 13) & 1u);
+    return (uint16_t)(sign | (u >> 13));
+}
+NA_HD inline float f16_bits_to_f32(uint16_t h) {
+    const uint32_t sign = ((uint32_t)h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3ffu;
+    uint32_t u;
+    if (e == 0) {
+        if (m == 0) u = sign;
+        else {                                                              // denormal: normalise
+            int k = 0;
+            uint32_t mm = m;
+            while (!(mm & 0x400u)) { mm <<= 1; ++k; }
+            u = sign | ((uint32_t)(113 - k) << 23) | ((mm & 0x3ffu) << 13);
+        }
+    } else if (e == 31) u = sign | 0x7f800000u | (m << 13);
+    else u = sign | ((e + 112u) << 23) | (m << 13);
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+// Element of a fragment of `part` (program.h FragDesc): bf16(w), or the fp16 pair of the split-precision stream --
+// hi = fp16(w) (0 where that would be a denormal, so no operand ever is one), lo = fp16((w - hi) 2^11).
+NA_HD inline uint16_t pack_value(float w, int part) {
+    if (part == 0) return f32_to_bf16_rne(w);
+    uint16_t hi = f32_to_f16_rne(w);
+    if ((hi & 0x7c00u) == 0) hi = 0;
+    if (part == 1) return hi;
+    return f32_to_f16_rne((w - f16_bits_to_f32(hi)) * 2048.0f);
+}
+
 // Weight column (inside the tensor) held by element j of lane `lane` of fragment d, or -1.
 NA_HD inline int frag_source(const FragDesc &d, int lane, int j, int n_out, int *row) {
     if (d.kind == FRAG_T16 || d.kind == FRAG_TG16 || d.kind == FRAG_TE16) {   // transposed: *row = output feature, column = input feature
@@ -46,13 +96,13 @@ NA_HD inline int frag_source(const FragDesc &d, int lane, int j, int n_out, int 
 // Every packed copy of a model from ONE launch (a re-pack follows every optimizer step of a training loop, where six
 // small launches cost more on the host than on the GPU): block ranges select the job.
 struct PackJobs {
-    const FragDesc *frags_bwd, *frags16, *frags;
+    const FragDesc *frags_bwd, *frags16, *frags, *frags_split;
     const TileDesc *tiles16, *tiles;
     const LayerF32 *layers;
     const TensorDesc *tensors;
-    uint16_t *stream_bwd, *stream_s16, *stream_bf16;
+    uint16_t *stream_bwd, *stream_s16, *stream_bf16, *stream_split;
     float *bias_s16, *bias_bf16, *stream_f32, *bias_f32;
-    int n_bwd, n16, n32, n_tiles16, n_tiles, n_layers;
+    int n_bwd, n16, n32, n_split, n_tiles16, n_tiles, n_layers;
     int b_bias16, b_bias32;          // blocks of the two bias tables
 };
 constexpr int PACK_F32_BLOCKS = 32;  // per layer
@@ -65,7 +115,7 @@ __device__ __forceinline__ void pack_frag(const FragDesc *frags, int n, const Te
     const TensorDesc t = tensors[d.tensor];
     const int col = frag_source(d, lane, j, t.n_out, &row);
     const float v = col < 0 ? 0.0f : weights[d.tensor][(int64_t)row * t.n_in + col];
-    stream[(int64_t)n * 512 + threadIdx.x] = f32_to_bf16_rne(v);
+    stream[(int64_t)n * 512 + threadIdx.x] = pack_value(v, d.part);
 }
 
 __global__ __launch_bounds__(512) void pack_all_kernel(PackJobs J, PtrTable weights_tab, PtrTable biases_tab) {
@@ -78,6 +128,8 @@ __global__ __launch_bounds__(512) void pack_all_kernel(PackJobs J, PtrTable weig
     b -= J.n16;
     if (b < J.n32) { pack_frag(J.frags, b, J.tensors, weights, J.stream_bf16); return; }
     b -= J.n32;
+    if (b < J.n_split) { pack_frag(J.frags_split, b, J.tensors, weights, J.stream_split); return; }
+    b -= J.n_split;
     if (b < J.b_bias16) {            // [tile][16 rows], natural row order
         const int e = b * 512 + threadIdx.x;
         if (e < J.n_tiles16 * 16) {
@@ -119,21 +171,24 @@ int launch_pack(const Program &p, const FragDesc *d_frags, const TileDesc *d_til
                 const TensorDesc *d_tensors, const PtrTable &d_w, const PtrTable &d_b,
                 uint16_t *stream_bf16, float *bias_bf16, float *stream_f32, float *bias_f32,
                 const FragDesc *d_frags16, const TileDesc *d_tiles16, uint16_t *stream_s16, float *bias_s16,
-                const FragDesc *d_frags_bwd, uint16_t *stream_bwd, hipStream_t s) {
+                const FragDesc *d_frags_bwd, uint16_t *stream_bwd, const FragDesc *d_frags_split, uint16_t *stream_split,
+                hipStream_t s) {
     PackJobs J;
-    J.frags_bwd = d_frags_bwd; J.frags16 = d_frags16; J.frags = d_frags;
+    J.frags_bwd = d_frags_bwd; J.frags16 = d_frags16; J.frags = d_frags; J.frags_split = d_frags_split;
+    J.stream_split = stream_split;
     J.tiles16 = d_tiles16; J.tiles = d_tiles; J.layers = d_layers; J.tensors = d_tensors;
     J.stream_bwd = stream_bwd; J.stream_s16 = stream_s16; J.stream_bf16 = stream_bf16;
     J.bias_s16 = bias_s16; J.bias_bf16 = bias_bf16; J.stream_f32 = stream_f32; J.bias_f32 = bias_f32;
     J.n_bwd = p.bf16_ok ? (int)p.frags_bwd.size() : 0;
     J.n16 = p.bf16_ok ? (int)p.frags16.size() : 0;
     J.n32 = p.bf16_ok ? (int)p.frags.size() : 0;
+    J.n_split = p.bf16_ok ? (int)p.frags_split.size() : 0;
     J.n_tiles16 = p.bf16_ok ? (int)p.tiles16.size() : 0;
     J.n_tiles = p.bf16_ok ? (int)p.tiles.size() : 0;
     J.n_layers = (int)p.layers.size();
     J.b_bias16 = (J.n_tiles16 * 16 + 511) / 512;
     J.b_bias32 = (J.n_tiles * 32 + 511) / 512;
-    const unsigned grid = (unsigned)(J.n_bwd + J.n16 + J.n32 + J.b_bias16 + J.b_bias32 + J.n_layers * PACK_F32_BLOCKS);
+    const unsigned grid = (unsigned)(J.n_bwd + J.n16 + J.n32 + J.n_split + J.b_bias16 + J.b_bias32 + J.n_layers * PACK_F32_BLOCKS);
     hipLaunchKernelGGL(pack_all_kernel, dim3(grid), dim3(512), 0, s, J, d_w, d_b);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
@@ -150,6 +205,19 @@ void pack_bf16_host(const Program &p, int shape, const float *const *w, const fl
                         const int col = frag_source(p.frags_bwd[n], lane, j, t.n_out, &row);
                         stream[n * 512 + lane * 8 + j] =
                             f32_to_bf16_rne(col < 0 ? 0.0f : w[p.frags_bwd[n].tensor][(int64_t)row * t.n_in + col]);
+                    }
+        return;
+    }
+    if (shape == 18) {       // split-precision stream (fp16 hi / lo fragments); bias table = shape 16's
+        if (stream)
+            for (size_t n = 0; n < p.frags_split.size(); ++n)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        int row;
+                        const FragDesc &d = p.frags_split[n];
+                        const TensorDesc &t = p.tensors[d.tensor];
+                        const int col = frag_source(d, lane, j, t.n_out, &row);
+                        stream[n * 512 + lane * 8 + j] = pack_value(col < 0 ? 0.0f : w[d.tensor][(int64_t)row * t.n_in + col], d.part);
                     }
         return;
     }

@@ -112,9 +112,13 @@ int build_program(const nerf_amd_arch &a, Program &p, const char **err) {
                 const int in_pair = (t + 1 < n_tiles) ? 2 : 1;
                 for (int u = 0; u < in_pair; ++u) p.tiles16.push_back({tensor, 16 * (t + u)});
                 for (const Seg &s : segs)
-                    for (int ks = 0; ks < s.nk; ++ks)
+                    for (int ks = 0; ks < s.nk; ++ks) {
                         for (int u = 0; u < in_pair; ++u)
                             p.frags16.push_back({tensor, s.kind, 16 * (t + u), s.col_base, ks, s.len, s.L, 0});
+                        for (int part = 1; part <= 2; ++part)          // the same fragments as fp16 hi / lo parts
+                            for (int u = 0; u < in_pair; ++u)
+                                p.frags_split.push_back({tensor, s.kind, 16 * (t + u), s.col_base, ks, s.len, s.L, part});
+                    }
             }
         };
         const Seg E16{FRAG_GEN16, 0, p.input_ch, p.KE16, Lx};
@@ -134,6 +138,8 @@ int build_program(const nerf_amd_arch &a, Program &p, const char **err) {
         }
         p.n_frags16_used = (int)p.frags16.size();
         while (p.frags16.size() % STREAM_PAD_FRAGS) p.frags16.push_back({0, FRAG_ZERO, 0, 0, 0, 0, 0, 0});
+        p.n_frags_split_used = (int)p.frags_split.size();
+        while (p.frags_split.size() % STREAM_PAD_FRAGS) p.frags_split.push_back({0, FRAG_ZERO, 0, 0, 0, 0, 0, 0});
 
         // ---- backward stream: g_in^T = W^T g_out^T, layer -> pair of 16-row input-feature tiles ->
         //      segment -> k-step -> tile of the pair (parameter gradients only: the encodings' own

@@ -70,7 +70,7 @@ struct FragDesc {        // one bf16 A fragment: 32 out rows x 16 k
     int32_t ks;          // k-step inside the segment
     int32_t seg_len;     // valid columns in the segment
     int32_t L;           // multires of the generated encoding (FRAG_GEN)
-    int32_t pad;
+    int32_t part;        // 0: bf16(w).  Split stream (mlp_split.hip): 1 = fp16 hi part of w, 2 = fp16 lo part, (w - hi) 2^11
 };
 
 struct TileDesc {        // one 32-row output tile (bias table entry)
@@ -152,6 +152,10 @@ struct Program {
     std::vector<FragDesc> frags16;
     std::vector<TileDesc> tiles16;
     int n_frags16_used = 0;
+    // split-precision stream (mlp_split.hip): the s16 program with every fragment as an fp16 (hi, lo) pair, ordered
+    // layer -> pair of output tiles -> k-step -> part -> tile of the pair; the bias table is tiles16's
+    std::vector<FragDesc> frags_split;
+    int n_frags_split_used = 0;
     // backward (transposed-weight) stream for the s16 kernel; view-branch (10,4) model only
     std::vector<FragDesc> frags_bwd;
     int n_frags_bwd_used = 0;

@@ -21,7 +21,8 @@ import torch.nn as nn
 from . import _lib
 from ._lib import lib
 
-_PRECISIONS = {"fp32": _lib.PREC_FP32, "bf16": _lib.PREC_BF16}
+# "fp32_split": fp32-class results on the 16-bit matrix pipe (fp16 operand pairs, three MFMAs per product; csrc/mlp_split.hip)
+_PRECISIONS = {"fp32": _lib.PREC_FP32, "bf16": _lib.PREC_BF16, "fp32_split": _lib.PREC_FP32_SPLIT}
 _default_precision = "bf16"
 
 
@@ -341,6 +342,8 @@ class NeRF(nn.Module):
         code = _PRECISIONS[name]
         if code == _lib.PREC_BF16 and self._handle is not None and not lib.nerf_amd_model_supports_bf16(self._handle):
             code = _lib.PREC_FP32      # still a HIP MFMA kernel, at the fp32 rate
+        if code == _lib.PREC_FP32_SPLIT and self._handle is not None and not lib.nerf_amd_model_supports_split(self._handle):
+            code = _lib.PREC_FP32      # the exact kernel covers every architecture
         return code
 
     def supports_bf16(self, device=None):

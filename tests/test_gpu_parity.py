@@ -338,12 +338,18 @@ G5_TOL = {"rgb_map": 2e-4, "acc_map": 2e-4, "rgb0": 2e-4, "acc0": 2e-4, "weights
 
 @pytest.mark.parametrize("tag", sorted(G5_CASES))
 def test_render_rays_fp32_golden(dev, golden, tag):
+    render_rays_golden_check(dev, golden, tag, "fp32")
+
+
+def render_rays_golden_check(dev, golden, tag, precision):
+    """The fp32 gates of render_rays against the reference's own outputs (golden G5), for a precision mode that
+    claims fp32-class results ("fp32": the exact kernel; "fp32_split": tests/test_gpu_split.py)."""
     _, render_utils, _ = amd()
     g = golden("g5_render_rays")
     over, arch, (sc, sf, sharpen), pytest_flag = G5_CASES[tag]
     r = render_utils.Renderer(**dict(BASE, **over))
-    coarse = gpu_model(dev, sc, sharpen, "fp32", **arch)
-    fine = gpu_model(dev, sf, sharpen, "fp32", **arch) if sf is not None else None
+    coarse = gpu_model(dev, sc, sharpen, precision, **arch)
+    fine = gpu_model(dev, sf, sharpen, precision, **arch) if sf is not None else None
     ret = r.render_rays(torch.from_numpy(g[tag + "__batch"]).to(dev), coarse, fine,
                         retraw=True, retweights=True, pytest=pytest_flag)
     expected = [k for k in G5_KEYS if tag + "__" + k in g]
@@ -538,7 +544,7 @@ def oracle_batch(cfg, H, W, K, c2w, idx):
     return torch.cat(cols, -1).contiguous()
 
 
-def staged_check(dev, cfg, arch, batch, seeds, use_pytest, label):
+def staged_check(dev, cfg, arch, batch, seeds, use_pytest, label, precision="fp32"):
     """Every stage of render_rays against the oracle ON IDENTICAL INPUTS, so the ill-conditioning of
     sample_pdf cannot hide (or fake) a discrepancy:
       coarse pass : oracle end to end (same seeded draws)                      -> tight
@@ -550,7 +556,7 @@ def staged_check(dev, cfg, arch, batch, seeds, use_pytest, label):
     R, Nc, Ni = batch.shape[0], cfg["N_samples"], cfg["N_importance"]
     (sc, sf, sharpen) = seeds
     coarse_cpu, fine_cpu = cpu_model(sc, sharpen, **arch), cpu_model(sf, sharpen, **arch)
-    coarse_gpu, fine_gpu = gpu_model(dev, sc, sharpen, "fp32", **arch), gpu_model(dev, sf, sharpen, "fp32", **arch)
+    coarse_gpu, fine_gpu = gpu_model(dev, sc, sharpen, precision, **arch), gpu_model(dev, sf, sharpen, precision, **arch)
     r = render_utils.Renderer(**cfg)
     out = {k: v.cpu() for k, v in r.render_rays(batch.to(dev), coarse_gpu, fine_gpu, retraw=True, retweights=True,
                                                 pytest=use_pytest).items()}
@@ -613,6 +619,10 @@ def test_render_rays_vs_oracle_staged(dev, name):
     of render_rays the end-to-end goldens only cover with a fraction criterion: stratified jitter,
     lindisp, sigma noise + black background, no view directions, NDC rays (render_utils.py:105-156).
     Ragged sizes on purpose: 333 rays."""
+    report("staged_" + name, run_staged_case(dev, name, "fp32"))
+
+
+def run_staged_case(dev, name, precision):
     over, arch, seeds, use_pytest, ndc_cam = STAGED_CASES[name]
     cfg = dict(BASE, **over)
     rng = np.random.default_rng(99)
@@ -626,7 +636,7 @@ def test_render_rays_vs_oracle_staged(dev, name):
         c2w = synth.pose_spherical(37.0)
     idx = np.sort(rng.choice(H * W, size=333, replace=False))
     batch = oracle_batch(cfg, H, W, K, c2w, idx)
-    report("staged_" + name, staged_check(dev, cfg, arch, batch, seeds, use_pytest, name))
+    return staged_check(dev, cfg, arch, batch, seeds, use_pytest, name, precision)
 
 
 def test_empty_and_errors(dev):

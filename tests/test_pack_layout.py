@@ -515,3 +515,165 @@ def test_unsupported_arch_reports_error():
     nf = ctypes.c_int64()
     rc = lib.nerf_amd_pack_bf16_host(ctypes.byref(arch), 32, None, None, 0, None, ctypes.byref(nf), None, None)
     assert rc == -3 and b"D=8" in lib.nerf_amd_last_error()
+
+
+# ---------------------------------------------------------------- split-precision stream (mlp_split.hip, shape 18)
+def split_np(x):
+    """x -> (hi, lo) as fp32 arrays holding fp16 values: hi = fp16(x) (0 where denormal), lo = fp16((x - hi) 2^11)."""
+    x = np.asarray(x, np.float32)
+    hi = x.astype(np.float16)
+    hi = np.where(np.abs(x) < 2.0 ** -14, np.float16(0), hi).astype(np.float16)
+    lo = ((x - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+    return hi.astype(np.float32), lo.astype(np.float32)
+
+
+def host_pack_split(arch_kwargs, sd):
+    names = ["pts_linears.%d" % i for i in range(arch_kwargs["D"])]
+    names += ["feature_linear", "alpha_linear", "views_linears.0", "rgb_linear"] if arch_kwargs["use_viewdirs"] else ["output_linear"]
+    ws = [np.ascontiguousarray(sd[n + ".weight"], np.float32) for n in names]
+    bs = [np.ascontiguousarray(sd[n + ".bias"], np.float32) for n in names]
+    arch = _lib.make_arch(arch_kwargs["D"], arch_kwargs["W"], arch_kwargs["output_ch"], arch_kwargs["skips"],
+                          arch_kwargs["use_viewdirs"], arch_kwargs["multires"], arch_kwargs["multires_views"], 0)
+    n = len(names)
+    wp = (ctypes.c_void_p * n)(*[w.ctypes.data for w in ws])
+    bp = (ctypes.c_void_p * n)(*[b.ctypes.data for b in bs])
+    nf, nb = ctypes.c_int64(), ctypes.c_int64()
+    _lib.check(lib.nerf_amd_pack_bf16_host(ctypes.byref(arch), 18, wp, bp, n, None, ctypes.byref(nf), None, ctypes.byref(nb)), "size query")
+    assert nb.value == 0
+    stream = np.zeros(nf.value * 512, np.uint16)
+    _lib.check(lib.nerf_amd_pack_bf16_host(ctypes.byref(arch), 18, wp, bp, n,
+                                           stream.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)), ctypes.byref(nf), None, None), "pack")
+    return stream.view(np.float16).astype(np.float32).reshape(nf.value, 64, 8)
+
+
+class WaveEmuSplit(WaveEmu16):
+    """One wave = 16 points; activation fragments come as (hi, lo) pairs: x[2k] = hi, x[2k+1] = lo (mlp_split.hip)."""
+
+    def pair(self, f0, t, x1, k1, x2=None, k2=0):
+        ah, al = [self.bias_init(t), self.bias_init(t + 1)], [np.zeros((64, 4)), np.zeros((64, 4))]
+        n = f0
+        for xs, kk in ((x1, k1), (x2, k2)):
+            for k in range(kk):
+                w0h, w1h, w0l, w1l = self.stream[n], self.stream[n + 1], self.stream[n + 2], self.stream[n + 3]
+                n += 4
+                xh, xl = xs[2 * k], xs[2 * k + 1]
+                ah[0] = self.mfma(w0h, xh, ah[0]); ah[1] = self.mfma(w1h, xh, ah[1])
+                al[0] = self.mfma(w0h, xl, al[0]); al[1] = self.mfma(w1h, xl, al[1])
+                al[0] = self.mfma(w0l, xh, al[0]); al[1] = self.mfma(w1l, xh, al[1])
+        return [(ah[u] + al[u] / 2048.0).astype(np.float32) for u in range(2)]
+
+    def single(self, f0, t, x1, k1):
+        ah, al = self.bias_init(t), np.zeros((64, 4))
+        for k in range(k1):
+            wh, wl = self.stream[f0 + 2 * k], self.stream[f0 + 2 * k + 1]
+            ah = self.mfma(wh, x1[2 * k], ah)
+            al = self.mfma(wh, x1[2 * k + 1], al)
+            al = self.mfma(wl, x1[2 * k], al)
+        return (ah + al / 2048.0).astype(np.float32)
+
+    def layer(self, f0, t0, npair, x1, k1, x2=None, k2=0, relu=True):
+        y = []
+        for p in range(npair):
+            ev, od = self.pair(f0 + p * 4 * (k1 + k2), t0 + 2 * p, x1, k1, x2, k2)
+            v = np.concatenate([ev, od], -1)
+            if relu:
+                v = np.maximum(v, 0)
+            y += list(split_np(v))
+        return y
+
+    @staticmethod
+    def encode(emb, L, K):
+        out = []
+        for ks in range(K):
+            f = np.zeros((64, 8), np.float32)
+            for l in range(64):
+                for j in range(8):
+                    c = gen16_col(ks, l >> 4, j, L)
+                    f[l, j] = emb[l & 15, c] if c >= 0 else 0.0
+            out += list(split_np(f))
+        return out
+
+
+def emulate_split(arch, sd, pts, dirs):
+    LX, LD, VD = arch["multires"], arch["multires_views"], arch["use_viewdirs"]
+    KE, KD = gen16_ksteps(LX), (gen16_ksteps(LD) if VD else 0)
+    _, bias = host_pack(arch, sd, 16)
+    stream = host_pack_split(arch, sd)
+    F_L1 = 32 * KE
+    F_L5 = F_L1 + 4 * 256
+    F_L6 = F_L5 + 32 * (KE + 8)
+    F_HEAD = F_L6 + 512
+    w = WaveEmuSplit(stream, bias)
+    E = w.encode(O.embed(torch.from_numpy(pts), LX).numpy(), LX, KE)
+    A = w.layer(0, 0, 8, E, KE)
+    B = w.layer(F_L1, 16, 8, A, 8)
+    A = w.layer(F_L1 + 256, 32, 8, B, 8)
+    B = w.layer(F_L1 + 512, 48, 8, A, 8)
+    A = w.layer(F_L1 + 768, 64, 8, B, 8)
+    B = w.layer(F_L5, 80, 8, E, KE, A, 8)
+    A = w.layer(F_L6, 96, 8, B, 8)
+    B = w.layer(F_L6 + 256, 112, 8, A, 8)
+    if VD:
+        Dv = w.encode(O.embed(torch.from_numpy(dirs), LD).numpy(), LD, KD)
+        F_ALPHA = F_HEAD + 256
+        F_VIEWS = F_ALPHA + 16
+        F_RGB = F_VIEWS + 16 * (8 + KD)
+        assert F_RGB + 8 <= stream.shape[0]
+        A = w.layer(F_HEAD, 128, 8, B, 8, relu=False)
+        alpha = w.single(F_ALPHA, 144, B, 8)
+        B2 = w.layer(F_VIEWS, 145, 4, A, 8, Dv, KD)
+        rgb = w.single(F_RGB, 153, B2, 4)
+        return np.concatenate([rgb[:16, 0:3], alpha[:16, 0:1]], -1)
+    o = w.single(F_HEAD, 128, B, 8)
+    out = np.zeros((16, arch["output_ch"]), np.float32)
+    for qq in range(4):
+        for r in range(4):
+            if 4 * qq + r < arch["output_ch"]:
+                out[:, 4 * qq + r] = o[16 * qq:16 * qq + 16, r]
+    return out
+
+
+def test_split_stream_values_are_exact_fp16_pairs():
+    """pack.hip's hand-written fp32 -> fp16 conversion against numpy's, and the pair's accuracy: hi + lo / 2^11
+    reproduces every weight to 2^-21 relative (22 significant bits), no fragment value is an fp16 denormal hi part."""
+    arch = CASES[0]
+    sd = synth.make_state_dict(3, 3.0, **{**arch, "skips": tuple(arch["skips"])})
+    # make the conversion meet denormals, ties and large values as well
+    w0 = sd["pts_linears.1.weight"]
+    w0[0, :8] = [1e-6, 6.0e-5, 6.2e-5, 3.0e-8, 1000.0, 65504.0, 1.0 + 2.0 ** -11, 1.0 + 3 * 2.0 ** -11]
+    stream = host_pack_split(arch, sd)
+    assert stream.shape[0] % 192 == 0 and stream.shape[0] >= 2344
+    # fragment order inside a pair and k-step: hi(t0), hi(t1), lo(t0), lo(t1); layer 1 = pts_linears.1 starts at 32 * KE
+    f0 = 32 * gen16_ksteps(10)
+    W = sd["pts_linears.1.weight"]
+    for u in range(2):
+        hi, lo = stream[f0 + u], stream[f0 + 2 + u]
+        for l in range(64):
+            for j in range(8):
+                col = 32 * 0 + 16 * (j >> 2) + 4 * (l >> 4) + (j & 3)          # acc16_col(ks = 0, q, j)
+                wv = np.float32(W[16 * u + (l & 15), col])
+                eh, el = split_np(wv)
+                assert hi[l, j] == eh and lo[l, j] == el, (u, l, j, wv, hi[l, j], eh, lo[l, j], el)
+                assert abs(np.float64(hi[l, j]) + np.float64(lo[l, j]) / 2048.0 - np.float64(wv)) <= 2.0 ** -21 * abs(np.float64(wv)) + 2.0 ** -25   # below 2^-14 the lo part alone carries the value
+
+
+@pytest.mark.parametrize("arch", CASES, ids=["vd_10_4", "vd_15_6", "novd_10"])
+def test_split_stream_matches_kernel_dataflow_at_fp32_accuracy(arch):
+    """mlp_split.hip's data flow replayed on the host-packed fp16 (hi, lo) stream: against an fp64 evaluation of
+    the fp32 weights it is inside the fp32 parity gate (1e-4 + 1e-4 |y|) on the x3 weights -- where bf16 pairs
+    are not."""
+    rng = np.random.default_rng(7)
+    pts = rng.uniform(-3, 3, size=(16, 3)).astype(np.float32)
+    dirs = rng.normal(size=(16, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    sd = synth.make_state_dict(3, 3.0, **{**arch, "skips": tuple(arch["skips"])})
+    got = emulate_split(arch, sd, pts, dirs)
+    sd64 = {k: torch.from_numpy(np.asarray(v)).double() for k, v in sd.items()}
+    a = O.Arch(**{**arch, "skips": tuple(arch["skips"])})
+    e = O.embed(torch.from_numpy(pts), arch["multires"])
+    if arch["use_viewdirs"]:
+        e = torch.cat([e, O.embed(torch.from_numpy(dirs), arch["multires_views"])], -1)
+    want = O.mlp(sd64, a, e.double()).numpy()
+    err = np.abs(got - want)
+    assert np.abs(want).max() > 1.0
+    assert (err <= 0.5 * (1e-4 + 1e-4 * np.abs(want))).all(), (err.max(), (err / (1e-4 + 1e-4 * np.abs(want))).max())

@@ -21,8 +21,16 @@ import torch  # noqa: E402
 from nerf_shared_amd import render_utils, synth, utils  # noqa: E402
 
 
-def sphere_image(H, W, K, c2w, dev, radius=1.0):
-    """Analytic target: Lambert-shaded unit sphere at the origin, white background."""
+def sphere_image(H, W, K, c2w, dev, radius=1.0, ss=1):
+    """Analytic target: Lambert-shaded unit sphere at the origin, white background.  ss > 1: the mean of ss x ss
+    sub-pixel samples (an anti-aliased silhouette, as a rendered dataset frame has)."""
+    if ss > 1:
+        Ks = np.array(K, np.float64).copy()
+        Ks[:2, :] *= ss                                      # an ss-times finer pixel grid over the same field of view
+        Ks[0, 2] += 0.5 * (ss - 1)
+        Ks[1, 2] += 0.5 * (ss - 1)                           # sub-pixel centres symmetric around the coarse pixel centre
+        fine = sphere_image(H * ss, W * ss, Ks, c2w, dev, radius, 1)
+        return fine.reshape(H, ss, W, ss, 3).mean((1, 3))
     ro, rd = utils.get_rays(H, W, K, torch.from_numpy(c2w))
     rd_n = rd / rd.norm(dim=-1, keepdim=True)
     b = (ro * rd_n).sum(-1)
@@ -54,7 +62,8 @@ def write_blender_scene(root, H, W, poses, images, i_train, i_test):
             json.dump(meta, f)
 
 
-def run(steps=600, res=64, views=12, n_rand=1024, seed=0, verbose=True, scene_dir=None, multires=10, multires_views=4):
+def run(steps=600, res=64, views=12, n_rand=1024, seed=0, verbose=True, scene_dir=None, multires=10, multires_views=4,
+        lrate=5e-4, ss=1):
     """scene_dir: write the scene to disk in the Blender format first and train from what
     utils.load_datasets reads back (8-bit frames) instead of from the in-memory float images."""
     torch.manual_seed(seed)
@@ -64,7 +73,7 @@ def run(steps=600, res=64, views=12, n_rand=1024, seed=0, verbose=True, scene_di
     K = synth.lego_intrinsics(H, W)
     poses = np.stack([np.concatenate([synth.pose_spherical(th, -30.0 + 20.0 * np.sin(i)), [[0, 0, 0, 1]]], 0)
                       for i, th in enumerate(np.linspace(-180, 180, views + 1)[:-1])], 0).astype(np.float32)
-    images = torch.stack([sphere_image(H, W, K, p[:3, :4], dev) for p in poses], 0)
+    images = torch.stack([sphere_image(H, W, K, p[:3, :4], dev, ss=ss) for p in poses], 0)
     i_train, i_test = list(range(1, views)), 0
     near, far = 2.0, 6.0
     if scene_dir is not None:
@@ -76,7 +85,7 @@ def run(steps=600, res=64, views=12, n_rand=1024, seed=0, verbose=True, scene_di
         images = torch.from_numpy(np.ascontiguousarray(imgs_np)).float().to(dev)
         i_train, i_test = list(i_train), int(i_test_arr[0])
         near, far = bds["near"], bds["far"]
-    args = SimpleNamespace(N_rand=n_rand, no_batching=False, lrate=5e-4, lrate_decay=250, netdepth=8, netwidth=256,
+    args = SimpleNamespace(N_rand=n_rand, no_batching=False, lrate=lrate, lrate_decay=250, netdepth=8, netwidth=256,
                            netdepth_fine=8, netwidth_fine=256, N_importance=128, use_viewdirs=True, multires=multires,
                            multires_views=multires_views, i_embed=0)
     coarse, fine = utils.create_nerf_models(args, dev)
@@ -121,5 +130,10 @@ if __name__ == "__main__":
     ap.add_argument("--scene-dir", default=None, help="write the scene in the Blender format here and train from disk")
     ap.add_argument("--multires", type=int, default=10)
     ap.add_argument("--multires-views", type=int, default=4)
+    ap.add_argument("--n-rand", type=int, default=1024)
+    ap.add_argument("--lrate", type=float, default=5e-4)
+    ap.add_argument("--ss", type=int, default=1, help="ss x ss sub-pixel samples per ground-truth pixel")
+    ap.add_argument("--quiet", action="store_true")
     a = ap.parse_args()
-    print(json.dumps(run(a.steps, a.res, a.views, scene_dir=a.scene_dir, multires=a.multires, multires_views=a.multires_views)[0]))
+    print(json.dumps(run(a.steps, a.res, a.views, n_rand=a.n_rand, scene_dir=a.scene_dir, multires=a.multires,
+                         multires_views=a.multires_views, lrate=a.lrate, ss=a.ss, verbose=not a.quiet)[0]))
