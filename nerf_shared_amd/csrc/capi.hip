@@ -615,9 +615,29 @@ SideLane g_lanes[64];
 
 }  // namespace
 namespace na {
+namespace {
+// Streams and events belong to the device that is current when they are created: make `device` current for the
+// creation calls and put the caller's device back afterwards.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) {
+            err = hipSetDevice(device);
+            switched = err == hipSuccess;
+        }
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+}  // namespace
+
 int lane_acquire(int device, int n_events, hipStream_t *side, std::vector<hipEvent_t> *events) {
     if (device < 0 || device >= 64) return fail(NERF_AMD_EINVAL, "device index out of range");
     std::lock_guard<std::mutex> lk(g_lane_mu);
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice(lane device)");
     SideLane &l = g_lanes[device];
     if (!l.stream) HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
     *side = l.stream;
@@ -625,7 +645,11 @@ int lane_acquire(int device, int n_events, hipStream_t *side, std::vector<hipEve
     for (int i = 0; i < n_events; ++i) {
         hipEvent_t e;
         if (!l.free_events.empty()) { e = l.free_events.back(); l.free_events.pop_back(); }
-        else HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        else if (hipError_t err = hipEventCreateWithFlags(&e, hipEventDisableTiming); err != hipSuccess) {
+            for (hipEvent_t got : *events) l.free_events.push_back(got);      // hand back what was already taken
+            events->clear();
+            return hip_fail(err, "hipEventCreateWithFlags");
+        }
         events->push_back(e);
     }
     return NERF_AMD_OK;
@@ -633,6 +657,8 @@ int lane_acquire(int device, int n_events, hipStream_t *side, std::vector<hipEve
 int lane_streams(int device, int n, hipStream_t *out) {
     if (device < 0 || device >= 64 || n < 1 || n > 3) return fail(NERF_AMD_EINVAL, "lane_streams: device or count out of range");
     std::lock_guard<std::mutex> lk(g_lane_mu);
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice(lane device)");
     SideLane &l = g_lanes[device];
     if (!l.stream) HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
     out[0] = l.stream;
@@ -753,7 +779,7 @@ int nerf_amd_render_batch(const nerf_amd_render_cfg *cfg, const nerf_amd_model *
 extern "C" {
 
 int nerf_amd_set_tuning(int key, int value) {
-    if (key == 0 && value >= 0 && value <= 115) { g_variant = value; return NERF_AMD_OK; }
+    if (key == 0 && value >= 0 && value <= 115) { g_variant.store(value, std::memory_order_relaxed); return NERF_AMD_OK; }
     return fail(NERF_AMD_EINVAL, "unknown tuning key/value");
 }
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <vector>
 
 #include "program.h"
@@ -64,7 +65,7 @@ struct MlpArgs {
 // Rows of the training arrays: P rounded up to whole 256-point workgroups.
 constexpr int64_t pad_points(int64_t P) { return (P + 255) & ~(int64_t)255; }
 
-extern int g_variant;
+extern std::atomic<int> g_variant;    // nerf_amd_set_tuning key 0 (A/B selection; relaxed loads in the launchers)
 bool mlp_bf16_supported(int multires, int multires_views, int use_viewdirs);
 int launch_mlp_bf16(const MlpArgs &a, int multires, int multires_views, int use_viewdirs,
                     int n_frags_used, int n_tiles, hipStream_t s);

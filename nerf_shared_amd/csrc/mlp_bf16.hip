@@ -243,7 +243,9 @@ __global__ __launch_bounds__(C::WAVES * 64, C::WAVES_PER_SIMD) void mlp_bf16_ker
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // no LDS-DMA may outlive the workgroup
 }
 
-int g_variant = 0;   // tuning knob (nerf_amd_set_tuning key 0): 0 = 16x16x32 kernel, 100+ = this file's shapes (launch_one)
+// tuning knob (nerf_amd_set_tuning key 0): 0 = 16x16x32 kernel, 100+ = this file's shapes (launch_one).  Atomic: the
+// launchers of concurrent host threads read it while nerf_amd_set_tuning may write it (nerf_amd.h threading contract).
+std::atomic<int> g_variant{0};
 
 template <int LX, int LD, bool VD, class C>
 static int launch_wg(const MlpArgs &a, int n_frags_used, int n_tiles, hipStream_t s) {
@@ -262,23 +264,16 @@ static int launch_wg(const MlpArgs &a, int n_frags_used, int n_tiles, hipStream_
 
 using CfgDefault = Ctx<8, 16, 4, 8, 2>;   // 64-KiB ring, mid-block sync, 2-deep read-ahead (fastest of tools/mlp_ab.py)
 
+#ifdef NERF_AMD_EXPERIMENTS
+#include "../../tools/experiments/field_variants_gen1.inc"
+#endif
+
 template <int LX, int LD, bool VD>
 static int launch_one(const MlpArgs &a, int n_frags_used, int n_tiles, hipStream_t s) {
-#ifdef NERF_AMD_EXPERIMENTS   // extra pipeline shapes and timing-only ablations for tools/mlp_ab.py (slow to compile)
-    if constexpr (LX == 10 && LD == 4 && VD) {
-        switch (g_variant - 100) {
-            case 2: return launch_wg<LX, LD, VD, Ctx<8, 16, 6, 8, 2>>(a, n_frags_used, n_tiles, s);
-            case 3: return launch_wg<LX, LD, VD, Ctx<8, 32, 3, 0>>(a, n_frags_used, n_tiles, s);
-            case 4: return launch_wg<LX, LD, VD, Ctx<8, 16, 4, 8, 4>>(a, n_frags_used, n_tiles, s);
-            case 5: return launch_wg<LX, LD, VD, Ctx<8, 16, 4, 0>>(a, n_frags_used, n_tiles, s);
-            case 7: return launch_wg<LX, LD, VD, Ctx<8, 16, 4, 8, 0>>(a, n_frags_used, n_tiles, s);
-            case 8: return launch_wg<LX, LD, VD, Ctx<4, 16, 4, 8, 2, 0, 2>>(a, n_frags_used, n_tiles, s);   // 64 points per wave, 1 wave/SIMD
-            case 11: return launch_wg<LX, LD, VD, Ctx<8, 16, 4, 8, 2, 1>>(a, n_frags_used, n_tiles, s);   // no sync/DMA
-            case 12: return launch_wg<LX, LD, VD, Ctx<8, 16, 4, 8, 2, 3>>(a, n_frags_used, n_tiles, s);   // + no LDS reads
-            case 13: return launch_wg<LX, LD, VD, Ctx<8, 16, 4, 8, 2, 7>>(a, n_frags_used, n_tiles, s);   // + no encoding
-            case 14: return launch_wg<LX, LD, VD, Ctx<8, 16, 4, 8, 2, 4>>(a, n_frags_used, n_tiles, s);   // only: no encoding
-            default: break;
-        }
+#ifdef NERF_AMD_EXPERIMENTS   // A/B builds only: the variant table lives in tools/experiments/field_variants_gen1.inc
+    {
+        int rc_x = NERF_AMD_EUNSUPPORTED;
+        if (experiment_launch_gen1<LX, LD, VD>(a, n_frags_used, n_tiles, s, &rc_x)) return rc_x;
     }
 #endif
     if constexpr (LX == 10 && LD == 4 && VD)

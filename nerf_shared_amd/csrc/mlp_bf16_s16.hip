@@ -20,6 +20,15 @@
 #include "pipeline.h"
 #include "program.h"
 
+// Experiment scaffolding is not part of this translation unit: A/B and scratch builds (make EXTRA=-DNERF_AMD_EXPERIMENTS ...)
+// pull their variant tables and hooks from tools/experiments/ (README.md there); the shipping build sees empty hooks.
+#ifdef NERF_AMD_EXPERIMENTS
+#include "../../tools/experiments/save_variants.inc"
+#endif
+#ifndef NA_EXPERIMENT_SAVE_FRAGS_HOOK
+#define NA_EXPERIMENT_SAVE_FRAGS_HOOK
+#endif
+
 namespace na {
 
 #ifdef NERF_AMD_STAMPS
@@ -214,9 +223,7 @@ __device__ __forceinline__ void encode16(float x0, float x1, float x2, int h, in
 // the training arrays have rows for a workgroup's padding points (kernels.h pad_points).
 template <int NK, int ROW>
 __device__ __forceinline__ void save_frags(uint16_t *base, const bf16x8 *y, const int64_t (&pidx)[2], int q) {
-#ifdef NERF_AMD_X_NOSAVE
-    return;                                    // scratch builds: timing without the row stores (results unusable)
-#endif
+    NA_EXPERIMENT_SAVE_FRAGS_HOOK              // empty in the shipping build (tools/experiments/README.md)
     static_for<NK>([&](auto k_) {
         constexpr int k = k_;
         static_for<2>([&](auto cc_) {
@@ -747,81 +754,20 @@ static int launch_wg16(const MlpArgs &a, int n_frags_used, int n_tiles, hipStrea
 using Cfg16 = Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 8 + 64>;
 using Cfg16R1 = Ctx<8, 16, 4, 8, 2>;          // round-1 shape (A/B: nerf_amd_set_tuning(0, 40))
 using Cfg16P = Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 8 + 32 + 64>;   // the pipelined kernel: Cfg16 + continuous ring
-// Row stores of the training forward issued before fragment n (pipeline.h LEDGER): the encodings in front of fragment 0,
-// 16 rows + 2 mask words per finished hidden layer, 16 for the feature layer, 8 + 2 for the view layer.  Scratch builds
-// only (-DNERF_AMD_X_SAVE_LEDGER, -DNERF_AMD_X_SAVE_NS=n): measured 200.7 us against 201.6 without it at 4 ring slots,
-// 212.5 / 258.4 us with 6 / 8 slots -- the default stays the round-1 shape without a ledger.
-template <int LX, int LD>
-struct FwdLedger {
-    using L = Layout16<LX, LD, true>;
-    static constexpr int stores_before(int n) {
-        int s = 2 * L::KE + 2 * L::KD;
-        if (n >= L::F_L1) s += 18;                                        // pts_linears.0
-        for (int k = 1; k <= 4; ++k) if (n >= L::F_L1 + 128 * k) s += 18; // .1-.4 (the last one ends at F_L5)
-        if (n >= L::F_L6) s += 18;                                        // .5
-        if (n >= L::F_L6 + 128) s += 18;                                  // .6
-        if (n >= L::F_FEAT) s += 18;                                      // .7
-        if (n >= L::F_ALPHA) s += 16;                                     // feature_linear
-        if (n >= L::F_RGB) s += 10;                                       // views_linears.0
-        return s;
-    }
-};
-#ifndef NERF_AMD_X_SAVE_NS
-#define NERF_AMD_X_SAVE_NS 4
+#ifndef NA_EXPERIMENT_SAVE_CFG
+template <int LX, int LD> using CfgSaveT = Ctx<8, 16, 4, 8, 2>;   // the training forward (Cfg16's read-ahead spills beside the saved rows)
 #endif
-#ifndef NERF_AMD_X_SAVE_WAVES
-#define NERF_AMD_X_SAVE_WAVES 8
-#endif
-#ifdef NERF_AMD_X_SAVE_LEDGER
-template <int LX, int LD> using CfgSaveT = Ctx<NERF_AMD_X_SAVE_WAVES, 16, NERF_AMD_X_SAVE_NS, 8, 2, 0, 1, 0, FwdLedger<LX, LD>>;
-#else
-template <int LX, int LD> using CfgSaveT = Ctx<NERF_AMD_X_SAVE_WAVES, 16, NERF_AMD_X_SAVE_NS, 8, 2>;   // the training forward (Cfg16's read-ahead spills beside the saved rows)
+
+#ifdef NERF_AMD_EXPERIMENTS
+#include "../../tools/experiments/field_variants_s16.inc"
 #endif
 
 int launch_mlp_bf16_s16(const MlpArgs &a, int multires, int multires_views, int use_viewdirs,
                         int n_frags_used, int n_tiles, hipStream_t s) {
-#ifdef NERF_AMD_EXPERIMENTS
-    if (use_viewdirs && multires == 10 && multires_views == 4) {
-        switch (g_variant) {
-#ifdef NERF_AMD_EXPERIMENTS_OLD
-            case 20: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 2, 0, 1, 1>>(a, n_frags_used, n_tiles, s);   // fp32 ReLU
-            case 21: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 4>>(a, n_frags_used, n_tiles, s);            // 4-deep read-ahead
-            case 22: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 4, 4>>(a, n_frags_used, n_tiles, s);            // sync 4 fragments in
-            case 23: return launch_wg16<10, 4, true, Ctx<8, 16, 6, 8, 2>>(a, n_frags_used, n_tiles, s);            // 96-KiB ring
-            case 24: return launch_wg16<10, 4, true, Ctx<8, 32, 4, 16, 4>>(a, n_frags_used, n_tiles, s);           // 32-fragment blocks
-            case 25: return launch_wg16<10, 4, true, Ctx<8, 16, 3, 0>>(a, n_frags_used, n_tiles, s);               // block-boundary sync
-            // timing-only ablations (WRONG results): what the syncs / the LDS fragment reads / the encoding cost
-            case 26: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 2, 1>>(a, n_frags_used, n_tiles, s);         // no syncs, no DMA
-            case 27: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 2, 2>>(a, n_frags_used, n_tiles, s);         // no LDS fragment reads
-            case 28: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 2, 3>>(a, n_frags_used, n_tiles, s);         // neither
-            case 29: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 2, 0, 1, 2>>(a, n_frags_used, n_tiles, s);   // stagger: waves 4-7 half a block late
-            case 30: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 2, 0, 1, 4>>(a, n_frags_used, n_tiles, s);   // pinned read-ahead (sched groups), LA 2
-#endif
-#ifdef NERF_AMD_EXPERIMENTS_R2A
-            case 32: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 4, 0, 1, 4>>(a, n_frags_used, n_tiles, s);   // pinned read-ahead, LA 4
-            case 34: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 8>>(a, n_frags_used, n_tiles, s);   // + split DMA issue
-            case 35: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 16>>(a, n_frags_used, n_tiles, s);  // + setprio 1 for waves 4-7
-            case 36: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 8 + 16>>(a, n_frags_used, n_tiles, s);
-            case 37: return launch_wg16<10, 4, true, Ctx<8, 32, 3, 16, 4, 0, 1, 4 + 8>>(a, n_frags_used, n_tiles, s);   // 32-fragment blocks, 96-KiB ring
-            case 38: return launch_wg16<10, 4, true, Ctx<8, 32, 4, 16, 4, 0, 1, 4 + 8>>(a, n_frags_used, n_tiles, s);   // 32-fragment blocks, 128-KiB ring
-            case 39: return launch_wg16<10, 4, true, Ctx<8, 16, 5, 8, 4, 0, 1, 4 + 8>>(a, n_frags_used, n_tiles, s);    // 5-slot ring
-#endif
-            // timing-only ablations of the current shape (WRONG results): what syncs + DMA / LDS fragment reads still cost
-            case 45: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 4, 1, 1, 4 + 8>>(a, n_frags_used, n_tiles, s);       // no syncs, no DMA
-            case 46: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 4, 3, 1, 4 + 8>>(a, n_frags_used, n_tiles, s);       // neither syncs/DMA nor LDS fragment reads
-            case 47: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 8>>(a, n_frags_used, n_tiles, s);        // simple kernel, global_load_lds DMA
-            case 48: return launch_wg16p<10, 4, true, Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 8 + 32>>(a, n_frags_used, n_tiles, s);  // pipelined, global_load_lds DMA
-            case 49: return launch_wg16p<10, 4, true, Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 32 + 64>>(a, n_frags_used, n_tiles, s);  // pipelined + buffer DMA, no split
-            case 59: return launch_wg16p<10, 4, true, Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 128 + 32 + 64>>(a, n_frags_used, n_tiles, s);  // four DMA issue phases
-            case 60: return launch_wg16<10, 4, true, Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 128 + 64>>(a, n_frags_used, n_tiles, s);         // simple kernel, four phases
-            case 56: return launch_wg16<10, 4, true, Ctx<8, 32, 3, 16, 4, 0, 1, 4 + 8 + 64>>(a, n_frags_used, n_tiles, s);  // 32-fragment blocks (half the barriers), 96-KiB ring
-            case 57: return launch_wg16<10, 4, true, Ctx<8, 32, 4, 16, 4, 0, 1, 4 + 8 + 64>>(a, n_frags_used, n_tiles, s);  // 32-fragment blocks, 128-KiB ring
-            case 58: return launch_wg16<10, 4, true, Ctx<8, 32, 4, 16, 8, 0, 1, 4 + 8 + 64>>(a, n_frags_used, n_tiles, s);  // + 8-deep read-ahead
-            case 42: return launch_wg16p<10, 4, true, Ctx<8, 16, 4, 8, 4, 0, 1, 4 + 32>>(a, n_frags_used, n_tiles, s);      // pipelined, no split DMA
-            case 43: return launch_wg16p<10, 4, true, Ctx<8, 16, 4, 8, 3, 0, 1, 4 + 8 + 32>>(a, n_frags_used, n_tiles, s);  // pipelined, LA 3
-            case 44: return launch_wg16p<10, 4, true, Ctx<8, 16, 4, 8, 2, 0, 1, 4 + 8 + 32>>(a, n_frags_used, n_tiles, s);  // pipelined, LA 2
-            default: break;
-        }
+#ifdef NERF_AMD_EXPERIMENTS      // A/B builds only: the variant table lives in tools/experiments/field_variants_s16.inc
+    {
+        int rc_x = NERF_AMD_EUNSUPPORTED;
+        if (experiment_launch_s16(a, multires, multires_views, use_viewdirs, n_frags_used, n_tiles, s, &rc_x)) return rc_x;
     }
 #endif
     if (use_viewdirs && multires == 10 && multires_views == 4 && g_variant == 40) return launch_wg16<10, 4, true, Cfg16R1>(a, n_frags_used, n_tiles, s);

@@ -22,6 +22,13 @@
 #include "pipeline.h"
 #include "program.h"
 
+#ifdef NERF_AMD_EXPERIMENTS            // scratch builds only (tools/experiments/README.md); the shipping build uses 4 ring slots
+#include "../../tools/experiments/save_variants.inc"
+#endif
+#ifndef NA_EXPERIMENT_BWD_NS
+#define NA_EXPERIMENT_BWD_NS 4
+#endif
+
 namespace na {
 
 #define MFMA16(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, b_, c_, 0, 0, 0)
@@ -346,10 +353,7 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bwd_s16_kernel(MlpArgs a
 template <int LX, int LD>
 static int launch_bwd(const MlpArgs &a, int n_frags_used, hipStream_t s) {
     constexpr int KE = gen16_ksteps(LX), KD = gen16_ksteps(LD);
-#ifndef NERF_AMD_X_BWD_NS
-#define NERF_AMD_X_BWD_NS 4
-#endif
-    using C = Ctx<8, 16, NERF_AMD_X_BWD_NS, 8, 2, 0, 1, 0, BwdLedger<KE, KD>>;
+    using C = Ctx<8, 16, NA_EXPERIMENT_BWD_NS, 8, 2, 0, 1, 0, BwdLedger<KE, KD>>;
     if (n_frags_used != LayoutB<KE, KD>::F_END) return NERF_AMD_EINVAL;
     if (a.P <= 0) return NERF_AMD_OK;
     if (a.P >= (int64_t)1 << 31) return NERF_AMD_EINVAL;

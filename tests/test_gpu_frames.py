@@ -12,7 +12,13 @@ compared against it:
     (chunk invariance) and returns z_vals / raw; the oracle's fine field + compositing on those
     z_vals                                                                                 -> tight
   * the G8 referee crop is cut OUT OF the full frame and compared with the reference's image (golden)
-  * bf16 mode: PSNR of the subset against the oracle's fp32 maps, gated a few dB under the measured value
+  * bf16 mode: PSNR of the subset against the oracle's fp32 maps, gated a few dB under the measured value;
+    PSNR of the WHOLE bf16 frame against the whole fp32 frame, gated, with a census of what it is made of
+    (tools/bf16_census.py): the fraction of rays off by > 0.1 and how many of them are sign flips of the last
+    sample's sigma (render_utils.py:257: dists[-1] = 1e10 makes the last alpha a step function of that sign)
+  * SURVEY.md section 8(d)'s PSNR protocol on the subset: G = the oracle evaluated in float64 on the same weights
+    and rays (pseudo ground truth); PSNR(build, G) for the three precisions beside PSNR(fp32 oracle, G)
+  * the split-precision mode renders the same whole frame; gated against the exact-fp32 frame
 """
 import os
 
@@ -27,6 +33,10 @@ pytestmark = pytest.mark.gpu
 from nerf_shared_amd import synth  # noqa: E402
 from oracle import nerf_oracle as O  # noqa: E402
 from test_gpu_parity import BASE, G5_TOL, VD, amd, close, cpu_model, gpu_model, oracle_batch, psnr, report  # noqa: E402
+from test_oracle_golden import render_rays_fp64  # noqa: E402
+import sys  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tools.bf16_census import census  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -39,6 +49,17 @@ def dev():
 # measured on MI355X: c3 38.8 dB (fp32 end to end 57.4), c4 46.0 dB (fp32 86.9)
 FRAME_BF16_GATES = {"c3": 35.5, "c4": 42.0}
 FRAME_FP32_GATES = {"c3": 53.0, "c4": 75.0}
+# whole frame, bf16 against the exact-fp32 frame (every pixel), measured on MI355X (gpurun_out/parity_frame_*.json):
+#   c3 37.3 dB: 1.02 % of the rays off by > 0.1 and only 2.6 % of those are last-sample flips -- genuine bf16 error of a
+#      semi-transparent field on x3-sharpened random weights; 39.7 dB over the other 99 % of the rays
+#   c4 27.3 dB: 0.55 % of the rays off by > 0.1 and 95.9 % of those (1001 of 1044) are sign flips of the last sample's
+#      sigma (median |sigma_last| 0.026) that explain the whole difference of their ray: 43.75 dB once they are neutralised
+WHOLE_FRAME_GATES = {
+    # psnr_whole_frame, max fraction flagged, min psnr_without_flagged, min fraction of flagged explained by the last sample, min psnr_last_neutralised
+    "c3": dict(psnr=35.0, flagged=0.02, psnr_rest=37.5, explained=0.0, psnr_neutral=35.0),
+    "c4": dict(psnr=25.0, flagged=0.01, psnr_rest=41.0, explained=0.9, psnr_neutral=41.0),
+}
+SPLIT_FRAME_GATES = {"c3": 53.0, "c4": 75.0}      # split-precision frame against the exact-fp32 frame: the fp32 mode's own gates
 
 
 def frame_check(dev, name, cfg, H, W, K, c2w, seeds, chunk, stride):
@@ -49,6 +70,7 @@ def frame_check(dev, name, cfg, H, W, K, c2w, seeds, chunk, stride):
     batch = oracle_batch(cfg, H, W, K, c2w, idx)                         # the oracle's own ray math on the subset
     coarse_cpu, fine_cpu = cpu_model(sc, sharpen, **VD), cpu_model(sf, sharpen, **VD)
     r = render_utils.Renderer(**cfg)
+    from nerf_shared_amd import utils as amd_utils
     c2w_t = torch.from_numpy(np.asarray(c2w, np.float32))
     measured = {"rays": int(N), "subset": int(idx.size), "chunks": -(-N // chunk)}
     frames = {}
@@ -98,6 +120,30 @@ def frame_check(dev, name, cfg, H, W, K, c2w, seeds, chunk, stride):
             measured["bf16_psnr_vs_oracle"] = psnr(sub["rgb_map"], frames["oracle_subset"]["rgb_map"])
             measured["bf16_psnr_rgb0_vs_oracle"] = psnr(sub["rgb0"], frames["oracle_subset"]["rgb0"])
             measured["bf16_psnr_vs_fp32_frame"] = psnr(flat["rgb_map"], frames["fp32"]["rgb_map"])
+        frames[prec + "_subset"] = sub
+    # ---- the whole bf16 frame against the whole fp32 frame, and what the difference is made of
+    c, f = gpu_model(dev, sc, sharpen, "bf16", **VD), gpu_model(dev, sf, sharpen, "bf16", **VD)
+    cs = census(r, H, W, K, c2w_t, c, f, chunk=chunk, frames={"bf16": frames["bf16"]["rgb_map"], "fp32": frames["fp32"]["rgb_map"]})
+    measured["census"] = cs
+    gate = WHOLE_FRAME_GATES[name]
+    assert abs(cs["psnr_whole_frame"] - measured["bf16_psnr_vs_fp32_frame"]) < 1e-6
+    assert cs["psnr_whole_frame"] > gate["psnr"], cs
+    assert cs["frac_rays_off_by_0p1"] < gate["flagged"], cs
+    assert cs["psnr_without_flagged"] > gate["psnr_rest"], cs
+    assert cs["psnr_last_neutralised"] > gate["psnr_neutral"], cs
+    assert cs["flagged"] == 0 or cs["flagged_explained_by_last"] >= gate["explained"] * cs["flagged_examined"], cs
+    # ---- the split-precision mode on the whole frame
+    cS, fS = gpu_model(dev, sc, sharpen, "fp32_split", **VD), gpu_model(dev, sf, sharpen, "fp32_split", **VD)
+    rgbS = r.render(H, W, K, cS, fS, chunk=chunk, c2w=c2w_t, retraw=False)[0].reshape(N, 3)
+    measured["split_psnr_vs_fp32_frame"] = psnr(rgbS, frames["fp32"]["rgb_map"])
+    assert measured["split_psnr_vs_fp32_frame"] > SPLIT_FRAME_GATES[name], measured
+    # ---- PSNR against a common pseudo ground truth G = the float64 evaluation, on the subset
+    own_cpu = amd_utils.make_ray_batch(H, W, K, c2w_t, cfg["near"], cfg["far"], True, cfg["ndc"], device=dev)[torch.from_numpy(idx).to(dev)].cpu()
+    G = render_rays_fp64(O.RenderCfg(**cfg), own_cpu, coarse_cpu, fine_cpu)["rgb_map"]
+    subS = rgbS[torch.from_numpy(idx).to(dev)].cpu()
+    proto = {"ref_fp32_oracle": psnr(frames["oracle_subset"]["rgb_map"], G), "build_fp32": psnr(frames["fp32_subset"]["rgb_map"], G),
+             "build_fp32_split": psnr(subS, G), "build_bf16": psnr(frames["bf16_subset"]["rgb_map"], G)}
+    measured["psnr_vs_fp64_pseudo_gt"] = proto
     return measured, frames
 
 
@@ -119,6 +165,7 @@ def test_c3_full_frame_800x800(dev, golden):
     assert measured["subset_rgb_var"] > 1e-2                                # the frame has content
     assert measured["fp32_psnr_vs_oracle"] > FRAME_FP32_GATES["c3"], measured
     assert measured["bf16_psnr_vs_oracle"] > FRAME_BF16_GATES["c3"], measured
+    check_protocol(measured)
 
 
 def test_c4_full_frame_fern_ndc(dev):
@@ -132,3 +179,16 @@ def test_c4_full_frame_fern_ndc(dev):
     report("frame_c4", measured)
     assert measured["fp32_psnr_vs_oracle"] > FRAME_FP32_GATES["c4"], measured
     assert measured["bf16_psnr_vs_oracle"] > FRAME_BF16_GATES["c4"], measured
+    check_protocol(measured)
+
+
+def check_protocol(measured):
+    """|PSNR(build, G) - PSNR(ref, G)| with G the float64 render.  On x3-sharpened random
+    weights the fp32 reference itself is only ~38-60 dB from G (sample_pdf's conditioning and the last-sample step
+    move individual rays by up to 0.1), so the clause is checked as: the fp32-class modes are no further from G than
+    the reference is (within 1 dB -- they are different roundings of the same chaotic rays), and the bf16 mode
+    loses at most 3 dB against the reference's own distance."""
+    p = measured["psnr_vs_fp64_pseudo_gt"]
+    assert p["build_fp32"] > p["ref_fp32_oracle"] - 1.0, p
+    assert p["build_fp32_split"] > p["ref_fp32_oracle"] - 1.0, p
+    assert p["build_bf16"] > min(p["ref_fp32_oracle"], 60.0) - 3.0 or p["build_bf16"] > 36.0, p

@@ -206,3 +206,48 @@ def test_g8_psnr_crop(golden):
         assert psnr > 100.0
     # the referee legs have content: a constant image would make any PSNR gate vacuous
     assert g["rgb_c19"].var() > 1e-2 and g["rgb_c12"].var() > 1e-2 and g["acc_c12"].var() > 1e-2
+
+
+def render_rays_fp64(cfg, batch, coarse, fine, **kw):
+    """The oracle evaluated in float64 on the same fp32 weights and rays: the pseudo ground truth of SURVEY.md section
+    8(d)'s PSNR protocol, and the yardstick for how much of an end-to-end difference is the reference's own rounding."""
+    to64 = lambda m: ({k: v.double() for k, v in m[0].items()}, m[1])       # noqa: E731
+    torch.set_default_dtype(torch.float64)
+    try:
+        return O.render_rays(cfg, batch.double(), to64(coarse), to64(fine) if fine is not None else None, **kw)
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
+def test_fraction_gates_sit_at_the_references_own_rounding_floor(golden):
+    """Calibration of the end-to-end fp32 gates of tests/test_gpu_parity.py (fine maps: >= 85-90 % of the elements within
+    2e-4, max 5e-2).  sample_pdf divides ~1e-7 cdf differences by bin masses down to 1e-5 (utils.py:110-113), so ANY
+    rounding-level change of the coarse weights moves some fine samples.  How far does the reference itself move?
+      * not at all with the thread count: the oracle on 1 and on 8 torch threads is bit-identical here, so that is no
+        perturbation to calibrate against;
+      * against its own float64 evaluation (same weights, same rays) on the content case det_c19: only ~85 % of the
+        rgb_map elements and ~90 % of acc / disp stay within 2e-4, the worst ray moves by 3e-2 -- while the coarse maps,
+        which no resampling precedes, agree to 4e-5.
+    The gates therefore sit at the floor fp32 arithmetic sets; the staged tests are what pins the kernels tightly."""
+    g = golden("g5_render_rays")
+    cfg = O.RenderCfg(perturb=0.0, N_importance=128, N_samples=64, use_viewdirs=True, white_bkgd=True, raw_noise_std=0.0,
+                      ndc=False, lindisp=False, near=2.0, far=6.0)
+    batch = torch.from_numpy(g["det_c19__batch"])
+    coarse, fine = model(1, 3.0, **VD), model(19, 3.0, **VD)
+    was = torch.get_num_threads()
+    try:
+        outs = []
+        for nt in (1, max(2, min(8, was))):
+            torch.set_num_threads(nt)
+            outs.append(O.render_rays(cfg, batch, coarse, fine, retweights=True))
+    finally:
+        torch.set_num_threads(was)
+    for k in outs[0]:
+        assert torch.equal(torch.nan_to_num(outs[0][k]), torch.nan_to_num(outs[1][k])), k
+    o64 = render_rays_fp64(cfg, batch, coarse, fine, retweights=True)
+    frac = {k: float(((outs[0][k].double() - o64[k]).abs() <= 2e-4).double().mean()) for k in ("rgb_map", "acc_map", "disp_map", "rgb0")}
+    worst = float((outs[0]["rgb_map"].double() - o64["rgb_map"]).abs().max())
+    print("fp32 reference vs its float64 evaluation:", frac, "max |rgb|", worst)
+    assert frac["rgb0"] == 1.0 and float((outs[0]["rgb0"].double() - o64["rgb0"]).abs().max()) < 1e-4
+    assert 0.75 < frac["rgb_map"] < 0.93 and 0.8 < frac["acc_map"] < 0.97 and 0.8 < frac["disp_map"] < 0.97, frac
+    assert 5e-3 < worst < 0.2, worst
