@@ -15,7 +15,14 @@
 #include "launch_util.h"
 #include "program.h"
 
+#include <utility>
+
 namespace na {
+
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_dw_impl(F &&f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for_dw(F &&f) { static_for_dw_impl(f, std::make_integer_sequence<int, N>{}); }
 
 enum { PERM_NAT = 0, PERM_ACC = 1, PERM_GEN = 2 };
 
@@ -35,7 +42,8 @@ struct DwArgs {
     const uint16_t *G; int ldg;          // [P, ldg] bf16 gradient rows, columns [0, 16*OT) used
     const uint16_t *X; int ldx;          // [P, ldx] bf16 activation rows, columns [0, 16*IT) used
     int64_t P;
-    float *slab;                         // per-workgroup partial results: [grid][OT*IT*256 + OT*16] fp32
+    float *slab;                         // per-workgroup partial results: [grid][OT*IT*256 + OT*16 (+ IT*256 + 16 with a head)] fp32
+    const uint16_t *H;                   // head gradients transposed inside 32-point chunks (kernels.h g_rawt), or NULL
 };
 
 struct DwReduceArgs {
@@ -43,7 +51,44 @@ struct DwReduceArgs {
     float *dW; int ld_dw, col_off;       // nn.Linear weight gradient [n_out][ld_dw], written at column col_off + feature
     float *db;                           // bias gradient [n_out] or NULL
     int out_kind, in_kind, in_L, n_valid, m_valid;
+    // a head product riding on this job (same X): one more 16-row tile whose rows are the columns of dL/draw; rows
+    // [head_row0, head_row0 + head_rows) of it are the head's weight gradient [head_rows][head_ld] (+ bias gradient)
+    int HT;                              // 0 or 1
+    float *head_dW, *head_db;
+    int head_row0, head_rows, head_ld;
 };
+__host__ __device__ inline int dw_slab_floats(int OT, int IT, int HT) { return OT * IT * 256 + OT * 16 + HT * (IT * 256 + 16); }
+
+// Element e of a job's summed slabs -> its place in the nn.Linear gradients.
+__device__ __forceinline__ void dw_scatter(const DwReduceArgs &a, int e, float acc) {
+    const int n_main = a.OT * a.IT * 256;
+    if (e < n_main) {
+        const int r = e & 3, lane = (e >> 2) & 63, tile = e >> 8;
+        const int to = tile / a.IT, ti = tile - to * a.IT;
+        const int o = slot_to_feature(a.out_kind, to * 16 + 4 * (lane >> 4) + r, 0);
+        const int i = slot_to_feature(a.in_kind, ti * 16 + (lane & 15), a.in_L);
+        if (i >= 0 && o >= 0 && i < a.m_valid && o < a.n_valid) a.dW[(int64_t)o * a.ld_dw + a.col_off + i] = acc;
+        return;
+    }
+    e -= n_main;
+    if (e < a.OT * 16) {
+        if (a.db) {
+            const int o = slot_to_feature(a.out_kind, e, 0);
+            if (o >= 0 && o < a.n_valid) a.db[o] = acc;
+        }
+        return;
+    }
+    e -= a.OT * 16;                      // head part: IT tiles (rows = columns of dL/draw, natural order), then 16 bias sums
+    if (e < a.IT * 256) {
+        const int r = e & 3, lane = (e >> 2) & 63, ti = e >> 8;
+        const int row = 4 * (lane >> 4) + r - a.head_row0;
+        const int i = slot_to_feature(a.in_kind, ti * 16 + (lane & 15), a.in_L);
+        if (row >= 0 && row < a.head_rows && i >= 0 && i < a.m_valid) a.head_dW[(int64_t)row * a.head_ld + i] = acc;
+    } else {
+        const int row = e - a.IT * 256 - a.head_row0;
+        if (row >= 0 && row < a.head_rows) a.head_db[row] = acc;
+    }
+}
 
 __device__ __forceinline__ bf16x8 tr_frag(const char *img, int row_stride, int col0, int lane) {
     // 8 consecutive image rows (points 8g..8g+7) of column col0 + (lane & 15), as an MFMA 16x16x32 operand.
@@ -168,7 +213,7 @@ __global__ __launch_bounds__(512) void dw_kernel(DwArgs a) {
 // 64 elements per block; the slabs are split four ways over the block's waves (more loads in flight).
 __global__ __launch_bounds__(256) void dw_reduce_kernel(DwReduceArgs a) {
     __shared__ float part[4][64];
-    const int per = a.OT * a.IT * 256 + a.OT * 16;
+    const int per = dw_slab_floats(a.OT, a.IT, a.HT);
     const int t = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + t;
     float acc = 0.f;
@@ -180,16 +225,7 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(DwReduceArgs a) {
     __syncthreads();
     if (grp != 0 || e >= per) return;
     acc = part[0][t] + part[1][t] + part[2][t] + part[3][t];
-    if (e < a.OT * a.IT * 256) {
-        const int r = e & 3, lane = (e >> 2) & 63, tile = e >> 8;
-        const int to = tile / a.IT, ti = tile - to * a.IT;
-        const int o = slot_to_feature(a.out_kind, to * 16 + 4 * (lane >> 4) + r, 0);
-        const int i = slot_to_feature(a.in_kind, ti * 16 + (lane & 15), a.in_L);
-        if (i >= 0 && o >= 0 && i < a.m_valid && o < a.n_valid) a.dW[(int64_t)o * a.ld_dw + a.col_off + i] = acc;
-    } else if (a.db) {
-        const int o = slot_to_feature(a.out_kind, e - a.OT * a.IT * 256, 0);
-        if (o >= 0 && o < a.n_valid) a.db[o] = acc;
-    }
+    dw_scatter(a, e, acc);
 }
 
 
@@ -259,7 +295,7 @@ __device__ __forceinline__ void dma_piece(const char *g, uint32_t lds_base) {
 
 __device__ __forceinline__ void dw_reduce_block(const DwReduceArgs &a, int block, int tid, float *part /* [8][64] LDS */) {
     // 64 elements of the summed register dumps per job; the slabs are split eight ways over the block's waves
-    const int per = a.OT * a.IT * 256 + a.OT * 16;
+    const int per = dw_slab_floats(a.OT, a.IT, a.HT);
     const int t = tid & 63, grp = tid >> 6;
     const int e = block * 64 + t;
     float acc = 0.f;
@@ -272,16 +308,7 @@ __device__ __forceinline__ void dw_reduce_block(const DwReduceArgs &a, int block
     if (grp != 0 || e >= per) return;
 #pragma unroll
     for (int k = 1; k < 8; ++k) acc += part[k * 64 + t];
-    if (e < a.OT * a.IT * 256) {
-        const int r = e & 3, lane = (e >> 2) & 63, tile = e >> 8;
-        const int to = tile / a.IT, ti = tile - to * a.IT;
-        const int o = slot_to_feature(a.out_kind, to * 16 + 4 * (lane >> 4) + r, 0);
-        const int i = slot_to_feature(a.in_kind, ti * 16 + (lane & 15), a.in_L);
-        if (i >= 0 && o >= 0 && i < a.m_valid && o < a.n_valid) a.dW[(int64_t)o * a.ld_dw + a.col_off + i] = acc;
-    } else if (a.db) {
-        const int o = slot_to_feature(a.out_kind, e - a.OT * a.IT * 256, 0);
-        if (o >= 0 && o < a.n_valid) a.db[o] = acc;
-    }
+    dw_scatter(a, e, acc);
 }
 
 __global__ __launch_bounds__(512) void dw_reduce8_kernel(DwReduceArgs a) {
@@ -289,18 +316,26 @@ __global__ __launch_bounds__(512) void dw_reduce8_kernel(DwReduceArgs a) {
     dw_reduce_block(a, blockIdx.x, threadIdx.x, part);
 }
 
-template <int OT, int IT, int WO, int WI>
+// HEAD: a head product (alpha_linear / rgb_linear: G = columns of dL/draw) rides on this job -- same X, one more 16-row
+// A operand per chunk.  Its operand needs no transposing read: the dX-chain kernel left dL/draw transposed inside 32-point
+// chunks (kernels.h g_rawt), 16 bytes per (point group, column) = one lane's MFMA A operand, so wave 0 moves the chunk's
+// 256 bytes into the ring slot with one more LDS-DMA instruction (lanes whose row is not a column of dL/draw fetch a valid
+// 16 bytes too and are zeroed after the LDS read) and every wave reads its operand back with one ds_read_b128.  The 16
+// head x X tiles are dealt two to a wave.
+template <int OT, int IT, int WO, int WI, bool HEAD = false>
 __device__ __forceinline__ void dw2_body(const DwArgs &a, const int wg, const int nwg) {
     static_assert(WO * WI == 8 && OT % WO == 0 && IT % WI == 0 && OT >= 4 && IT >= 2, "bad shape");
     constexpr int TO = OT / WO, TI = IT / WI;
+    static_assert(!HEAD || TI == 2 * WO, "the head's X tiles are dealt two to a wave");
     constexpr int RG = OT * 32, RX = IT * 32;                   // row bytes (unpadded)
     constexpr int PG = OT * 2, PX = IT * 2;                     // 16-byte pieces per row
-    constexpr int IMG = 32 * (RG + RX);                         // one chunk's image
+    constexpr int IMG_GX = 32 * (RG + RX);                      // G and X rows of one chunk
+    constexpr int IMG = IMG_GX + (HEAD ? 1024 : 0);             // one chunk's image (+ the head operand)
     constexpr int NI = OT + IT, CNT = (NI + 7) / 8;             // 1-KiB DMA instructions per chunk; per wave (the last ones may repeat)
     // ring slots: what fits in 128 KiB, at least 4 and at most 12 -- a narrow product keeps as many BYTES in flight as a
     // wide one (a workgroup's rate is bytes in flight / latency, and the one-launch path shares the CUs by bytes)
     constexpr int NS = DW2_NS(OT, IT);
-    static_assert((NS - 2) * CNT <= 63, "vmcnt field is 6 bits");
+    static_assert((NS - 2) * (CNT + (HEAD ? 1 : 0)) <= 63, "vmcnt field is 6 bits");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -331,9 +366,14 @@ __device__ __forceinline__ void dw2_body(const DwArgs &a, const int wg, const in
             src += (pos ^ (is_g ? dw_swz<PG>(r) : dw_swz<PX>(r))) << 4;
             dma_piece(src, slot + (is_g ? 0 : 32 * RG) + 1024 * jj);
         }
+        if constexpr (HEAD) {
+            if (wave == 0)                                      // the chunk's head operand: lane (i, g) <- 16 bytes of (group g, column i & 3)
+                dma_piece(reinterpret_cast<const char *>(a.H) + ch * 256 + ((lane >> 4) * 4 + (lane & 3)) * 16, slot + IMG_GX);
+        }
     };
 
     f32x4 acc[TO][TI], accb[TO];
+    f32x4 acch[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, acchb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int x = 0; x < TO; ++x) {
         accb[x] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -350,7 +390,8 @@ __device__ __forceinline__ void dw2_body(const DwArgs &a, const int wg, const in
         for (int64_t i = 0; i < n_local; ++i) {
             // chunk i has landed (this wave's pieces; chunks i+1, i+2 stay in flight), everyone agrees, then the slot of
             // chunk i-1 -- which every wave finished reading before it came here -- is refilled with chunk i+3
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * CNT) : "memory");
+            if (HEAD && wave == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * (CNT + 1)) : "memory");   // wave 0 issues one more piece per chunk
+            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * CNT) : "memory");
             issue_chunk(i + NS - 1);
             const uint32_t gimg = ring + (uint32_t)(i % NS) * IMG, ximg = gimg + 32 * RG;
             const int64_t ch = wg + i * nwg;
@@ -375,11 +416,24 @@ __device__ __forceinline__ void dw2_body(const DwArgs &a, const int wg, const in
                     acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[x], B[y], acc[x][y], 0, 0, 0);
                 if (wi == 0) accb[x] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[x], ones, accb[x], 0, 0, 0);
             }
+            if constexpr (HEAD) {
+                typedef __attribute__((address_space(3))) const bf16x8 lds_bf16x8;
+                bf16x8 Ah = *(lds_bf16x8 *)(uintptr_t)(gimg + IMG_GX + lane * 16);
+                if ((lane & 15) >= 4) Ah = bf16x8{};            // rows 4..15 of the head tile do not exist
+                static_for_dw<WO>([&](auto x_) {                // this wave's two X tiles: 2 wo, 2 wo + 1 of its TI
+                    constexpr int x = x_;
+                    if (wo == x) {
+                        acch[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, B[2 * x], acch[0], 0, 0, 0);
+                        acch[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, B[2 * x + 1], acch[1], 0, 0, 0);
+                    }
+                });
+                if (wave == 0) acchb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, ones, acchb, 0, 0, 0);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the trailing re-reads: no DMA may outlive the workgroup
     }
     // ---- this workgroup's partial tile as a register dump (1 KiB per 16x16 tile, fully coalesced) + the bias partials
-    float *slab = a.slab + (int64_t)wg * (OT * IT * 256 + OT * 16);
+    float *slab = a.slab + (int64_t)wg * dw_slab_floats(OT, IT, HEAD ? 1 : 0);
 #pragma unroll
     for (int x = 0; x < TO; ++x)
 #pragma unroll
@@ -390,6 +444,65 @@ __device__ __forceinline__ void dw2_body(const DwArgs &a, const int wg, const in
         for (int x = 0; x < TO; ++x)
             *reinterpret_cast<f32x4 *>(slab + OT * IT * 256 + (wo * TO + x) * 16 + 4 * (lane >> 4)) = accb[x];
     }
+    if constexpr (HEAD) {                                       // head tiles behind the main part: [IT][64 lanes][4], then 16 bias sums
+        float *hs = slab + OT * IT * 256 + OT * 16;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            *reinterpret_cast<f32x4 *>(hs + ((wi * TI + 2 * wo + t) * 64 + lane) * 4) = acch[t];
+        if (wave == 0 && (lane & 15) == 0) *reinterpret_cast<f32x4 *>(hs + IT * 256 + 4 * (lane >> 4)) = acchb;
+    }
+}
+
+// A head product alone (rgb_linear: nothing else multiplies the view layer's output): X rows only in the ring, the head
+// operand as in dw2_body, one X tile per wave.
+template <int IT>
+__device__ __forceinline__ void dw_head_body(const DwArgs &a, const int wg, const int nwg) {
+    static_assert(IT == 8, "one 16-column X tile per wave");
+    constexpr int RX = IT * 32, PX = IT * 2, IMG_X = 32 * RX, IMG = IMG_X + 1024;
+    constexpr int NS = 12;                                      // 12 x 9 KiB: as many bytes in flight as a wide product keeps
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t ring = (uint32_t)(uintptr_t)smem;
+    const int64_t n_chunks = (a.P + 31) / 32;
+    const int64_t n_local = wg < n_chunks ? (n_chunks - wg + nwg - 1) / nwg : 0;
+    auto issue_chunk = [&](int64_t i) {
+        int64_t ch = wg + i * nwg;
+        if (ch >= n_chunks) ch = n_chunks - 1;                  // past the end: a harmless re-read that is never consumed
+        const uint32_t slot = ring + (uint32_t)(i % NS) * IMG;
+        const int e = 64 * wave + lane;                         // 16-byte piece of the X image: this wave's 1 KiB
+        const int r = e / PX, pos = e % PX;
+        int64_t p = ch * 32 + r;
+        if (p >= pad_points(a.P)) p = pad_points(a.P) - 1;
+        dma_piece(reinterpret_cast<const char *>(a.X) + (p * a.ldx) * 2 + ((pos ^ dw_swz<PX>(r)) << 4), slot + 1024 * wave);
+        if (wave == 0)
+            dma_piece(reinterpret_cast<const char *>(a.H) + ch * 256 + ((lane >> 4) * 4 + (lane & 3)) * 16, slot + IMG_X);
+    };
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+    if (n_local > 0) {
+#pragma unroll
+        for (int i = 0; i < NS - 1; ++i) issue_chunk(i);
+        for (int64_t i = 0; i < n_local; ++i) {
+            if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * 2) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NS - 2) : "memory");
+            issue_chunk(i + NS - 1);
+            const uint32_t ximg = ring + (uint32_t)(i % NS) * IMG;
+            typedef __attribute__((address_space(3))) const bf16x8 lds_bf16x8;
+            bf16x8 Ah = *(lds_bf16x8 *)(uintptr_t)(ximg + IMG_X + lane * 16);
+            if ((lane & 15) >= 4) Ah = bf16x8{};
+            // rows past P of the last chunk hold the padding points' saved activations: finite, and their dL/draw is zero
+            const bf16x8 B = tr_frag_swz<PX>(ximg, wave * 16, lane);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, B, acc, 0, 0, 0);
+            if (wave == 0) accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, ones, accb, 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    float *slab = a.slab + (int64_t)wg * dw_slab_floats(0, IT, 1);
+    *reinterpret_cast<f32x4 *>(slab + (wave * 64 + lane) * 4) = acc;
+    if (wave == 0 && (lane & 15) == 0) *reinterpret_cast<f32x4 *>(slab + IT * 256 + 4 * (lane >> 4)) = accb;
 }
 
 template <int OT, int IT, int WO, int WI>
@@ -508,7 +621,7 @@ static void launch_dw_small(hipStream_t s, int64_t P, float *slab, const uint16_
 constexpr int DW_MAX_JOBS = 16;
 struct DwJob {
     DwArgs a;
-    int shape;                           // 0: <16,16,4,2>  1: <8,16,4,2>  2: <16,4,8,1>  3: <8,2,8,1>
+    int shape;                           // 0: <16,16,4,2>  1: <8,16,4,2>  2: <16,4,8,1>  3: <8,2,8,1>  4: <16,16,4,2> + head  5: head alone on 8 X tiles
     int first_block, n_blocks;
 };
 struct DwMulti {
@@ -531,7 +644,9 @@ __global__ __launch_bounds__(512, 2) void dw_multi_kernel(DwMulti m) {
     case 0: dw2_body<16, 16, 4, 2>(J.a, wg, J.n_blocks); break;
     case 1: dw2_body<8, 16, 4, 2>(J.a, wg, J.n_blocks); break;
     case 2: dw2_body<16, 4, 8, 1>(J.a, wg, J.n_blocks); break;
-    default: dw2_body<8, 2, 8, 1>(J.a, wg, J.n_blocks); break;
+    case 3: dw2_body<8, 2, 8, 1>(J.a, wg, J.n_blocks); break;
+    case 4: dw2_body<16, 16, 4, 2, true>(J.a, wg, J.n_blocks); break;
+    default: dw_head_body<8>(J.a, wg, J.n_blocks); break;
     }
 }
 
@@ -543,27 +658,18 @@ __global__ __launch_bounds__(DWR_BLOCK) void dw_reduce_multi_kernel(DwReduceMult
     while (j + 1 < m.n && (int)blockIdx.x >= m.first_block[j + 1]) ++j;
     j = __builtin_amdgcn_readfirstlane(j);
     const DwReduceArgs &a = m.r[j];
-    const int per = a.OT * a.IT * 256 + a.OT * 16;
+    const int per = dw_slab_floats(a.OT, a.IT, a.HT);
     const int e = ((int)blockIdx.x - m.first_block[j]) * DWR_BLOCK + (int)threadIdx.x;
     if (e >= per) return;
     float acc = 0.f;
 #pragma unroll 8
     for (int b = 0; b < a.n_slabs; ++b) acc += a.slab[(int64_t)b * per + e];
-    if (e < a.OT * a.IT * 256) {
-        const int r = e & 3, lane = (e >> 2) & 63, tile = e >> 8;
-        const int to = tile / a.IT, ti = tile - to * a.IT;
-        const int o = slot_to_feature(a.out_kind, to * 16 + 4 * (lane >> 4) + r, 0);
-        const int i = slot_to_feature(a.in_kind, ti * 16 + (lane & 15), a.in_L);
-        if (i >= 0 && o >= 0 && i < a.m_valid && o < a.n_valid) a.dW[(int64_t)o * a.ld_dw + a.col_off + i] = acc;
-    } else if (a.db) {
-        const int o = slot_to_feature(a.out_kind, e - a.OT * a.IT * 256, 0);
-        if (o >= 0 && o < a.n_valid) a.db[o] = acc;
-    }
+    dw_scatter(a, e, acc);
 }
 
 namespace {
 struct TrainWs {
-    uint16_t *sv_e, *sv_d, *sv_h, *sv_feat, *sv_hv, *g_rawb, *g_hv, *g_feat, *g_h;
+    uint16_t *sv_e, *sv_d, *sv_h, *sv_feat, *sv_hv, *g_rawb, *g_rawt, *g_hv, *g_feat, *g_h;
     uint8_t *sv_bits;
     float *slab;        // 2 x DW_GRID partial [256 x 256 + 256] fp32 results of a weight-gradient product (alternating:
                         // the reduction of one product runs beside the next product)
@@ -585,6 +691,7 @@ int64_t carve(const Program &p, int64_t P_points, char *base, TrainWs *w) {
     t.sv_hv = (uint16_t *)take(P * 128 * 2);
     t.sv_bits = (uint8_t *)take(P * (8 * 32 + 16));
     t.g_rawb = (uint16_t *)take(P * 4 * 2);
+    t.g_rawt = (uint16_t *)take(P * 4 * 2);
     t.g_hv = (uint16_t *)take(P * 128 * 2);
     t.g_feat = (uint16_t *)take(P * 256 * 2);
     t.g_h = (uint16_t *)take((size_t)8 * P * 256 * 2);
@@ -607,7 +714,7 @@ void train_fill_args(const Program &p, int64_t P, void *workspace, MlpArgs *a) {
     carve(p, P, static_cast<char *>(workspace), &w);
     a->sv_e = w.sv_e; a->sv_d = w.sv_d; a->sv_h = w.sv_h; a->sv_feat = w.sv_feat; a->sv_hv = w.sv_hv;
     a->sv_bits = w.sv_bits;
-    a->g_rawb = w.g_rawb; a->g_hv = w.g_hv; a->g_feat = w.g_feat; a->g_h = w.g_h;
+    a->g_rawb = w.g_rawb; a->g_rawt = w.g_rawt; a->g_hv = w.g_hv; a->g_feat = w.g_feat; a->g_h = w.g_h;
 }
 
 // The products of one training step in order.  Product k dumps its slabs into buffer k % 2 on the caller's stream; its
@@ -673,9 +780,10 @@ static int launch_dw2(const DwArgs &a, const DwReduceArgs &ra, DwSeq &q) {
     if (q.multi) {
         static_assert((OT == 16 && IT == 16) || (OT == 8 && IT == 16) || (OT == 16 && IT == 4), "shape not in dw_multi_kernel");
         if (q.mj.n >= DW_MAX_JOBS) return NERF_AMD_EINVAL;
+        if (ra.HT && !(OT == 16 && IT == 16)) return NERF_AMD_EINVAL;      // a head rides on the 256 x 256 shape only
         DwJob &J = q.mj.job[q.mj.n];
         J.a = a;
-        J.shape = OT == 16 ? (IT == 16 ? 0 : 2) : 1;
+        J.shape = OT == 16 ? (IT == 16 ? (ra.HT ? 4 : 0) : 2) : 1;
         DwReduceArgs &r = q.mr.r[q.mj.n];
         r = ra; r.OT = OT; r.IT = IT;
         ++q.mj.n;
@@ -736,7 +844,7 @@ static int launch_dw(const DwArgs &a, const DwReduceArgs &ra, DwSeq &q) {
 
 int DwSeq::flush() {
     if (!multi || mj.n == 0) return NERF_AMD_OK;
-    const size_t lds = 4 * 32 * (16 * 32 + 16 * 32);
+    const size_t lds = 4 * (32 * (16 * 32 + 16 * 32) + 1024);     // the largest job shape: 256 x 256 with a head operand per ring slot
     static DynamicLdsOptIn opt_in;
     if (opt_in.ensure(reinterpret_cast<const void *>(dw_multi_kernel), lds) != hipSuccess) return NERF_AMD_EHIP;
     // workgroups in proportion to the bytes per point of a product, DW_GRID in all (never more than a product has
@@ -746,7 +854,7 @@ int DwSeq::flush() {
     int w[DW_MAX_JOBS], total_w = 0, nb[DW_MAX_JOBS], per[DW_MAX_JOBS], used = 0;
     for (int j = 0; j < mj.n; ++j) {
         const DwReduceArgs &r = mr.r[j];
-        w[j] = r.OT + r.IT; per[j] = r.OT * r.IT * 256 + r.OT * 16;
+        w[j] = r.OT + r.IT; per[j] = dw_slab_floats(r.OT, r.IT, r.HT);
         total_w += w[j];
     }
     for (int j = 0; j < mj.n; ++j) { nb[j] = DW_GRID * w[j] / total_w; if (nb[j] < 1) nb[j] = 1; used += nb[j]; }
@@ -772,13 +880,23 @@ int DwSeq::flush() {
 }
 
 // dW[:, col_off : col_off + m_valid] (+ db) of one Linear from G [P, 16*OT] and X [P, 16*IT].
+// A head product that shares X with a streaming product (or stands alone): rows [row0, row0 + rows) of dL/draw's columns.
+struct HeadSpec {
+    const uint16_t *H = nullptr;         // kernels.h g_rawt
+    int row0 = 0, rows = 0, ld = 0;
+    float *dW = nullptr, *db = nullptr;
+};
+
 static int weight_grad(DwSeq &s, int64_t P, float *slab, const uint16_t *X, int n_in_slots, int in_kind, int in_L,
                        int m_valid, const uint16_t *G, int n_out_slots, int n_valid, float *dW, int ld_dw, int col_off,
-                       float *db) {
+                       float *db, const HeadSpec *head = nullptr) {
     DwArgs a;
-    a.G = G; a.ldg = n_out_slots; a.X = X; a.ldx = n_in_slots; a.P = P; a.slab = slab;
+    a.G = G; a.ldg = n_out_slots; a.X = X; a.ldx = n_in_slots; a.P = P; a.slab = slab; a.H = head ? head->H : nullptr;
     DwReduceArgs r;
     r.slab = slab; r.n_slabs = 0; r.OT = 0; r.IT = 0;
+    r.HT = head ? 1 : 0; r.head_dW = head ? head->dW : nullptr; r.head_db = head ? head->db : nullptr;
+    r.head_row0 = head ? head->row0 : 0; r.head_rows = head ? head->rows : 0; r.head_ld = head ? head->ld : 0;
+    if (head && !(s.multi && n_out_slots == 256 && n_in_slots == 256)) return NERF_AMD_EINVAL;
     r.dW = dW; r.ld_dw = ld_dw; r.col_off = col_off; r.db = db;
     r.out_kind = PERM_ACC; r.in_kind = in_kind; r.in_L = in_L; r.n_valid = n_valid; r.m_valid = m_valid;
     if (n_out_slots == 256 && n_in_slots == 256) return g_variant == 50 ? launch_dw<16, 16, 4, 2>(a, r, s) : launch_dw2<16, 16, 4, 2>(a, r, s);
@@ -789,6 +907,21 @@ static int weight_grad(DwSeq &s, int64_t P, float *slab, const uint16_t *X, int 
     if (n_out_slots == 128 && n_in_slots == 256) return launch_dw<8, 16, 4, 2>(a, r, s);
     if (n_out_slots == 128 && n_in_slots == 32) return launch_dw<8, 2, 8, 1>(a, r, s);
     return NERF_AMD_EUNSUPPORTED;
+}
+
+// A head product alone, as a job of the one launch (shape 5): X [P, 128] slot-major rows.
+static int head_grad(DwSeq &s, int64_t P, const uint16_t *X, int n_in_slots, int in_kind, int m_valid, const HeadSpec &head) {
+    if (!s.multi || n_in_slots != 128 || s.mj.n >= DW_MAX_JOBS) return NERF_AMD_EINVAL;
+    DwJob &J = s.mj.job[s.mj.n];
+    J.a.G = nullptr; J.a.ldg = 0; J.a.X = X; J.a.ldx = n_in_slots; J.a.P = P; J.a.slab = nullptr; J.a.H = head.H;
+    J.shape = 5;
+    DwReduceArgs &r = s.mr.r[s.mj.n];
+    r.slab = nullptr; r.n_slabs = 0; r.OT = 0; r.IT = n_in_slots / 16;
+    r.dW = nullptr; r.ld_dw = 0; r.col_off = 0; r.db = nullptr;
+    r.out_kind = PERM_NAT; r.in_kind = in_kind; r.in_L = 0; r.n_valid = 0; r.m_valid = m_valid;
+    r.HT = 1; r.head_dW = head.dW; r.head_db = head.db; r.head_row0 = head.row0; r.head_rows = head.rows; r.head_ld = head.ld;
+    ++s.mj.n;
+    return NERF_AMD_OK;
 }
 
 // Parameter gradients of the view-branch model from the saved activations and the
@@ -865,14 +998,22 @@ int train_param_grads(const Program &p, int64_t P, void *workspace, float *const
         }
     }
     const uint16_t *h8 = w.sv_h + (D - 1) * HS;
-    // feature_linear
-    if (!rc) rc = weight_grad(s, P, w.slab, h8, W, PERM_ACC, 0, W, w.g_feat, W, W, gw[D], W, 0, gb[D]);
+    // feature_linear -- and alpha_linear, whose product has the same X (h8): in the one launch its gradient column rides
+    // along as a head tile (row 3 of dL/draw's columns) instead of a separate fp32 FMA kernel re-reading h8
+    HeadSpec alpha_head, rgb_head;
+    alpha_head.H = w.g_rawt; alpha_head.row0 = 3; alpha_head.rows = 1; alpha_head.ld = W; alpha_head.dW = gw[D + 1]; alpha_head.db = gb[D + 1];
+    rgb_head.H = w.g_rawt; rgb_head.row0 = 0; rgb_head.rows = 3; rgb_head.ld = W / 2; rgb_head.dW = gw[D + 3]; rgb_head.db = gb[D + 3];
+    const bool fold_heads = s.multi && g_variant != 57;       // A/B 57: the round-2 head kernels beside the one launch
+    if (!rc) rc = weight_grad(s, P, w.slab, h8, W, PERM_ACC, 0, W, w.g_feat, W, W, gw[D], W, 0, gb[D], fold_heads ? &alpha_head : nullptr);
     // views_linears.0: [feature | dirs]
     if (!rc) rc = weight_grad(s, P, w.slab, w.sv_feat, W, PERM_ACC, 0, W, w.g_hv, W / 2, W / 2, gw[D + 2], W + icv, 0, gb[D + 2]);
     if (!rc) rc = weight_grad(s, P, w.slab, w.sv_d, Dd, PERM_GEN, Ld, icv, w.g_hv, W / 2, W / 2, gw[D + 2], W + icv, W, nullptr);
     // (the two head products as jobs of the one launch: 2.13 ms per step instead of 1.69 -- their fp32 FMA loops want a
     // thousand small blocks in flight, not a twentieth of the CUs)
-    if (s.multi && s.lanes == 3) {
+    if (fold_heads) {
+        // rgb_linear: nothing else multiplies the view layer's output, so its three gradient columns are a job of their own
+        if (!rc) rc = head_grad(s, P, w.sv_hv, W / 2, PERM_ACC, W / 2, rgb_head);
+    } else if (s.multi && s.lanes == 3) {
         // both heads start with the one launch and run beside it on a stream each (their blocks are small enough to share a
         // CU with a streaming workgroup); second half of the slab buffer, a quarter each
         launch_dw_small<1>(s.lane_s[0], P, w.slab + SLAB_FLOATS, w.g_rawb, 3, w.sv_h + (D - 1) * HS, W, gw[D + 1], gb[D + 1]);
@@ -884,7 +1025,7 @@ int train_param_grads(const Program &p, int64_t P, void *workspace, float *const
     s.join();
     if (s.overlap || s.lanes) lane_release(device, s.ev);
     if (rc) return rc;
-    if (!heads_first && !heads_tail) heads(stream, w.slab);
+    if (!fold_heads && !heads_first && !heads_tail) heads(stream, w.slab);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
 

@@ -50,6 +50,8 @@ struct MlpArgs {
     // backward inputs / outputs
     const float *g_raw;            // [P, 4] dL/draw
     uint16_t *g_rawb;              // [P, 4] bf16 copy of g_raw (GEMM operand)
+    uint16_t *g_rawt;              // the same values transposed inside 32-point chunks, [P/32][4 point groups][4 columns][8 points]:
+                                   // the 16 bytes at (group g, column i) are lane (i, g)'s MFMA operand of the head products (backward.hip)
     uint16_t *g_hv;                // [P, 128] dL/d(pre-activation) of views_linears.0, slot-major
     uint16_t *g_feat;              // [P, 256]
     uint16_t *g_h;                 // [8][P, 256]  dL/d(pre-activation) of pts_linears.0..7

@@ -265,15 +265,22 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bwd_s16_kernel(MlpArgs a
             dv[cc][0] = d[0]; dv[cc][1] = d[1]; dv[cc][2] = d[2];
         }
         f32x4 g = {0.f, 0.f, 0.f, 0.f};
-        if (valid[cc] && q == 0) g = *reinterpret_cast<const f32x4 *>(a.g_raw + 4 * p);
+        if (valid[cc]) g = *reinterpret_cast<const f32x4 *>(a.g_raw + 4 * p);
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+        const bf16x4 gb = {(__bf16)g[0], (__bf16)g[1], (__bf16)g[2], (__bf16)g[3]};
         bf16x8 r = {}, s = {};
-        r[0] = (__bf16)g[0]; r[1] = (__bf16)g[1]; r[2] = (__bf16)g[2];     // k slot (q=0, j) = rgb_linear output j
-        s[0] = (__bf16)g[3];                                                // k slot (0, 0)   = alpha_linear output
+        if (q == 0) {
+            r[0] = gb[0]; r[1] = gb[1]; r[2] = gb[2];                       // k slot (q=0, j) = rgb_linear output j
+            s[0] = gb[3];                                                   // k slot (0, 0)   = alpha_linear output
+        }
         Grgb[cc] = r; Gsig[cc] = s;
-        if (valid[cc] && q == 0) {
-            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-            bf16x4 o = {r[0], r[1], r[2], s[0]};
-            *reinterpret_cast<bf16x4 *>(a.g_rawb + 4 * p) = o;
+        if (valid[cc] && q == 0) *reinterpret_cast<bf16x4 *>(a.g_rawb + 4 * p) = gb;
+        // the same values as the operand of the head weight-gradient products: transposed inside the wave's 32-point chunk,
+        // lane quarter q writes column q (zeros for the padding points, so their saved rows contribute nothing)
+        {
+            const int pl = cc * 16 + (lane & 15);                          // this point inside its chunk (a wave's 32 points)
+            const __bf16 v = q == 0 ? gb[0] : q == 1 ? gb[1] : q == 2 ? gb[2] : gb[3];
+            reinterpret_cast<__bf16 *>(a.g_rawt)[(p >> 5) * 128 + ((pl >> 3) * 4 + q) * 8 + (pl & 7)] = v;
         }
     });
 
