@@ -162,8 +162,10 @@ int nerf_amd_raw2outputs_backward(const float *raw, int32_t raw_ch, const float 
 
 /* ------------------------------------------------------------------------
  * Training (what loss.backward() does through NeRF.forward, main.py:85-104).
- * Covered: the D=8, W=256, skips=[4] view-branch model with multires 10/4 or 15/6 (every config the
- * reference ships); gradients of the parameters,
+ * Covered: the D=8, W=256, skips=[4] model with view branch and multires 10/4 or 15/6 (every config the
+ * reference ships), or without view branch (the output_linear models of nerf.py:91-94,131-132 -- the default
+ * use_viewdirs=False of config_parser.py:50 -- multires 10 or 15, output_ch <= 16: raw / g_raw are [P, output_ch],
+ * rays are [R,8], viewdirs NULL); gradients of the parameters,
  * of the points / rays (through the positional encoding) and of the view directions; bf16 operands /
  * fp32 accumulation.
  *   forward_train : the fused bf16 forward (explicit pts + viewdirs, or rays + z_vals with pts = o + d z) that also saves every
@@ -174,10 +176,10 @@ int nerf_amd_raw2outputs_backward(const float *raw, int32_t raw_ch, const float 
 int     nerf_amd_model_supports_training(const nerf_amd_model *m);
 int64_t nerf_amd_train_workspace(const nerf_amd_model *m, int64_t n_points);
 int     nerf_amd_field_forward_train(const nerf_amd_model *m, const float *pts /* [R*S,3] or NULL */,
-                                     const float *viewdirs /* [R,3], with pts */, const float *rays /* [R,11], without pts */,
+                                     const float *viewdirs /* [R,3], with pts */, const float *rays /* [R,11|8], without pts */,
                                      int32_t ray_ch, const float *z_vals, int64_t R, int32_t S, float *raw,
                                      void *workspace, int64_t workspace_bytes, void *stream);
-int     nerf_amd_field_backward(const nerf_amd_model *m, const float *g_raw /* [R*S,4] */,
+int     nerf_amd_field_backward(const nerf_amd_model *m, const float *g_raw /* [R*S,4|output_ch] */,
                                 const float *pts, const float *viewdirs, const float *rays, int32_t ray_ch,
                                 const float *z_vals, int64_t R, int32_t S /* the forward_train inputs */,
                                 void *workspace, int64_t workspace_bytes, float *const *grad_weights,

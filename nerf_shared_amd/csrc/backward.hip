@@ -515,7 +515,7 @@ __global__ __launch_bounds__(512, 2) void dw2_kernel(DwArgs a) {
 // per row) of every (256 / groups)-th row.  Partial sums meet in LDS and leave as one slab row per
 // block ([NO][n_in] weights, then NO biases); dw_small_reduce_kernel sums the rows.
 template <int NO, int NT>
-__device__ __forceinline__ void dw_small_body(const uint16_t *G, int g_col0, const uint16_t *X, int ldx, int n_in, int64_t P,
+__device__ __forceinline__ void dw_small_body(const uint16_t *G, int ldg, int g_col0, const uint16_t *X, int ldx, int n_in, int64_t P,
                                               float *slab, float (*red)[256 + 1] /* LDS [NO][257] */, const int wg, const int nwg) {
     const int groups = n_in / 8;                       // column groups per row (32 for 256 columns, 16 for 128)
     const int rows_par = NT / groups;                  // rows in flight per block
@@ -538,12 +538,12 @@ __device__ __forceinline__ void dw_small_body(const uint16_t *G, int g_col0, con
                 x[2 * j] = __builtin_bit_cast(float, xv[j] << 16);
                 x[2 * j + 1] = __builtin_bit_cast(float, xv[j] & 0xffff0000u);
             }
-            // the row's four gradient values as one 8-byte load (one VMEM instruction instead of NO)
+            // the row's four gradient values (the aligned group of four columns g_col0 lies in) as one 8-byte load
             typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-            const u32x2 gv = *reinterpret_cast<const u32x2 *>(G + p * 4);
+            const u32x2 gv = *reinterpret_cast<const u32x2 *>(G + p * ldg + (g_col0 & ~3));
 #pragma unroll
             for (int k = 0; k < NO; ++k) {
-                const int col = g_col0 + k;
+                const int col = (g_col0 & 3) + k;
                 const unsigned word = (col & 2) ? gv[1] : gv[0];
                 const float g = __builtin_bit_cast(float, (col & 1) ? (word & 0xffff0000u) : (word << 16));
                 if (cg == 0) bs[k] += g;
@@ -572,10 +572,10 @@ __device__ __forceinline__ void dw_small_body(const uint16_t *G, int g_col0, con
 }
 
 template <int NO>
-__global__ __launch_bounds__(256) void dw_small_kernel(const uint16_t *G, int g_col0, const uint16_t *X, int ldx, int n_in,
+__global__ __launch_bounds__(256) void dw_small_kernel(const uint16_t *G, int ldg, int g_col0, const uint16_t *X, int ldx, int n_in,
                                                        int64_t P, float *slab) {
     __shared__ float red[NO][256 + 1];
-    dw_small_body<NO, 256>(G, g_col0, X, ldx, n_in, P, slab, red, blockIdx.x, gridDim.x);
+    dw_small_body<NO, 256>(G, ldg, g_col0, X, ldx, n_in, P, slab, red, blockIdx.x, gridDim.x);
 }
 
 // dW[k][feature(slot)] / db[k] = sum of the slab rows dw_small_kernel left; 64 elements per block.
@@ -603,13 +603,14 @@ __global__ __launch_bounds__(1024) void dw_small_reduce_kernel(const float *slab
     }
 }
 
+// G [P, ldg] bf16 rows; columns g_col0 .. g_col0 + NO - 1 must lie inside one aligned group of four.
 template <int NO>
 static void launch_dw_small(hipStream_t s, int64_t P, float *slab, const uint16_t *G, int g_col0, const uint16_t *X, int n_in,
-                            float *dW, float *db) {
+                            float *dW, float *db, int ldg = 4) {
     int64_t g = (P + 255) / 256;
     const int64_t cap = g_variant == 50 ? 256 : 1024;  // four 256-thread blocks per CU keep enough 16-byte loads in flight; 1024 * (3 * 256 + 3) floats fit the slab
     if (g > cap) g = cap;
-    hipLaunchKernelGGL(dw_small_kernel<NO>, dim3((unsigned)g), dim3(256), 0, s, G, g_col0, X, n_in, n_in, P, slab);
+    hipLaunchKernelGGL(dw_small_kernel<NO>, dim3((unsigned)g), dim3(256), 0, s, G, ldg, g_col0, X, n_in, n_in, P, slab);
     hipLaunchKernelGGL(dw_small_reduce_kernel, dim3((NO * n_in + NO + 63) / 64), dim3(1024), 0, s, slab, (int)g, NO, n_in,
                        (int)PERM_ACC, dW, n_in, db);
 }
@@ -690,7 +691,7 @@ int64_t carve(const Program &p, int64_t P_points, char *base, TrainWs *w) {
     t.sv_feat = (uint16_t *)take(P * 256 * 2);
     t.sv_hv = (uint16_t *)take(P * 128 * 2);
     t.sv_bits = (uint8_t *)take(P * (8 * 32 + 16));
-    t.g_rawb = (uint16_t *)take(P * 4 * 2);
+    t.g_rawb = (uint16_t *)take(P * 16 * 2);           // [P, 4] with a view branch, [P, 16] without
     t.g_rawt = (uint16_t *)take(P * 4 * 2);
     t.g_hv = (uint16_t *)take(P * 128 * 2);
     t.g_feat = (uint16_t *)take(P * 256 * 2);
@@ -703,8 +704,9 @@ int64_t carve(const Program &p, int64_t P_points, char *base, TrainWs *w) {
 
 bool train_supported(const Program &p) {
     const nerf_amd_arch &a = p.arch;
-    return p.bf16_ok && a.use_viewdirs && a.i_embed == 0 &&
-           ((a.multires == 10 && a.multires_views == 4) || (a.multires == 15 && a.multires_views == 6));
+    if (!p.bf16_ok || a.i_embed != 0) return false;
+    if (a.use_viewdirs) return (a.multires == 10 && a.multires_views == 4) || (a.multires == 15 && a.multires_views == 6);
+    return (a.multires == 10 || a.multires == 15) && p.out_ch <= 16;       // output_linear models (nerf.py:91-94)
 }
 
 int64_t train_workspace_bytes(const Program &p, int64_t P) { return carve(p, P, nullptr, nullptr); }
@@ -931,7 +933,8 @@ int train_param_grads(const Program &p, int64_t P, void *workspace, float *const
     TrainWs w;
     carve(p, P, static_cast<char *>(workspace), &w);
     const int D = p.arch.D, W = p.arch.W, E = 32 * p.KE16, Dd = 32 * p.KD16, ic = p.input_ch, icv = p.input_ch_views;
-    if (W != 256 || (E != 64 && E != 96) || (Dd != 32 && Dd != 64)) return NERF_AMD_EUNSUPPORTED;
+    const bool vd = p.arch.use_viewdirs != 0;
+    if (W != 256 || (E != 64 && E != 96) || (vd && Dd != 32 && Dd != 64)) return NERF_AMD_EUNSUPPORTED;
     DwSeq s;
     s.main_s = stream; s.slab = w.slab;
     constexpr int MAX_PRODUCTS = 24;
@@ -979,6 +982,19 @@ int train_param_grads(const Program &p, int64_t P, void *workspace, float *const
     heads_first = heads_first && s.lanes >= 2;
     heads_tail = heads_tail && s.lanes >= 2;
     auto heads = [&](hipStream_t hs, float *slab) {    // alpha_linear (column 3 of g_rawb) and rgb_linear (columns 0..2)
+        if (!vd) {
+            // output_linear [out_ch, W]: X = h8, G = the out_ch <= 16 columns of g_rawb [P, 16], four rows per launch
+            const uint16_t *h8x = w.sv_h + (D - 1) * HS;
+            for (int r0 = 0; r0 < p.out_ch; r0 += 4) {
+                const int n = p.out_ch - r0 < 4 ? p.out_ch - r0 : 4;
+                float *dWr = gw[D] + (int64_t)r0 * W, *dbr = gb[D] + r0;
+                if (n == 1) launch_dw_small<1>(hs, P, slab, w.g_rawb, r0, h8x, W, dWr, dbr, 16);
+                else if (n == 2) launch_dw_small<2>(hs, P, slab, w.g_rawb, r0, h8x, W, dWr, dbr, 16);
+                else if (n == 3) launch_dw_small<3>(hs, P, slab, w.g_rawb, r0, h8x, W, dWr, dbr, 16);
+                else launch_dw_small<4>(hs, P, slab, w.g_rawb, r0, h8x, W, dWr, dbr, 16);
+            }
+            return;
+        }
         launch_dw_small<1>(hs, P, slab, w.g_rawb, 3, w.sv_h + (D - 1) * HS, W, gw[D + 1], gb[D + 1]);
         launch_dw_small<3>(hs, P, slab, w.g_rawb, 0, w.sv_hv, W / 2, gw[D + 3], gb[D + 3]);
     };
@@ -996,6 +1012,17 @@ int train_param_grads(const Program &p, int64_t P, void *workspace, float *const
         } else {
             rc = weight_grad(s, P, w.slab, w.sv_h + (l - 1) * HS, W, PERM_ACC, 0, W, G, W, W, gw[l], n_in, 0, gb[l]);
         }
+    }
+    if (!vd) {
+        // output_linear models: the hidden layers' products are the one launch; the head (out_ch <= 16 rows over h8) runs on
+        // the side stream beside it (fp32 FMA kernels: this model family is not the one the step time is tuned on)
+        if (s.lanes >= 2) heads(s.lane_s[0], w.slab + (s.multi ? SLAB_FLOATS : 2 * SLAB_FLOATS / s.lanes));
+        if (!rc) rc = s.flush();
+        s.join();
+        if (s.overlap || s.lanes) lane_release(device, s.ev);
+        if (rc) return rc;
+        if (s.lanes < 2) heads(stream, w.slab);
+        return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
     }
     const uint16_t *h8 = w.sv_h + (D - 1) * HS;
     // feature_linear -- and alpha_linear, whose product has the same X (h8): in the one launch its gradient column rides

@@ -309,9 +309,10 @@ int nerf_amd_field_forward_train(const nerf_amd_model *m, const float *pts, cons
                                  int32_t ray_ch, const float *z_vals, int64_t R, int32_t S, float *raw, void *workspace,
                                  int64_t workspace_bytes, void *stream) {
     if (!m || R < 0 || S < 1) return fail(NERF_AMD_EINVAL, "bad forward_train arguments");
-    if (!pts && ray_ch != 11) return fail(NERF_AMD_EINVAL, "rays must be [R,11]");
-    if (pts && !viewdirs) return fail(NERF_AMD_EINVAL, "pts mode needs viewdirs [R,3]");
-    if (!train_supported(m->prog)) return fail(NERF_AMD_EUNSUPPORTED, "training kernels cover the D=8, W=256, skips=[4] view-branch model with multires 10/4 or 15/6");
+    const bool vd = m->prog.arch.use_viewdirs != 0;
+    if (!pts && ray_ch != (vd ? 11 : 8)) return fail(NERF_AMD_EINVAL, vd ? "rays must be [R,11]" : "rays must be [R,8] for a model without view branch");
+    if (pts && vd && !viewdirs) return fail(NERF_AMD_EINVAL, "pts mode needs viewdirs [R,3]");
+    if (!train_supported(m->prog)) return fail(NERF_AMD_EUNSUPPORTED, "training kernels cover D=8, W=256, skips=[4] with view branch (multires 10/4 or 15/6) or without (multires 10 or 15, output_ch <= 16)");
     if (!m->packed) return fail(NERF_AMD_EINVAL, "model has no parameters yet");
     if (R == 0) return NERF_AMD_OK;
     const int64_t P = R * S;
@@ -320,11 +321,11 @@ int nerf_amd_field_forward_train(const nerf_amd_model *m, const float *pts, cons
     MlpArgs a;
     std::memset(&a, 0, sizeof(a));
     a.stream_s16 = m->stream_s16; a.bias_s16 = m->bias_s16;
-    if (pts) { a.pts = pts; a.viewdirs = viewdirs; a.vd_stride = 3; }
-    else { a.rays = rays; a.ray_stride = ray_ch; a.z_vals = z_vals; a.viewdirs = rays + 8; a.vd_stride = ray_ch; }
-    a.P = P; a.S = S; a.out = raw; a.out_ch = 4;
+    if (pts) { a.pts = pts; a.viewdirs = vd ? viewdirs : nullptr; a.vd_stride = 3; }
+    else { a.rays = rays; a.ray_stride = ray_ch; a.z_vals = z_vals; a.viewdirs = vd ? rays + 8 : nullptr; a.vd_stride = ray_ch; }
+    a.P = P; a.S = S; a.out = raw; a.out_ch = m->prog.out_ch;
     train_fill_args(m->prog, P, workspace, &a);
-    int rc = launch_mlp_bf16_s16_save(a, m->prog.arch.multires, m->prog.arch.multires_views, m->prog.n_frags16_used, (int)m->prog.tiles16.size(), static_cast<hipStream_t>(stream));
+    int rc = launch_mlp_bf16_s16_save(a, m->prog.arch.multires, m->prog.arch.multires_views, vd, m->prog.n_frags16_used, (int)m->prog.tiles16.size(), static_cast<hipStream_t>(stream));
     return rc ? fail(rc, "training forward launch failed") : NERF_AMD_OK;
 }
 
@@ -335,8 +336,10 @@ int nerf_amd_field_backward(const nerf_amd_model *m, const float *g_raw, const f
                             void *stream) {
     const int64_t n_points = R * S;
     if (!m || R < 0 || S < 1 || !grad_weights || !grad_biases) return fail(NERF_AMD_EINVAL, "bad backward arguments");
-    if ((!pts && (ray_ch != 11 || !rays || !z_vals)) || (pts && !viewdirs)) return fail(NERF_AMD_EINVAL, "backward needs the forward's inputs (pts + viewdirs, or rays [R,11] + z_vals)");
-    if (!train_supported(m->prog)) return fail(NERF_AMD_EUNSUPPORTED, "training kernels cover the D=8, W=256, skips=[4] view-branch model with multires 10/4 or 15/6");
+    const bool vd = m->prog.arch.use_viewdirs != 0;
+    if ((!pts && (ray_ch != (vd ? 11 : 8) || !rays || !z_vals)) || (pts && vd && !viewdirs))
+        return fail(NERF_AMD_EINVAL, "backward needs the forward's inputs (pts + viewdirs, or rays [R,11] + z_vals; [R,8] without view branch)");
+    if (!train_supported(m->prog)) return fail(NERF_AMD_EUNSUPPORTED, "training kernels cover D=8, W=256, skips=[4] with view branch (multires 10/4 or 15/6) or without (multires 10 or 15, output_ch <= 16)");
     if (n_tensors != (int)m->prog.tensors.size()) return fail(NERF_AMD_EINVAL, "wrong number of gradient tensors");
     if (n_points == 0) return NERF_AMD_OK;
     if (!g_raw || !workspace || workspace_bytes < train_workspace_bytes(m->prog, n_points))
@@ -344,12 +347,12 @@ int nerf_amd_field_backward(const nerf_amd_model *m, const float *g_raw, const f
     hipStream_t s = static_cast<hipStream_t>(stream);
     MlpArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.stream_bwd = m->stream_bwd; a.g_raw = g_raw; a.P = n_points; a.S = S;
-    if (pts) { a.pts = pts; a.viewdirs = viewdirs; a.vd_stride = 3; }
-    else { a.rays = rays; a.ray_stride = ray_ch; a.z_vals = z_vals; a.viewdirs = rays + 8; a.vd_stride = ray_ch; }
-    a.g_pts = g_pts; a.g_rays = g_rays; a.g_vd = g_viewdirs;
+    a.stream_bwd = m->stream_bwd; a.g_raw = g_raw; a.P = n_points; a.S = S; a.out_ch = m->prog.out_ch;
+    if (pts) { a.pts = pts; a.viewdirs = vd ? viewdirs : nullptr; a.vd_stride = 3; }
+    else { a.rays = rays; a.ray_stride = ray_ch; a.z_vals = z_vals; a.viewdirs = vd ? rays + 8 : nullptr; a.vd_stride = ray_ch; }
+    a.g_pts = g_pts; a.g_rays = g_rays; a.g_vd = vd ? g_viewdirs : nullptr;
     train_fill_args(m->prog, n_points, workspace, &a);
-    int rc = launch_mlp_bwd_s16(a, m->prog.arch.multires, m->prog.arch.multires_views, m->prog.n_frags_bwd_used, s);
+    int rc = launch_mlp_bwd_s16(a, m->prog.arch.multires, m->prog.arch.multires_views, vd, m->prog.n_frags_bwd_used, s);
     if (rc) return fail(rc, "backward kernel launch failed");
     rc = train_param_grads(m->prog, n_points, workspace, grad_weights, grad_biases, m->device, s);
     return rc ? fail(rc, "weight-gradient GEMMs failed") : NERF_AMD_OK;

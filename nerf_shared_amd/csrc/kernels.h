@@ -49,7 +49,7 @@ struct MlpArgs {
                                    // views_linears.0 (lane quarter q owns bytes q*NK .. of a row; bit layout: mlp_bf16_s16.hip save_bits)
     // backward inputs / outputs
     const float *g_raw;            // [P, 4] dL/draw
-    uint16_t *g_rawb;              // [P, 4] bf16 copy of g_raw (GEMM operand)
+    uint16_t *g_rawb;              // [P, 4] bf16 copy of g_raw (GEMM operand); output_linear models: [P, 16], columns >= out_ch zero
     uint16_t *g_rawt;              // the same values transposed inside 32-point chunks, [P/32][4 point groups][4 columns][8 points]:
                                    // the 16 bytes at (group g, column i) are lane (i, g)'s MFMA operand of the head products (backward.hip)
     uint16_t *g_hv;                // [P, 128] dL/d(pre-activation) of views_linears.0, slot-major
@@ -92,9 +92,9 @@ int launch_pack(const Program &p, const FragDesc *d_frags, const TileDesc *d_til
 void pack_bf16_host(const Program &p, int shape, const float *const *w, const float *const *b, uint16_t *stream, float *bias);
 int launch_mlp_bf16_s16(const MlpArgs &a, int multires, int multires_views, int use_viewdirs,
                         int n_frags_used, int n_tiles, hipStream_t s);
-// training kernels: the view-branch model with multires 10/4 or 15/6
-int launch_mlp_bf16_s16_save(const MlpArgs &a, int multires, int multires_views, int n_frags_used, int n_tiles, hipStream_t s);
-int launch_mlp_bwd_s16(const MlpArgs &a, int multires, int multires_views, int n_frags_used, hipStream_t s);
+// training kernels: the view-branch model with multires 10/4 or 15/6, the output_linear model with multires 10 or 15
+int launch_mlp_bf16_s16_save(const MlpArgs &a, int multires, int multires_views, int use_viewdirs, int n_frags_used, int n_tiles, hipStream_t s);
+int launch_mlp_bwd_s16(const MlpArgs &a, int multires, int multires_views, int use_viewdirs, int n_frags_used, hipStream_t s);
 
 // backward.hip
 bool train_supported(const Program &p);

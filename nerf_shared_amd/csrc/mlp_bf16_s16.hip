@@ -795,10 +795,17 @@ int launch_mlp_bf16_s16(const MlpArgs &a, int multires, int multires_views, int 
 extern "C" void nerf_amd_debug_set_stamp_buffer(void *p) { g_stamp_buf = static_cast<unsigned long long *>(p); }
 #endif
 
-int launch_mlp_bf16_s16_save(const MlpArgs &a, int multires, int multires_views, int n_frags_used, int n_tiles, hipStream_t s) {
+int launch_mlp_bf16_s16_save(const MlpArgs &a, int multires, int multires_views, int use_viewdirs, int n_frags_used, int n_tiles,
+                             hipStream_t s) {
     // the training forward keeps the round-1 pipeline shape: with its activation stores the pinned / split shape spills
-    if (multires == 10 && multires_views == 4) return launch_wg16<10, 4, true, CfgSaveT<10, 4>, true>(a, n_frags_used, n_tiles, s);
-    if (multires == 15 && multires_views == 6) return launch_wg16<15, 6, true, CfgSaveT<15, 6>, true>(a, n_frags_used, n_tiles, s);
+    if (use_viewdirs) {
+        if (multires == 10 && multires_views == 4) return launch_wg16<10, 4, true, CfgSaveT<10, 4>, true>(a, n_frags_used, n_tiles, s);
+        if (multires == 15 && multires_views == 6) return launch_wg16<15, 6, true, CfgSaveT<15, 6>, true>(a, n_frags_used, n_tiles, s);
+    } else if (a.out_ch <= 16) {             // output_linear models (nerf.py:91-94): hidden layers saved the same way, no view branch
+        using CfgSaveNV = Ctx<8, 16, 4, 8, 2>;
+        if (multires == 10) return launch_wg16<10, 0, false, CfgSaveNV, true>(a, n_frags_used, n_tiles, s);
+        if (multires == 15) return launch_wg16<15, 0, false, CfgSaveNV, true>(a, n_frags_used, n_tiles, s);
+    }
     return NERF_AMD_EUNSUPPORTED;
 }
 

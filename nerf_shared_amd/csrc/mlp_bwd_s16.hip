@@ -1,5 +1,6 @@
 // mlp_bwd_s16.hip -- backward of the fused 8x256 NeRF MLP with respect to every
-// layer's pre-activation (the "dX chain"), for the view-branch models (multires 10/4 and 15/6).
+// layer's pre-activation (the "dX chain"), for the view-branch models (multires 10/4 and 15/6) and the
+// output_linear models (use_viewdirs=False, nerf.py:91-94,131-132; multires 10 or 15, output_ch <= 16).
 //
 // What torch.autograd computes for NeRF.MLP (/root/reference/nerf_shared/nerf.py:110-134)
 // given dL/draw: walking the layers in reverse,
@@ -191,13 +192,15 @@ __device__ __forceinline__ void tenc(C &c, const bf16x8 *x1, float (&g)[2][8 * N
 }
 
 // Fragment offsets of the backward stream (program.cpp frags_bwd) for encodings of KE / KD k-steps.
-template <int KE, int KD>
+// Without a view branch (VD = false) the chain starts at g_h8 = relu'(h8) * (W_output^T dL/draw): 8 pairs x 1 k-step.
+template <int KE, int KD, bool VD = true>
 struct LayoutB {
     static constexpr int F_HV = 0;                       // 4 pairs x 1 k-step
     static constexpr int F_FEAT = F_HV + 8;              // 8 pairs x 4 k-steps
     static constexpr int F_DIRS = F_FEAT + 64;           // view-direction encoding slots: KD pairs x 4 k-steps
-    static constexpr int F_H8 = F_DIRS + 8 * KD;         // 8 pairs x (8 + 1) k-steps
-    static constexpr int F_L7 = F_H8 + 144;              // pts_linears.7, .6, .5: 8 pairs x 8 k-steps each
+    static constexpr int F_H8 = VD ? F_DIRS + 8 * KD : 0;   // 8 pairs x (8 + 1) k-steps (VD) / x 1 k-step
+    static constexpr int H8_FRAGS_PER_PAIR = VD ? 18 : 2;
+    static constexpr int F_L7 = F_H8 + 8 * H8_FRAGS_PER_PAIR;   // pts_linears.7, .6, .5: 8 pairs x 8 k-steps each
     static constexpr int F_E5 = F_L7 + 3 * 128;          // xyz encoding slots through pts_linears.5: KE pairs x 8 k-steps
     static constexpr int F_L4 = F_E5 + 16 * KE;          // pts_linears.4 .. .1
     static constexpr int F_E0 = F_L4 + 4 * 128;          // xyz encoding slots through pts_linears.0
@@ -206,24 +209,25 @@ struct LayoutB {
 
 // Row stores issued before fragment n (pipeline.h LEDGER): two per finished tile pair of a tlayer
 // (the encoding products store nothing).
-template <int KE, int KD>
+template <int KE, int KD, bool VD = true>
 struct BwdLedger {
-    using L = LayoutB<KE, KD>;
+    using L = LayoutB<KE, KD, VD>;
     static constexpr int pairs_done(int n, int f0, int frags_per_pair, int n_pairs) {
         const int d = n <= f0 ? 0 : (n - f0) / frags_per_pair;
         return d > n_pairs ? n_pairs : d;
     }
     static constexpr int stores_before(int n) {
-        return 2 * (pairs_done(n, L::F_HV, 2, 4) + pairs_done(n, L::F_FEAT, 8, 8) + pairs_done(n, L::F_H8, 18, 8) +
+        return 2 * ((VD ? pairs_done(n, L::F_HV, 2, 4) + pairs_done(n, L::F_FEAT, 8, 8) : 0) +
+                    pairs_done(n, L::F_H8, L::H8_FRAGS_PER_PAIR, 8) +
                     pairs_done(n, L::F_L7, 16, 24) + pairs_done(n, L::F_L4, 16, 32));
     }
 };
 
-template <int LX, int LD, class C>
+template <int LX, int LD, bool VD, class C>
 __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bwd_s16_kernel(MlpArgs a) {
     constexpr int WG_POINTS = C::WAVES * 32;
-    constexpr int KE = gen16_ksteps(LX), KD = gen16_ksteps(LD);
-    using LayoutB = LayoutB<KE, KD>;
+    constexpr int KE = gen16_ksteps(LX), KD = VD ? gen16_ksteps(LD) : 1;
+    using LayoutB = LayoutB<KE, KD, VD>;
     constexpr int NF = LayoutB::F_END, NB = (NF + C::BF - 1) / C::BF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -261,8 +265,26 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bwd_s16_kernel(MlpArgs a
                 xp[cc][1] = mul_then_add(r[4], zp[cc], r[1]);
                 xp[cc][2] = mul_then_add(r[5], zp[cc], r[2]);
             }
-            const float *d = a.viewdirs + ray * a.vd_stride;
-            dv[cc][0] = d[0]; dv[cc][1] = d[1]; dv[cc][2] = d[2];
+            if constexpr (VD) {
+                const float *d = a.viewdirs + ray * a.vd_stride;
+                dv[cc][0] = d[0]; dv[cc][1] = d[1]; dv[cc][2] = d[2];
+            }
+        }
+        if constexpr (!VD) {
+            // dL/draw [P, out_ch] as the FRAG_TG16 operand: k slot (q, j) = output_linear row 8 q + j (q < 2); the bf16
+            // values also go to g_rawb as rows of 16 columns for the head's weight-gradient product (backward.hip)
+            bf16x8 o = {};
+            if (q < 2) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int col = 8 * q + j;
+                    const float gv = (valid[cc] && col < a.out_ch) ? a.g_raw[(int64_t)a.out_ch * p + col] : 0.0f;
+                    o[j] = (__bf16)gv;
+                }
+                *reinterpret_cast<bf16x8 *>(a.g_rawb + 16 * p + 8 * q) = o;      // rows exist for the padding points
+            }
+            Gsig[cc] = o; Grgb[cc] = o;
+            return;
         }
         f32x4 g = {0.f, 0.f, 0.f, 0.f};
         if (valid[cc]) g = *reinterpret_cast<const f32x4 *>(a.g_raw + 4 * p);
@@ -293,20 +315,26 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bwd_s16_kernel(MlpArgs a
     bf16x8 A[16], B[16];
     float gx[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, gd[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     const MaskBits<8> none = {};
-    // g_hv = relu'(hv) * (W_rgb^T g_rgb)
-    const MaskBits<4> m_hv = load_bits<4>(a.sv_bits + 8 * BS, pidx, q);
     MaskBits<8> m_cur = load_bits<8>(a.sv_bits + 7 * BS, pidx, q), m_next;
-    tlayer<LayoutB::F_HV, 4, 1, 0, true, 128, NB, NF>(c, Grgb, Grgb, B, m_hv, a.g_hv, pidx, q);
-    // g_feat = W_views[:, :256]^T g_hv          (feature_linear has no activation)
-    tlayer<LayoutB::F_FEAT, 8, 4, 0, false, 256, NB, NF>(c, B, B, A, none, a.g_feat, pidx, q);
-    {   // view-direction encoding: g_dirs = W_views[:, 256:]^T g_hv, then through the encoding
-        float g[2][8 * KD];
-        tenc<LayoutB::F_DIRS, KD, 4, NB, NF>(c, B, g);
-        static_for<2>([&](auto cc_) { constexpr int cc = cc_; encode16_bwd<LD, KD>(dv[cc][0], dv[cc][1], dv[cc][2], hh, bb, g[cc], gd[cc]); });
+    if constexpr (VD) {
+        // g_hv = relu'(hv) * (W_rgb^T g_rgb)
+        const MaskBits<4> m_hv = load_bits<4>(a.sv_bits + 8 * BS, pidx, q);
+        tlayer<LayoutB::F_HV, 4, 1, 0, true, 128, NB, NF>(c, Grgb, Grgb, B, m_hv, a.g_hv, pidx, q);
+        // g_feat = W_views[:, :256]^T g_hv          (feature_linear has no activation)
+        tlayer<LayoutB::F_FEAT, 8, 4, 0, false, 256, NB, NF>(c, B, B, A, none, a.g_feat, pidx, q);
+        {   // view-direction encoding: g_dirs = W_views[:, 256:]^T g_hv, then through the encoding
+            float g[2][8 * KD];
+            tenc<LayoutB::F_DIRS, KD, 4, NB, NF>(c, B, g);
+            static_for<2>([&](auto cc_) { constexpr int cc = cc_; encode16_bwd<LD, KD>(dv[cc][0], dv[cc][1], dv[cc][2], hh, bb, g[cc], gd[cc]); });
+        }
+        // g_h8 = relu'(h8) * (W_feature^T g_feat + W_alpha^T g_sigma)
+        m_next = load_bits<8>(a.sv_bits + 6 * BS, pidx, q);
+        tlayer<LayoutB::F_H8, 8, 8, 1, true, 256, NB, NF>(c, A, Gsig, B, m_cur, a.g_h + 7 * HS, pidx, q);
+    } else {
+        // g_h8 = relu'(h8) * (W_output^T dL/draw)
+        m_next = load_bits<8>(a.sv_bits + 6 * BS, pidx, q);
+        tlayer<LayoutB::F_H8, 8, 1, 0, true, 256, NB, NF>(c, Gsig, Gsig, B, m_cur, a.g_h + 7 * HS, pidx, q);
     }
-    // g_h8 = relu'(h8) * (W_feature^T g_feat + W_alpha^T g_sigma)
-    m_next = load_bits<8>(a.sv_bits + 6 * BS, pidx, q);
-    tlayer<LayoutB::F_H8, 8, 8, 1, true, 256, NB, NF>(c, A, Gsig, B, m_cur, a.g_h + 7 * HS, pidx, q);
     // g_h(l-1) = relu'(h(l-1)) * (W_l^T g_h(l)),  l = 7 .. 1   (layer 5 uses the h-columns of its [e | h] input)
     m_cur = m_next; m_next = load_bits<8>(a.sv_bits + 5 * BS, pidx, q);
     tlayer<LayoutB::F_L7 + 0 * 128, 8, 8, 0, true, 256, NB, NF>(c, B, B, A, m_cur, a.g_h + 6 * HS, pidx, q);
@@ -349,32 +377,40 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bwd_s16_kernel(MlpArgs a
                     atomicAdd(a.g_rays + rayi[cc] * 6 + 3 + k, gx[cc][k] * zp[cc]);
                 }
             }
-            if (a.g_vd)
+            if constexpr (VD) {
+                if (a.g_vd)
 #pragma unroll
-                for (int k = 0; k < 3; ++k) atomicAdd(a.g_vd + rayi[cc] * 3 + k, gd[cc][k]);
+                    for (int k = 0; k < 3; ++k) atomicAdd(a.g_vd + rayi[cc] * 3 + k, gd[cc][k]);
+            }
         }
     });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // no LDS-DMA may outlive the workgroup
 }
 
-template <int LX, int LD>
+template <int LX, int LD, bool VD>
 static int launch_bwd(const MlpArgs &a, int n_frags_used, hipStream_t s) {
-    constexpr int KE = gen16_ksteps(LX), KD = gen16_ksteps(LD);
-    using C = Ctx<8, 16, NA_EXPERIMENT_BWD_NS, 8, 2, 0, 1, 0, BwdLedger<KE, KD>>;
-    if (n_frags_used != LayoutB<KE, KD>::F_END) return NERF_AMD_EINVAL;
+    constexpr int KE = gen16_ksteps(LX), KD = VD ? gen16_ksteps(LD) : 1;
+    using C = Ctx<8, 16, NA_EXPERIMENT_BWD_NS, 8, 2, 0, 1, 0, BwdLedger<KE, KD, VD>>;
+    if (n_frags_used != LayoutB<KE, KD, VD>::F_END) return NERF_AMD_EINVAL;
     if (a.P <= 0) return NERF_AMD_OK;
     if (a.P >= (int64_t)1 << 31) return NERF_AMD_EINVAL;
+    if (!VD && a.out_ch > 16) return NERF_AMD_EUNSUPPORTED;
     const size_t lds = C::RING_BYTES;
     static DynamicLdsOptIn opt_in;
-    if (opt_in.ensure(reinterpret_cast<const void *>(mlp_bwd_s16_kernel<LX, LD, C>), lds) != hipSuccess) return NERF_AMD_EHIP;
+    if (opt_in.ensure(reinterpret_cast<const void *>(mlp_bwd_s16_kernel<LX, LD, VD, C>), lds) != hipSuccess) return NERF_AMD_EHIP;
     const int64_t groups = (a.P + 255) / 256;
-    hipLaunchKernelGGL((mlp_bwd_s16_kernel<LX, LD, C>), dim3((unsigned)groups), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((mlp_bwd_s16_kernel<LX, LD, VD, C>), dim3((unsigned)groups), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
 
-int launch_mlp_bwd_s16(const MlpArgs &a, int multires, int multires_views, int n_frags_used, hipStream_t s) {
-    if (multires == 10 && multires_views == 4) return launch_bwd<10, 4>(a, n_frags_used, s);
-    if (multires == 15 && multires_views == 6) return launch_bwd<15, 6>(a, n_frags_used, s);
+int launch_mlp_bwd_s16(const MlpArgs &a, int multires, int multires_views, int use_viewdirs, int n_frags_used, hipStream_t s) {
+    if (use_viewdirs) {
+        if (multires == 10 && multires_views == 4) return launch_bwd<10, 4, true>(a, n_frags_used, s);
+        if (multires == 15 && multires_views == 6) return launch_bwd<15, 6, true>(a, n_frags_used, s);
+    } else {
+        if (multires == 10) return launch_bwd<10, 0, false>(a, n_frags_used, s);
+        if (multires == 15) return launch_bwd<15, 0, false>(a, n_frags_used, s);
+    }
     return NERF_AMD_EUNSUPPORTED;
 }
 

@@ -144,7 +144,7 @@ int build_program(const nerf_amd_arch &a, Program &p, const char **err) {
         // ---- backward stream: g_in^T = W^T g_out^T, layer -> pair of 16-row input-feature tiles ->
         //      segment -> k-step -> tile of the pair (parameter gradients only: the encodings' own
         //      gradients, i.e. ray gradients, are not propagated)
-        if (a.use_viewdirs) {
+        {
             struct SegT { int tensor, kind, col_base, nk; };
             auto add_bwd = [&](int n_in, std::initializer_list<SegT> segs) {
                 for (int t = 0; t < n_in / 16; t += 2)
@@ -161,10 +161,14 @@ int build_program(const nerf_amd_arch &a, Program &p, const char **err) {
                         for (int u = 0; u < 2; ++u)
                             p.frags_bwd.push_back({tensor, FRAG_TE16, 16 * (t + u), col_base, ks, p.tensors[tensor].n_out, L, 0});
             };
-            add_bwd(W / 2, {SegT{D + 3, FRAG_TG16, 0, 1}});                                    // g_hv   <- rgb_linear
-            add_bwd(W, {SegT{D + 2, FRAG_T16, 0, (W / 2) / 32}});                              // g_feat <- views_linears.0
-            add_bwd_enc(D + 2, W, 32 * p.KD16, Ld, (W / 2) / 32);                              // g_dirs <- views_linears.0[:, W:]
-            add_bwd(W, {SegT{D + 0, FRAG_T16, 0, W / 32}, SegT{D + 1, FRAG_TG16, 0, 1}});      // g_h8   <- feature + alpha
+            if (a.use_viewdirs) {
+                add_bwd(W / 2, {SegT{D + 3, FRAG_TG16, 0, 1}});                                // g_hv   <- rgb_linear
+                add_bwd(W, {SegT{D + 2, FRAG_T16, 0, (W / 2) / 32}});                          // g_feat <- views_linears.0
+                add_bwd_enc(D + 2, W, 32 * p.KD16, Ld, (W / 2) / 32);                          // g_dirs <- views_linears.0[:, W:]
+                add_bwd(W, {SegT{D + 0, FRAG_T16, 0, W / 32}, SegT{D + 1, FRAG_TG16, 0, 1}});  // g_h8   <- feature + alpha
+            } else {
+                add_bwd(W, {SegT{D, FRAG_TG16, 0, 1}});                                        // g_h8   <- output_linear (<= 16 rows)
+            }
             for (int l = D - 1; l >= 1; --l) {                                                 // g_h(l) <- pts_linears.l
                 add_bwd(W, {SegT{l, FRAG_T16, is_skip(l - 1) ? p.input_ch : 0, W / 32}});
                 if (is_skip(l - 1)) add_bwd_enc(l, 0, 32 * p.KE16, Lx, W / 32);                // g_e    <- its [input_pts] columns

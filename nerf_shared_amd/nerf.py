@@ -109,7 +109,7 @@ class _FieldTrainFn(torch.autograd.Function):
         if nbytes < 0:
             raise _lib.NerfAmdError("this architecture has no training kernels")
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
-        raw = torch.empty(P, 4, device=dev, dtype=torch.float32)
+        raw = torch.empty(P, 4 if model.use_viewdirs else model.output_ch, device=dev, dtype=torch.float32)
         with torch.cuda.device(dev):
             _lib.check(lib.nerf_amd_field_forward_train(handle, _lib.ptr(pts), _lib.ptr(viewdirs), _lib.ptr(rays),
                                                         rays.shape[1] if rays is not None else 0, _lib.ptr(z_vals),
@@ -143,7 +143,7 @@ class _FieldTrainFn(torch.autograd.Function):
         need_pts, need_vd, need_rays = ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
         g_pts = torch.empty(R * S, 3, device=dev, dtype=torch.float32) if (pts is not None and need_pts) else None
         g_rays6 = torch.zeros(R, 6, device=dev, dtype=torch.float32) if (rays is not None and need_rays) else None
-        g_vd = torch.zeros(R, 3, device=dev, dtype=torch.float32) if ((pts is not None and need_vd) or g_rays6 is not None) else None
+        g_vd = torch.zeros(R, 3, device=dev, dtype=torch.float32) if (model.use_viewdirs and ((pts is not None and need_vd) or g_rays6 is not None)) else None
         with torch.cuda.device(dev):
             _lib.check(lib.nerf_amd_field_backward(model._handle, g.data_ptr(), _lib.ptr(pts), _lib.ptr(viewdirs), _lib.ptr(rays),
                                                    rays.shape[1] if rays is not None else 0, _lib.ptr(z_vals), R, S,
@@ -151,14 +151,14 @@ class _FieldTrainFn(torch.autograd.Function):
                                                    _lib.ptr(g_vd), _lib.stream_of(dev)), "nerf_amd_field_backward")
         ctx.ws = None
         g_rays = None
-        if g_rays6 is not None:           # [R, 11] = d/d(o, d, near, far, viewdir)
-            g_rays = torch.cat([g_rays6, torch.zeros(R, 2, device=dev), g_vd], -1)
+        if g_rays6 is not None:           # [R, 11] = d/d(o, d, near, far, viewdir); [R, 8] without view branch
+            g_rays = torch.cat([g_rays6, torch.zeros(R, 2, device=dev)] + ([g_vd] if g_vd is not None else []), -1)
         grads = []                        # parameter order of _train_params(): weight, bias per linear
         parts = flat.split([sh[0] * sh[1] for sh in shapes] + [sh[0] for sh in shapes])
         for i, shape in enumerate(shapes):
             grads.append(parts[i].view(shape))
             grads.append(parts[n + i])
-        return (None, g_pts, g_vd if (pts is not None and need_vd) else None, g_rays, None, None, None) + tuple(grads)
+        return (None, g_pts, g_vd if (pts is not None and need_vd and g_vd is not None) else None, g_rays, None, None, None) + tuple(grads)
 
 
 # The packed device copy of a model's weights is refreshed when a parameter's (data_ptr, _version)
@@ -320,8 +320,8 @@ class NeRF(nn.Module):
         if prec != "bf16" or not self.__dict__['_trainable_kernels']:
             raise _lib.NerfAmdError(
                 "gradients were requested (grad mode is on and a parameter or input requires grad) but the HIP "
-                "training kernels cover NeRF(D=8, W=256, skips=[4], use_viewdirs=True) with multires/multires_views "
-                "10/4 or 15/6 in precision 'bf16'; this model is %s(D=%d, W=%d, skips=%s, use_viewdirs=%s, multires=%d, "
+                "training kernels cover NeRF(D=8, W=256, skips=[4]) with use_viewdirs=True and multires/multires_views "
+                "10/4 or 15/6, or use_viewdirs=False with multires 10 or 15 and output_ch <= 16, in precision 'bf16'; this model is %s(D=%d, W=%d, skips=%s, use_viewdirs=%s, multires=%d, "
                 "multires_views=%d) in precision '%s'.  For inference wrap the call in torch.no_grad() or call "
                 "model.requires_grad_(False); there is no PyTorch fallback"
                 % (type(self).__name__, self.D, self.W, list(self.skips), self.use_viewdirs, self.multires,
@@ -333,7 +333,7 @@ class NeRF(nn.Module):
         differentiable with respect to the parameters and the ray batch."""
         R, S = z_vals.shape
         raw = _FieldTrainFn.apply(self, None, None, rays, z_vals, R, S, *self._train_params())
-        return raw.reshape(R, S, 4)
+        return raw.reshape(R, S, 4 if self.use_viewdirs else self.output_ch)
 
     def _precision_code(self):
         name = self.precision or _default_precision

@@ -28,8 +28,11 @@ class Adam(torch.optim.Adam):
                          foreach=False, fused=False)
         # Per group, while every parameter of the group steps together (the training loop's case): the common step
         # count and the pointer tables of exp_avg / exp_avg_sq.  The per-parameter `step` tensors of the state (CPU
-        # scalars, as in torch.optim.Adam) are brought up to date by state_dict() -- 48 scalar tensor increments per
-        # step would cost more host time than the launch.
+        # scalars, as in torch.optim.Adam) are brought up to date by state_dict() / copies / pickles -- 48 scalar tensor
+        # increments per step would cost more host time than the launch; code that reads optimizer.state[p]["step"]
+        # between steps calls optimizer.state_dict() first (or _sync_steps()).  Replacing a state tensor by hand
+        # (state[p]["exp_avg"] = ...) needs load_state_dict() or add_param_group() to drop the cached tables; a parameter
+        # that moved is noticed by its data_ptr.
         self._together = {}
 
     # -- torch.optim.Optimizer surface -------------------------------------------
@@ -43,7 +46,10 @@ class Adam(torch.optim.Adam):
 
     def state_dict(self):
         self._sync_steps()
-        return super().state_dict()
+        sd = super().state_dict()
+        for g in sd["param_groups"]:       # a checkpoint loaded into the reference's torch.optim.Adam must not pin its slow
+            g["foreach"] = g["fused"] = None   # single-tensor loop: leave the implementation choice to the loading side
+        return sd
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
@@ -78,6 +84,11 @@ class Adam(torch.optim.Adam):
             grads = [p.grad for p in params]
             mask = tuple(g is not None for g in grads)
             c = self._together.get(gi)
+            if c is not None and c["mask"] == mask and c["ptrs"] != tuple(p.data_ptr() for p in c["params"]):
+                # a parameter moved (model.to(), .half() and back, a replaced tensor): the cached pointer tables are stale
+                self._sync_steps(gi)
+                del self._together[gi]
+                c = None
             if c is not None and c["mask"] == mask:
                 # the same parameters as last time got gradients (a model's unused tensors never do -- the reference's
                 # NeRF(use_viewdirs=False) keeps an idle views_linears.0): one counter, cached tables, one launch
@@ -105,7 +116,8 @@ class Adam(torch.optim.Adam):
                 tables = self._tables(ps)
                 self._launch(ps, gs, tables, step, group)
                 if len(by_step) == 1:
-                    self._together[gi] = {"mask": mask, "step": step, "tables": tables, "params": ps}
+                    self._together[gi] = {"mask": mask, "step": step, "tables": tables, "params": ps,
+                                          "ptrs": tuple(p.data_ptr() for p in ps)}
         return loss
 
     @staticmethod

@@ -89,24 +89,34 @@ class _RoundBf16(torch.autograd.Function):
 
 
 def bf16_field(sd, pts, vd, Lx=10, Ld=4):
-    """The view-branch NeRF.MLP (nerf.py:110-134) with the kernel's roundings: weights, encodings and
-    every hidden activation rounded to bf16, fp32 accumulation, fp32 bias/ReLU.  Differentiable."""
+    """NeRF.MLP (nerf.py:110-134) with the kernel's roundings: weights, encodings and
+    every hidden activation rounded to bf16, fp32 accumulation, fp32 bias/ReLU.  Differentiable.
+    vd None: the output_linear model (nerf.py:131-132)."""
     rb = _RoundBf16.apply
     lin = lambda n, x: torch.nn.functional.linear(x, rb(sd[n + ".weight"]), sd[n + ".bias"])   # noqa: E731
     e = rb(O.embed(pts.reshape(-1, 3), Lx))
-    d = rb(O.embed(vd[:, None].expand(pts.shape).reshape(-1, 3), Ld))
     h = e
     for i in range(8):
         h = rb(torch.relu(lin("pts_linears.%d" % i, h)))
         if i == 4:
             h = torch.cat([e, h], -1)
+    if vd is None:
+        out = lin("output_linear", h)
+        return out.reshape(list(pts.shape[:-1]) + [out.shape[-1]])
+    d = rb(O.embed(vd[:, None].expand(pts.shape).reshape(-1, 3), Ld))
     sigma = lin("alpha_linear", h)
     feat = rb(lin("feature_linear", h))
     hv = rb(torch.relu(lin("views_linears.0", torch.cat([feat, d], -1))))
     return torch.cat([lin("rgb_linear", hv), sigma], -1).reshape(list(pts.shape[:-1]) + [4])
 
 
-@pytest.mark.parametrize("seed,sharpen,arch", [(0, 1.0, VD), (1, 2.0, VD), (2, 1.0, VD15)])
+NOVD = dict(D=8, W=256, output_ch=5, skips=[4], use_viewdirs=False, multires=10, multires_views=4)   # create_nerf_models without --use_viewdirs
+NOVD4 = dict(NOVD, output_ch=4)                         # NeRF()'s own defaults (nerf.py:62)
+NOVD15 = dict(NOVD, multires=15, output_ch=13)          # a third tile row group of output_linear: columns 8..12 come from lane quarter 1
+
+
+@pytest.mark.parametrize("seed,sharpen,arch", [(0, 1.0, VD), (1, 2.0, VD), (2, 1.0, VD15), (3, 1.0, NOVD), (4, 2.0, NOVD4), (5, 1.0, NOVD15)],
+                         ids=["vd_s0", "vd_x2", "vd_15_6", "novd", "novd_out4_x2", "novd_15_out13"])
 def test_field_backward_matches_autograd(dev, seed, sharpen, arch):
     """dL/dtheta of NeRF.forward for a random linear loss on raw, HIP against torch.autograd on
     (a) the same network with the kernel's bf16 roundings (same ReLU masks): relative L2 error
@@ -122,22 +132,27 @@ def test_field_backward_matches_autograd(dev, seed, sharpen, arch):
     pts = torch.from_numpy(rng.uniform(-2, 2, size=(R, S, 3)).astype(np.float32))
     vd = torch.from_numpy(rng.normal(size=(R, 3)).astype(np.float32))
     vd = vd / vd.norm(dim=-1, keepdim=True)
-    coef = torch.from_numpy(rng.normal(size=(R, S, 4)).astype(np.float32))
+    if not arch["use_viewdirs"]:
+        vd = None
+    coef = torch.from_numpy(rng.normal(size=(R, S, 4 if arch["use_viewdirs"] else arch["output_ch"])).astype(np.float32))
     m, cpu = _models(dev, seed, sharpen, arch)
     (O.nerf_forward(cpu, O.Arch(**arch), pts, vd) * coef).sum().backward()
     cpu_b = {k: v.detach().clone().requires_grad_(True) for k, v in cpu.items()}
     out_b = bf16_field(cpu_b, pts, vd, arch["multires"], arch["multires_views"])
     (out_b * coef).sum().backward()
-    out = m(pts.to(dev), vd.to(dev))
+    out = m(pts.to(dev), vd.to(dev) if vd is not None else None)
     assert out.requires_grad
     (out * coef.to(dev)).sum().backward()
     # forward: the kernel against its own rounding model, and training forward == inference forward
     print("forward rel err vs bf16 model", rel_err(out, out_b))
     assert rel_err(out, out_b) < 1e-3
     with torch.no_grad():
-        torch.testing.assert_close(m(pts.to(dev), vd.to(dev)), out.detach(), rtol=0, atol=0)
+        torch.testing.assert_close(m(pts.to(dev), vd.to(dev) if vd is not None else None), out.detach(), rtol=0, atol=0)
     table = []
     for name, p in m.named_parameters():
+        if cpu[name].grad is None:               # views_linears.0 of an output_linear model: unused there too (nerf.py:83)
+            assert p.grad is None, name
+            continue
         assert p.grad is not None and p.grad.shape == cpu[name].shape, name
         g = p.grad.detach().cpu()
         assert torch.isfinite(g).all(), name
@@ -590,6 +605,68 @@ def test_training_gradients_of_the_other_render_configurations(dev, monkeypatch,
             worst = max(worst, e)
     print(variant, "worst relative gradient error %.4f" % worst)
     assert worst < 8e-2, worst
+
+
+def test_training_without_view_branch(dev, monkeypatch):
+    """The model main.py builds without --use_viewdirs (config_parser.py:50; nerf.py:91-94,131-132: output_linear with
+    output_ch = 5 when N_importance > 0, utils.py:127-131) through the reference's training loss: Renderer.render(rays=...)
+    with [R, 8] ray batches, mse(rgb) + mse(rgb0), both networks.  Parameter gradients against torch.autograd on the oracle
+    with the kernel's roundings; the unused views_linears.0 parameters get no gradient, as in the reference; gradients also
+    reach the rays (pose estimation without view directions)."""
+    from nerf_shared_amd import render_utils
+    batch, target = _batch(80, 21)
+    cfg = dict(BASE, N_samples=32, N_importance=40, use_viewdirs=False)
+    r = render_utils.Renderer(**cfg)
+    mc, cc = _models(dev, 2, 1.0, NOVD)
+    mf, cf = _models(dev, 12, 1.0, NOVD)
+    with torch.no_grad():                    # lift the density bias: a semi-transparent volume, non-degenerate gradients
+        for m, sd in ((mc, cc), (mf, cf)):
+            m.output_linear.bias[3] += 0.3
+            sd["output_linear.bias"][3] += 0.3
+    ro = batch[:, 0:3].clone().to(dev).requires_grad_(True)
+    rd = batch[:, 3:6].clone().to(dev).requires_grad_(True)
+    rgb, disp, acc, extras = r.render(400, 400, None, mc, mf, chunk=48, rays=(ro, rd), retraw=True)
+    assert extras["raw"].shape == (80, 72, 5)
+    t = target.to(dev)
+    loss = ((rgb - t) ** 2).mean() + ((extras["rgb0"] - t) ** 2).mean()
+    loss.backward()
+    assert ro.grad is not None and rd.grad is not None and bool(torch.isfinite(ro.grad).all()) and float(ro.grad.abs().sum()) > 0
+
+    monkeypatch.setattr(O, "nerf_forward", lambda sd, arch, pts, vd, netchunk=0: bf16_field(sd, pts, None))
+    c = {k: v.detach().clone().requires_grad_(True) for k, v in cc.items()}
+    f = {k: v.detach().clone().requires_grad_(True) for k, v in cf.items()}
+    o = O.render(O.RenderCfg(**cfg), 400, 400, None, (c, O.Arch(**NOVD)), (f, O.Arch(**NOVD)), chunk=48,
+                 rays=(batch[:, 0:3], batch[:, 3:6]), retraw=True)
+    l = ((o[0] - target) ** 2).mean() + ((o[3]["rgb0"] - target) ** 2).mean()
+    l.backward()
+    monkeypatch.undo()
+    assert abs(float(loss) - float(l)) < 3e-3 * max(1.0, abs(float(l)))
+    worst = 0.0
+    for m, ref in ((mc, c), (mf, f)):
+        for name, p in m.named_parameters():
+            if name.startswith("views_linears"):
+                assert p.grad is None and ref[name].grad is None, name
+                continue
+            assert p.grad is not None and torch.isfinite(p.grad).all(), name
+            e = rel_err(p.grad.detach().cpu(), ref[name].grad)
+            print("   %-26s %.4f   |g| %.3e" % (name, e, float(ref[name].grad.norm())))
+            assert float(ref[name].grad.norm()) > 0, "degenerate test: zero gradient"
+            worst = max(worst, e)
+    print("no view branch: worst relative gradient error %.4f" % worst)
+    assert worst < 8e-2, worst
+    # a few Adam steps through the library optimizer lower the loss (the packed weights follow)
+    from nerf_shared_amd import utils
+    from types import SimpleNamespace
+    opt = utils.get_optimizer(mc, mf, SimpleNamespace(lrate=5e-4))
+    losses = []
+    for _ in range(8):
+        opt.zero_grad(set_to_none=True)
+        rgb, _, _, extras = r.render(400, 400, None, mc, mf, chunk=128, rays=(batch[:, 0:3].to(dev), batch[:, 3:6].to(dev)), retraw=True)
+        ls = ((rgb - t) ** 2).mean() + ((extras["rgb0"] - t) ** 2).mean()
+        ls.backward()
+        opt.step()
+        losses.append(float(ls))
+    assert losses[-1] < losses[0], losses
 
 
 def test_training_gradients_through_render_with_ndc_rays(dev, monkeypatch):

@@ -688,13 +688,15 @@ def test_sample_counts_beyond_the_lds_are_refused_with_the_real_reason(dev):
 def test_gradient_requests_outside_the_training_kernels_raise(dev):
     """main.py:103 calls loss.backward() on whatever render() returned: a model the HIP training kernels do not
     cover must raise when gradients are requested instead of returning outputs without autograd history
-    (nerf.py:91-94 output_linear branch, precision fp32, other widths).  Under no_grad it renders."""
+    (precision fp32 / fp32_split, other depths and widths, an output_linear model with multires the kernels are not
+    instantiated for).  Under no_grad it renders."""
     nerf, render_utils, utils = amd()
     from nerf_shared_amd._lib import NerfAmdError
     K = synth.lego_intrinsics(40, 40)
     r = render_utils.Renderer(**dict(BASE, N_samples=16, N_importance=16))
     small = dict(D=4, W=128, output_ch=4, skips=[1], use_viewdirs=True, multires=6, multires_views=2)
-    cases = [("fp32 precision", VD, "fp32", True), ("no view branch", NOVD, "bf16", False), ("D=4 W=128", small, "bf16", True)]
+    cases = [("fp32 precision", VD, "fp32", True), ("split precision", VD, "fp32_split", True),
+             ("no view branch, multires 6", dict(NOVD, multires=6), "bf16", False), ("D=4 W=128", small, "bf16", True)]
     for label, arch, prec, vd in cases:
         rr = render_utils.Renderer(**dict(BASE, N_samples=16, N_importance=16, use_viewdirs=vd))
         m = nerf.NeRF(**arch).to(dev)
@@ -717,12 +719,17 @@ def test_gradient_requests_outside_the_training_kernels_raise(dev):
         rays = batch.clone().requires_grad_(True)                      # ... unless the rays do (pose estimation)
         with pytest.raises(NerfAmdError, match="gradients were requested"):
             rr.render_rays(rays, m, m)
-    # the covered model in bf16 keeps its history
-    m = nerf.NeRF(**VD).to(dev)
-    out = r.render_rays(utils.make_ray_batch(40, 40, K, synth.LEGO_C2W, 2.0, 6.0, True, False, device=dev, n=64), m, m)
-    assert out["rgb_map"].requires_grad
-    out["rgb_map"].sum().backward()
-    assert m.pts_linears[0].weight.grad is not None and bool(torch.isfinite(m.pts_linears[0].weight.grad).all())
+    # the covered models in bf16 keep their history: with the view branch, and the output_linear model that
+    # NeRF() / config_parser.py:50 build by default (use_viewdirs=False)
+    for arch, vd in ((VD, True), (NOVD, False), (dict(D=8, W=256, skips=[4]), False)):
+        m = nerf.NeRF(**arch).to(dev)
+        rr = render_utils.Renderer(**dict(BASE, N_samples=16, N_importance=16, use_viewdirs=vd))
+        out = rr.render_rays(utils.make_ray_batch(40, 40, K, synth.LEGO_C2W, 2.0, 6.0, vd, False, device=dev, n=64), m, m)
+        assert out["rgb_map"].requires_grad
+        out["rgb_map"].sum().backward()
+        assert m.pts_linears[0].weight.grad is not None and bool(torch.isfinite(m.pts_linears[0].weight.grad).all())
+        head = m.rgb_linear if vd else m.output_linear
+        assert head.weight.grad is not None and float(head.weight.grad.abs().sum()) > 0
 
 
 # ------------------------------------------------------------------ properties at the benchmark batch size
