@@ -2,7 +2,7 @@
 // standalone positional encoding.
 //
 // Replaces Embedder.embed (/root/reference/nerf_shared/nerf.py:16-41) and
-// NeRF.forward + NeRF.MLP (nerf.py:96-134) for every D / W (multiple of 32) /
+// NeRF.forward + NeRF.MLP (nerf.py:96-134) for every D / W (2..1024, any value) /
 // skips / multires / viewdirs combination the reference constructor accepts.
 // This is the parity path (v_mfma_f32_32x32x2_f32 is a bit-exact fp32 fma
 // chain) and the fallback for architectures the fused bf16 kernel does not

@@ -13,8 +13,7 @@
 //     acc_l += W_hi x_lo + W_lo x_hi        (two MFMAs)          y = acc_h + 2^-11 acc_l + bias
 // and the dropped W_lo x_lo term is 2^-22 relative.  (bf16 pairs carry 16 bits: measured on the x3 weight sets
 // against an fp64 evaluation they miss the fp32 gates, 1e-4 + 1e-4 |y|, by 4-6x; fp16 pairs are inside them
-// by 4x, i.e. as far from fp64 as the fp32 reference itself.)  Values below 2^-14 in magnitude go entirely
-// to the lo part, so no operand is an fp16 denormal.  Range: |activation| must stay below 65504.
+// by 4x, i.e. as far from fp64 as the fp32 reference itself.)  Range: |activation| must stay below 65504.
 //
 // Layout.  The machinery of mlp_bf16_s16.hip (program.h "s16" layout, pipeline.h ring) with the two column
 // tiles of a wave re-used as (hi, lo) of ONE 16-point tile: a wave owns 16 points, a workgroup 128.
@@ -41,10 +40,11 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4s;
 
 constexpr float SPLIT_SCALE = 2048.0f, SPLIT_INV = 1.0f / 2048.0f;
 
-// x -> (hi, lo) as fp16 bit patterns.  hi = fp16(x) rounded to nearest, 0 where that would be a denormal.
+// x -> (hi, lo): hi = fp16(x) rounded to nearest, lo = fp16 of the (exact) residual scaled by 2^11.  A denormal hi is
+// fine: v_mfma_f32_16x16x32_f16 multiplies fp16 denormals exactly (tools/micro/mfma_f16_denorm.hip), and the residual
+// carries whatever hi could not.
 __device__ __forceinline__ void split_f16(float x, _Float16 &hi, _Float16 &lo) {
-    _Float16 h = (_Float16)x;
-    if (__builtin_fabsf(x) < 6.103515625e-05f) h = (_Float16)0.0f;
+    const _Float16 h = (_Float16)x;
     hi = h;
     lo = (_Float16)((x - (float)h) * SPLIT_SCALE);
 }

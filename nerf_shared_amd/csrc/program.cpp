@@ -10,7 +10,9 @@ struct Seg { int kind, col_base, len, nk, L; };
 int build_program(const nerf_amd_arch &a, Program &p, const char **err) {
     p = Program();
     p.arch = a;
-    if (a.D < 1 || a.D > 64 || a.W < 32 || a.W % 32 != 0 || a.W > 1024) { *err = "D/W out of range (W must be a multiple of 32)"; return -1; }
+    // any width the reference constructor takes, up to 1024: the fp32 kernel's 32-row tiles and 8-column groups are
+    // guarded / zero-padded (mlp_fp32.hip), W / 2 is the reference's W // 2 (nerf.py:83)
+    if (a.D < 1 || a.D > 64 || a.W < 2 || a.W > 1024) { *err = "D/W out of range (D 1..64, W 2..1024)"; return -1; }
     if (a.n_skips < 0 || a.n_skips > NERF_AMD_MAX_SKIPS) { *err = "too many skips"; return -1; }
     if (a.i_embed != 0 && a.i_embed != -1) { *err = "i_embed must be 0 or -1"; return -1; }
     if (a.multires < 0 || a.multires > 20 || a.multires_views < 0 || a.multires_views > 20) { *err = "multires out of range"; return -1; }

@@ -576,6 +576,13 @@ int launch_resample(const float *z_coarse, const float *weights, const float *u,
 // get_rays + viewdirs + ndc_rays + batch assembly: utils.py:33-71,
 // render_utils.py:200-226.  One thread per pixel.
 // ---------------------------------------------------------------------------
+// |v| of a 3-vector, the library's one definition (make_rays, assemble_rays): separately rounded squares summed as
+// (x^2 + z^2) + y^2, correctly rounded sqrt (this file is built with -ffp-contract=off).  It is the order torch.norm(v, dim=-1)
+// uses for 3 elements on the build this was written against (torch 2.10 / ROCm 7, tools/micro/norm_probe.py), so the fast
+// rays= path equals the autograd-tracked torch expression bit for bit there; on another torch the two may differ by one
+// ulp of the norm, which is why parity tests compare view directions with a tolerance (2e-7), not bit for bit.
+__device__ __forceinline__ float norm3(float x, float y, float z) { return sqrtf((x * x + z * z) + y * y); }
+
 struct RayGen {
     float fx, fy, cx, cy;
     float c2w[12], c2ws[12];
@@ -605,7 +612,7 @@ __global__ __launch_bounds__(256) void make_rays_kernel(RayGen g, int64_t pix0, 
     const int ch = g.use_viewdirs ? 11 : 8;
     float *row = out + idx * ch;
     if (g.use_viewdirs) {
-        const float nrm = sqrtf(vd[0] * vd[0] + vd[1] * vd[1] + vd[2] * vd[2]);
+        const float nrm = norm3(vd[0], vd[1], vd[2]);      // one summation order for every path that normalises a view direction
         row[8] = vd[0] / nrm; row[9] = vd[1] / nrm; row[10] = vd[2] / nrm;
     }
     if (g.ndc) {
@@ -844,10 +851,7 @@ __global__ __launch_bounds__(256) void assemble_rays_kernel(const float *o, cons
     r[6] = near; r[7] = far;
     if (v) {
         const float x = v[3 * i], y = v[3 * i + 1], z = v[3 * i + 2];
-        // torch.norm(v, dim=-1) of a 3-vector on this build (torch 2.10 / ROCm 7): the squares are rounded on their own and the
-        // reduction tree pairs elements 0 and 2 first -- sqrt((x^2 + z^2) + y^2), measured bit for bit on 1e5 vectors
-        // (tools/micro/norm_probe.py); sqrt and the division are correctly rounded (this file is built without contraction)
-        const float nrm = sqrtf((x * x + z * z) + y * y);
+        const float nrm = norm3(x, y, z);
         r[8] = x / nrm; r[9] = y / nrm; r[10] = z / nrm;
     }
 }

@@ -158,6 +158,23 @@ def test_nerf_forward_fp32_other_archs(dev, golden):
     close(gpu_model(dev, 5, 3.0, "bf16", **small)(pts, vd), g["small_s1"], atol=1e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("arch", [dict(D=3, W=100, output_ch=4, skips=[1], use_viewdirs=True, multires=5, multires_views=3),
+                                  dict(D=5, W=37, output_ch=7, skips=[2], use_viewdirs=False, multires=4, multires_views=4),
+                                  dict(D=2, W=250, output_ch=4, skips=[], use_viewdirs=True, multires=10, multires_views=4)],
+                         ids=["W100", "W37_novd", "W250"])
+def test_nerf_forward_any_width(dev, arch):
+    """The reference constructor takes any width (nerf.py:62-94: W and W // 2 are plain nn.Linear sizes): widths that are
+    not multiples of the fp32 kernel's 32-row tiles / 8-column groups against the oracle, view branch with an odd W // 2
+    included.  (bf16 / split precision requested on such a model run on the exact kernel.)"""
+    rng = np.random.default_rng(4)
+    pts = torch.from_numpy(rng.uniform(-2, 2, size=(41, 7, 3)).astype(np.float32))
+    vd = torch.nn.functional.normalize(torch.from_numpy(rng.normal(size=(41, 3)).astype(np.float32)), dim=-1) if arch["use_viewdirs"] else None
+    ref = O.nerf_forward(*cpu_model(9, 2.0, **arch), pts, vd)
+    for prec in ("fp32", "bf16", "fp32_split"):
+        out = gpu_model(dev, 9, 2.0, prec, **arch)(pts.to(dev), vd.to(dev) if vd is not None else None)
+        close(out, ref, atol=1e-4, rtol=1e-4)
+
+
 @pytest.mark.parametrize("tag,seed,sharpen", [("s0", 0, 1.0), ("s1", 1, 3.0)])
 def test_nerf_forward_bf16_golden(dev, golden, tag, seed, sharpen):
     g = golden("g2_nerf")

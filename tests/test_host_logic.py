@@ -42,10 +42,12 @@ def test_struct_layouts_match_header():
 def test_program_validation_errors():
     lib = _lib.lib
     h = ctypes.c_void_p()
-    bad = _lib.make_arch(8, 250, 4, [4], True, 10, 4, 0)        # W not a multiple of 32
+    bad = _lib.make_arch(8, 1056, 4, [4], True, 10, 4, 0)       # W beyond the fp32 kernel's tile budget
     nf = ctypes.c_int64()
     assert lib.nerf_amd_pack_bf16_host(ctypes.byref(bad), 32, None, None, 0, None, ctypes.byref(nf), None, None) == -1
-    assert b"multiple of 32" in lib.nerf_amd_last_error()
+    assert b"W 2..1024" in lib.nerf_amd_last_error()
+    odd = _lib.make_arch(8, 250, 4, [4], True, 10, 4, 0)        # any other width is a valid program (exact-fp32 kernel only)
+    assert lib.nerf_amd_pack_bf16_host(ctypes.byref(odd), 32, None, None, 0, None, ctypes.byref(nf), None, None) == -3
     bad = _lib.make_arch(8, 256, 4, [7], True, 10, 4, 0)        # skip on the last layer: the reference fails too
     assert lib.nerf_amd_pack_bf16_host(ctypes.byref(bad), 32, None, None, 0, None, ctypes.byref(nf), None, None) == -1
     with pytest.raises(ValueError):

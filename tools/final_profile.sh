@@ -2,7 +2,7 @@
 # Round-end measurement pass on the GPU box: the bench line and the rocprofv3 summaries that go under profiles/.
 #   tools/final_profile.sh <tag>      -> gpurun_out/final_<tag>/...
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/final_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
