@@ -49,6 +49,23 @@ __device__ __forceinline__ void split_f16(float x, _Float16 &hi, _Float16 &lo) {
     lo = (_Float16)((x - (float)h) * SPLIT_SCALE);
 }
 
+// Two values at once, on packed registers: hi = (fp16(x0), fp16(x1)) is one v_cvt_pk_f16_f32; each lo is ONE mixed-precision
+// fma that reads its hi straight out of the packed register -- fp16(-2^11 hi + 2^11 x), both products exact, one rounding: the
+// same value as split_f16's, without converting hi back to fp32 (the compiler does not form v_fma_mix from the C expression).
+__device__ __forceinline__ void split_f16_pair(float x0, float x1, f16x2 &hi, f16x2 &lo) {
+    f16x2 h;
+    h[0] = (_Float16)x0; h[1] = (_Float16)x1;
+    typedef __attribute__((ext_vector_type(2))) float f32x2s;
+    const f32x2s sc = f32x2s{x0, x1} * SPLIT_SCALE;          // one v_pk_mul_f32
+    const float kneg = -SPLIT_SCALE;
+    unsigned l;
+    const unsigned hb = __builtin_bit_cast(unsigned, h);
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hb), "v"(kneg), "v"(sc[0]));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hb), "v"(kneg), "v"(sc[1]));
+    hi = h;
+    lo = __builtin_bit_cast(f16x2, l);
+}
+
 template <class C, int NR, int NM>
 __device__ __forceinline__ void sched_step_split() {
     if constexpr ((C::OPT & 4) != 0) {
@@ -111,13 +128,14 @@ __device__ __forceinline__ void pack_pair_split(const f32x4 (&acc)[2][2], bf16x8
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = __builtin_fmaf(acc[u][1][r], SPLIT_INV, acc[u][0][r]);
-            if (RELU) v = relu_bits(v);
-            _Float16 a, b;
-            split_f16(v, a, b);
-            h[4 * u + r] = a;
-            l[4 * u + r] = b;
+        for (int r = 0; r < 4; r += 2) {
+            float v0 = __builtin_fmaf(acc[u][1][r], SPLIT_INV, acc[u][0][r]);
+            float v1 = __builtin_fmaf(acc[u][1][r + 1], SPLIT_INV, acc[u][0][r + 1]);
+            if (RELU) { v0 = relu_bits(v0); v1 = relu_bits(v1); }
+            f16x2 a, b;
+            split_f16_pair(v0, v1, a, b);
+            h[4 * u + r] = a[0]; h[4 * u + r + 1] = a[1];
+            l[4 * u + r] = b[0]; l[4 * u + r + 1] = b[1];
         }
     yh = __builtin_bit_cast(bf16x8, h);
     yl = __builtin_bit_cast(bf16x8, l);
