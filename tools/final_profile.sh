@@ -8,8 +8,10 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 python bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
 tail -c 600 $OUT/bench.json
-# kernel trace + stats of the same command (no CPU leg: it only adds host time)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.err || exit 1
+# kernel trace + stats of the same command (no CPU leg: it only adds host time; no sub-records, so the field kernel's
+# average in the stats is over the metric's own launches -- 10 per view, warm-up included -- and must agree with the
+# bench's hipEvent figure, roofline.avg_launch_ms)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --no-cpu-baseline --no-subrecords > $OUT/bench_under_rocprof.json 2> $OUT/stats.err || exit 1
 # counters: separate passes, --pmc only
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "MfmaUtil" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES" "GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY"; do
   N=$(echo $C | tr ' ' '_' | cut -c1-40)
