@@ -739,7 +739,10 @@ def test_gradient_requests_outside_the_training_kernels_raise(dev):
     # the covered models in bf16 keep their history: with the view branch, and the output_linear model that
     # NeRF() / config_parser.py:50 build by default (use_viewdirs=False)
     for arch, vd in ((VD, True), (NOVD, False), (dict(D=8, W=256, skips=[4]), False)):
-        m = nerf.NeRF(**arch).to(dev)
+        torch.manual_seed(5)                  # nn.Linear's own init: fix it, and lift the density bias so that the volume is
+        m = nerf.NeRF(**arch).to(dev)         # not empty (sigma <= 0 everywhere means zero gradients, legitimately)
+        with torch.no_grad():
+            (m.alpha_linear.bias if vd else m.output_linear.bias[3:4]).add_(1.0)
         rr = render_utils.Renderer(**dict(BASE, N_samples=16, N_importance=16, use_viewdirs=vd))
         out = rr.render_rays(utils.make_ray_batch(40, 40, K, synth.LEGO_C2W, 2.0, 6.0, vd, False, device=dev, n=64), m, m)
         assert out["rgb_map"].requires_grad
