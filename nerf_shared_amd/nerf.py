@@ -93,6 +93,33 @@ def _destroy_handle(handle):
         lib.nerf_amd_model_destroy(handle)
 
 
+class _DeferredGradFn(torch.autograd.Function):
+    """Identity that ties a forward-only result to a tensor that requires grad, with a backward that raises: what a
+    model outside the training kernels returns when gradients were requested (NeRF._grad_request).  The reference would
+    return a differentiable result here; this path renders it the same way and fails loudly -- with the reason -- the
+    moment someone calls backward() through it, instead of refusing the forward (plain inference written without
+    torch.no_grad() keeps working) or silently returning outputs with no history (main.py:103 would train nothing)."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, msg):
+        ctx.msg = msg
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        raise _lib.NerfAmdError(ctx.msg)
+
+
+def attach_deferred_grad(out, deferred):
+    """out: tensor or dict of tensors; deferred: (anchor tensor, message) from NeRF._grad_request, or None."""
+    if deferred is None:
+        return out
+    anchor, msg = deferred
+    if isinstance(out, dict):
+        return {k: _DeferredGradFn.apply(v, anchor, msg) for k, v in out.items()}
+    return _DeferredGradFn.apply(out, anchor, msg)
+
+
 class _FieldTrainFn(torch.autograd.Function):
     """The fused bf16 field with HIP backward kernels: forward saves
     every layer's activations in a workspace tensor; backward runs the dX-chain kernel and the
@@ -306,27 +333,37 @@ class NeRF(nn.Module):
             out += [p['weight'], p['bias']]
         return out
 
-    def _wants_grad(self, device, *inputs):
-        """True when autograd has to flow into the parameters (or the given inputs): gradients are
-        enabled and something requires them.  The training kernels cover the standard model in bf16
-        mode; for anything else this raises -- outputs never silently lose their autograd history
-        (the reference's loss.backward(), main.py:103, would train nothing).  Inference on such a
-        model runs under torch.no_grad() (as render_utils.py:302 does) or after requires_grad_(False)."""
-        if not torch.is_grad_enabled() or not (any(p.requires_grad for p in self._train_params())
-                                               or any(t is not None and t.requires_grad for t in inputs)):
-            return False
+    def _grad_request(self, device, *inputs):
+        """("none", None): no gradient is requested (grad mode off, or nothing requires grad) -> forward-only kernels.
+        ("train", None): gradients are requested and the training kernels cover this model (bf16 mode) -> autograd Functions
+        with HIP backward kernels.
+        ("defer", (anchor, message)): gradients are requested but the training kernels do not cover this model or precision:
+        the call runs on the forward-only kernels and its results are tied to `anchor` by a backward that raises `message`
+        (attach_deferred_grad) -- outputs never silently lose their autograd history (the reference's loss.backward(),
+        main.py:103, would train nothing), and inference written without torch.no_grad() still works as in the reference."""
+        if not torch.is_grad_enabled():
+            return "none", None
+        anchor = next((p for p in self._train_params() if p.requires_grad), None)
+        if anchor is None:
+            anchor = next((t for t in inputs if t is not None and t.requires_grad), None)
+        if anchor is None:
+            return "none", None
         prec = self.precision or _default_precision
         self._ensure_handle(device)
-        if prec != "bf16" or not self.__dict__['_trainable_kernels']:
-            raise _lib.NerfAmdError(
-                "gradients were requested (grad mode is on and a parameter or input requires grad) but the HIP "
-                "training kernels cover NeRF(D=8, W=256, skips=[4]) with use_viewdirs=True and multires/multires_views "
-                "10/4 or 15/6, or use_viewdirs=False with multires 10 or 15 and output_ch <= 16, in precision 'bf16'; this model is %s(D=%d, W=%d, skips=%s, use_viewdirs=%s, multires=%d, "
-                "multires_views=%d) in precision '%s'.  For inference wrap the call in torch.no_grad() or call "
-                "model.requires_grad_(False); there is no PyTorch fallback"
-                % (type(self).__name__, self.D, self.W, list(self.skips), self.use_viewdirs, self.multires,
-                   self.multires_views, prec))
-        return True
+        if prec == "bf16" and self.__dict__['_trainable_kernels']:
+            return "train", None
+        msg = ("backward() reached a result of the forward-only kernels: the HIP training kernels cover NeRF(D=8, W=256, skips=[4]) "
+               "with use_viewdirs=True and multires/multires_views 10/4 or 15/6, or use_viewdirs=False with multires 10 or 15 and "
+               "output_ch <= 16, in precision 'bf16'; this model is %s(D=%d, W=%d, skips=%s, use_viewdirs=%s, multires=%d, "
+               "multires_views=%d, output_ch=%d) in precision '%s'.  Gradients were requested when it was evaluated (grad mode on, a "
+               "parameter or input requiring grad), so the result was given this backward instead of none; there is no PyTorch fallback"
+               % (type(self).__name__, self.D, self.W, list(self.skips), self.use_viewdirs, self.multires,
+                  self.multires_views, self.output_ch, prec))
+        return "defer", (anchor, msg)
+
+    def _wants_grad(self, device, *inputs):
+        """True when the training kernels will run for this call (see _grad_request)."""
+        return self._grad_request(device, *inputs)[0] == "train"
 
     def forward_rays(self, rays, z_vals):
         """raw [R, S, 4] of rays [R, 11] at depths z_vals [R, S] (pts = o + d z formed in the kernel);
@@ -357,7 +394,8 @@ class NeRF(nn.Module):
         tiles points itself, so chunking cannot change the result."""
         _lib.require_device(inputs, "inputs")
         dev = inputs.device
-        want = self._wants_grad(dev, inputs, viewdirs)
+        mode, deferred = self._grad_request(dev, inputs, viewdirs)
+        want = mode == "train"
         pts = (inputs if want else inputs.detach()).reshape(-1, 3).contiguous().float()
         n_samples = inputs.shape[-2] if inputs.dim() >= 2 else 1
         vd = None
@@ -380,7 +418,7 @@ class NeRF(nn.Module):
             _lib.check(lib.nerf_amd_nerf_forward(handle, pts.data_ptr(), _lib.ptr(vd), n_rays, n_samples,
                                                  out.data_ptr(), self._precision_code(), _lib.stream_of(dev)),
                        "nerf_amd_nerf_forward")
-        return out.reshape(list(inputs.shape[:-1]) + [out_ch])
+        return attach_deferred_grad(out.reshape(list(inputs.shape[:-1]) + [out_ch]), deferred)
 
     def MLP(self, x):
         """Already-embedded rows [P, input_ch + input_ch_views] -> [P, 4|output_ch]

@@ -23,6 +23,7 @@ import numpy as np
 import torch
 
 from . import _lib, utils
+from . import nerf as nerf_mod
 from ._lib import lib
 from .nerf import NeRF
 
@@ -408,6 +409,17 @@ class Renderer(torch.nn.Module):
             outs['z_std'] = torch.empty(R, **f)
         return outs
 
+    def _grad_mode(self, coarse_model, fine_model, rays):
+        """The models' gradient requests for one call, combined: "train" only if every model that asks for gradients is
+        covered by the training kernels; one uncovered model defers the whole call (nerf.NeRF._grad_request)."""
+        reqs = [coarse_model._grad_request(rays.device, rays)]
+        if fine_model is not None and self.N_importance > 0:
+            reqs.append(fine_model._grad_request(rays.device, rays))
+        for m, d in reqs:
+            if m == "defer":
+                return m, d
+        return ("train", None) if any(m == "train" for m, _ in reqs) else ("none", None)
+
     def render_rays(self, ray_batch, coarse_model, fine_model, retraw=False, retweights=False,
                     verbose=False, pytest=False):
         """Volumetric rendering of one ray batch (render_utils.py:67-174).
@@ -423,15 +435,14 @@ class Renderer(torch.nn.Module):
         self._check_model(coarse_model, "coarse_model")
         if fine_model is not None:
             self._check_model(fine_model, "fine_model")
-        if rays.shape[0] > 0 and (coarse_model._wants_grad(rays.device, ray_batch)
-                                  or (fine_model is not None and self.N_importance > 0
-                                      and fine_model._wants_grad(rays.device, ray_batch))):
+        mode, deferred = self._grad_mode(coarse_model, fine_model, ray_batch) if rays.shape[0] > 0 else ("none", None)
+        if mode == "train":
             live = ray_batch.contiguous().float() if (torch.is_grad_enabled() and ray_batch.requires_grad) else rays
             return self._render_rays_train(live, coarse_model, fine_model, retraw, retweights, pytest)
         out_ch = 4 if coarse_model.use_viewdirs else coarse_model.output_ch
         outs = self._alloc_outputs(rays.shape[0], rays.device, out_ch, retraw, retweights)
         self._launch(rays, coarse_model, fine_model, outs, retraw, retweights, pytest)
-        ret = outs
+        ret = nerf_mod.attach_deferred_grad(outs, deferred)
         if DEBUG:
             for k in ret:
                 if torch.isnan(ret[k]).any() or torch.isinf(ret[k]).any():
@@ -462,8 +473,12 @@ class Renderer(torch.nn.Module):
         N, dev = rays.shape[0], rays.device
         out_ch = 4 if coarse_model.use_viewdirs else coarse_model.output_ch
         starts = list(range(0, N, chunk))
-        if N > 0 and (coarse_model._wants_grad(dev, rays_flat) or (fine_model is not None and self.N_importance > 0
-                                                                 and fine_model._wants_grad(dev, rays_flat))):
+        mode, deferred = self._grad_mode(coarse_model, fine_model, rays_flat) if N > 0 else ("none", None)
+        if mode == "defer":            # forward-only kernels now, a backward that explains itself later (nerf._grad_request)
+            with torch.no_grad():
+                plain = self.render_batch(coarse_model, fine_model, rays_flat, chunk, retraw)
+            return nerf_mod.attach_deferred_grad(plain, deferred)
+        if mode == "train":
             live = rays_flat if (torch.is_grad_enabled() and rays_flat.requires_grad) else rays
             parts = {}                     # training: autograd graph per chunk, concatenated like the reference
             for i in starts:

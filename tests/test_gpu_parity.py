@@ -703,14 +703,15 @@ def test_sample_counts_beyond_the_lds_are_refused_with_the_real_reason(dev):
 
 
 def test_gradient_requests_outside_the_training_kernels_raise(dev):
-    """main.py:103 calls loss.backward() on whatever render() returned: a model the HIP training kernels do not
-    cover must raise when gradients are requested instead of returning outputs without autograd history
-    (precision fp32 / fp32_split, other depths and widths, an output_linear model with multires the kernels are not
-    instantiated for).  Under no_grad it renders."""
+    """main.py:103 calls loss.backward() on whatever render() returned: for a model the HIP training kernels do not cover
+    (precision fp32 / fp32_split, other depths and widths, an output_linear model with a multires the kernels are not
+    instantiated for) a call made with gradients requested renders on the forward-only kernels -- as the reference would
+    render it, so inference written without torch.no_grad() works -- and returns results that DO carry autograd history:
+    a backward that raises NerfAmdError with the reason.  Nothing comes back silently without history, nothing trains
+    silently wrong."""
     nerf, render_utils, utils = amd()
     from nerf_shared_amd._lib import NerfAmdError
     K = synth.lego_intrinsics(40, 40)
-    r = render_utils.Renderer(**dict(BASE, N_samples=16, N_importance=16))
     small = dict(D=4, W=128, output_ch=4, skips=[1], use_viewdirs=True, multires=6, multires_views=2)
     cases = [("fp32 precision", VD, "fp32", True), ("split precision", VD, "fp32_split", True),
              ("no view branch, multires 6", dict(NOVD, multires=6), "bf16", False), ("D=4 W=128", small, "bf16", True)]
@@ -720,22 +721,32 @@ def test_gradient_requests_outside_the_training_kernels_raise(dev):
         m.precision = prec
         batch = utils.make_ray_batch(40, 40, K, synth.LEGO_C2W, 2.0, 6.0, vd, False, device=dev, n=64)
         assert all(p.requires_grad for p in m.parameters())
-        with pytest.raises(NerfAmdError, match="gradients were requested"):
-            rr.render_rays(batch, m, m)                                # grad mode on, parameters require grad
-        with pytest.raises(NerfAmdError, match="gradients were requested"):
-            rr.render_batch(m, m, batch, chunk=32)
+        with torch.no_grad():                                          # the reference values: plain inference
+            want = rr.render_rays(batch, m, m)
+        assert want["rgb_map"].shape == (64, 3) and not want["rgb_map"].requires_grad
         pts = torch.zeros(4, 3, 3, device=dev)
-        with pytest.raises(NerfAmdError, match="gradients were requested"):
-            m(pts, torch.ones(4, 3, device=dev) if vd else None)
-        with torch.no_grad():                                          # inference is unaffected
-            out = rr.render_rays(batch, m, m)
-        assert out["rgb_map"].shape == (64, 3) and not out["rgb_map"].requires_grad
+        calls = [lambda: rr.render_rays(batch, m, m)["rgb_map"],                      # grad mode on, parameters require grad
+                 lambda: rr.render_batch(m, m, batch, chunk=32)["rgb_map"],
+                 lambda: rr.render(40, 40, K, m, m, chunk=48, c2w=torch.from_numpy(synth.LEGO_C2W), retraw=False)[0],
+                 lambda: m(pts, torch.ones(4, 3, device=dev) if vd else None)]
+        for i, call in enumerate(calls):
+            out = call()
+            assert out.requires_grad and out.grad_fn is not None, (label, i)          # history, not a bare tensor
+            if i < 2:
+                assert torch.equal(out.detach(), want["rgb_map"]), (label, i)         # the same kernels, the same values
+            with pytest.raises(NerfAmdError, match="backward\\(\\) reached a result of the forward-only kernels"):
+                out.sum().backward()
+            assert all(p.grad is None for p in m.parameters())
         m.requires_grad_(False)
-        out = rr.render_rays(batch, m, m)                              # nothing requires grad: forward-only kernels
+        out = rr.render_rays(batch, m, m)                              # nothing requires grad: no history, no trap
         assert not out["rgb_map"].requires_grad
         rays = batch.clone().requires_grad_(True)                      # ... unless the rays do (pose estimation)
-        with pytest.raises(NerfAmdError, match="gradients were requested"):
-            rr.render_rays(rays, m, m)
+        out = rr.render_rays(rays, m, m)["rgb_map"]
+        assert out.requires_grad
+        with pytest.raises(NerfAmdError, match="forward-only kernels"):
+            out.sum().backward()
+    r = render_utils.Renderer(**dict(BASE, N_samples=16, N_importance=16))
+    assert r is not None
     # the covered models in bf16 keep their history: with the view branch, and the output_linear model that
     # NeRF() / config_parser.py:50 build by default (use_viewdirs=False)
     for arch, vd in ((VD, True), (NOVD, False), (dict(D=8, W=256, skips=[4]), False)):
