@@ -15,6 +15,7 @@
 //   [input_ch+W, +input_ch_views)    encoded view dir (kept for the view concat)
 // so both torch.cat calls of the reference (nerf.py:117-118, :123) are just a different first row.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "kernels.h"
 #include "launch_util.h"
@@ -61,6 +62,9 @@ int launch_embed(const float *x, int64_t n, int multires, float *out, hipStream_
 // never overwritten, so both concats of the reference are a different first row.
 constexpr int F32_MAX_TILES_PER_WAVE = 4;            // n_out <= 8 * 4 * 32 = 1024
 
+// TPW: 32-row output tiles per wave (n_out <= 8 * 32 * TPW): the accumulators of all of a wave's tiles stay in registers from
+// the compute phase to the write-back, so the instantiation for W <= 256 holds 32 of them instead of 128.
+template <int TPW>
 __global__ __launch_bounds__(512) void mlp_f32_kernel(MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) float act[];
     const int rows = a.lds_rows;
@@ -105,11 +109,59 @@ __global__ __launch_bounds__(512) void mlp_f32_kernel(MlpArgs a) {
 
     for (int li = 0; li < a.n_layers; ++li) {
         const LayerF32 L = a.layers[li];
+        if (TPW < F32_MAX_TILES_PER_WAVE && L.out_row < 0 && L.n_out <= 8) {      // (the widest instantiation has no registers to spare)
+            // A head that leaves for global memory (alpha_linear: 1 row, rgb_linear: 3, output_linear <= 8): as a 32 x 32 x 2 tile
+            // it is 1-8 live rows of 32 on one wave, 64 matrix-pipe cycles per k-pair, while seven waves wait at the layer's
+            // barriers (in-kernel stamps: 7 % of a tile's cycles for the two heads of the view-branch model).
+            // v_mfma_f32_4x4x1_16B_f32 fits it: sixteen 4 x 4 blocks = 4 output rows x 64 points per instruction, one k at a
+            // time, 8 cycles each -- the B operand of lane l is simply point l's activation (one conflict-free ds_read_b32
+            // per k), D register i of lane l is output row i of point l, and lane l's A operand is W[l & 3][k], eight k's
+            // per pair of 16-byte loads from the fragment stream.  Wave 0 does it alone and no barrier is needed: a head
+            // only reads rows the previous layer's trailing barrier published and writes to global memory; the next
+            // layer's first barrier (which wave 0 joins after its own tile) still precedes any overwrite of those rows.
+            if (wave == 0) {
+                f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+                const float *xcol = act + L.in_row * 64 + lane;
+                const float *wrow = a.stream_f32 + L.frag_off + 4 * (lane & 3);        // rows 0..3 of tile 0; rows 4..7 are 16 floats on
+                const int groups8 = (L.n_in + 7) >> 3;
+                const bool two = L.n_out > 4;
+                for (int g = 0; g < groups8; ++g) {
+                    const f32x4 we = *reinterpret_cast<const f32x4 *>(wrow + g * 256);          // W[o][8g + 0, 2, 4, 6]
+                    const f32x4 wo = *reinterpret_cast<const f32x4 *>(wrow + g * 256 + 128);    // W[o][8g + 1, 3, 5, 7]
+                    f32x4 we2 = we, wo2 = wo;
+                    if (two) {
+                        we2 = *reinterpret_cast<const f32x4 *>(wrow + g * 256 + 16);
+                        wo2 = *reinterpret_cast<const f32x4 *>(wrow + g * 256 + 128 + 16);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {              // k = 8g + 2i, 8g + 2i + 1 (columns past n_in are zero in the stream)
+                        const float x0 = xcol[(8 * g + 2 * i) * 64], x1 = xcol[(8 * g + 2 * i + 1) * 64];
+                        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(we[i], x0, d0, 0, 0, 0);
+                        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wo[i], x1, d0, 0, 0, 0);
+                        if (two) {
+                            d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(we2[i], x0, d1, 0, 0, 0);
+                            d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wo2[i], x1, d1, 0, 0, 0);
+                        }
+                    }
+                }
+                const int64_t p = p0 + lane;
+                if (p < a.P) {
+#pragma unroll
+                    for (int o = 0; o < 8; ++o)
+                        if (o < L.n_out) {
+                            float v = (o < 4 ? d0[o & 3] : d1[o & 3]) + a.bias_f32[L.bias_off + o];
+                            if (L.relu) v = fmaxf(v, 0.0f);
+                            a.out[(int64_t)a.out_ch * p + L.out_col + o] = v;
+                        }
+                }
+            }
+            continue;
+        }
         const float *in = act + L.in_row * 64 + pt;
         const int tiles = (L.n_out + 31) >> 5, groups = (L.n_in + 7) >> 3;
-        f32x16 acc[F32_MAX_TILES_PER_WAVE][2];
+        f32x16 acc[TPW][2];
 #pragma unroll
-        for (int u = 0; u < F32_MAX_TILES_PER_WAVE; ++u) {
+        for (int u = 0; u < TPW; ++u) {
             const int t = wave + 8 * u;
             if (t < tiles) {                                   // wave-uniform
 #pragma unroll
@@ -137,7 +189,7 @@ __global__ __launch_bounds__(512) void mlp_f32_kernel(MlpArgs a) {
         // inside, the compiler emitted ~20 instructions and three branches per value: tools/tile stamps put the write-back at
         // 10 % of a tile's cycles.)
 #pragma unroll
-        for (int u = 0; u < F32_MAX_TILES_PER_WAVE; ++u) {
+        for (int u = 0; u < TPW; ++u) {
             const int t = wave + 8 * u;
             if (t < tiles) {
                 if (L.relu) {
@@ -179,11 +231,18 @@ int launch_mlp_f32(const MlpArgs &a, hipStream_t s) {
     const size_t lds = (size_t)a.lds_rows * 64 * sizeof(float);
     if (lds > 160 * 1024) return NERF_AMD_EUNSUPPORTED;
     if (a.W > 8 * F32_MAX_TILES_PER_WAVE * 32) return NERF_AMD_EUNSUPPORTED;
-    static DynamicLdsOptIn opt_in;         // the size depends on the model: raise the limit to the CU's 160 KiB once per device
-    if (opt_in.ensure(reinterpret_cast<const void *>(mlp_f32_kernel), 160 * 1024) != hipSuccess) return NERF_AMD_EHIP;
     const int64_t blocks = (a.P + 63) / 64;
-    hipLaunchKernelGGL(mlp_f32_kernel, dim3((unsigned)blocks), dim3(512), lds, s, a);
-    return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
+    const int widest = a.W > a.out_ch ? a.W : a.out_ch;      // rows of the widest layer
+    auto go = [&](auto tpw_) -> int {
+        constexpr int TPW = decltype(tpw_)::value;
+        static DynamicLdsOptIn opt_in;     // the size depends on the model: raise the limit to the CU's 160 KiB once per device
+        if (opt_in.ensure(reinterpret_cast<const void *>(mlp_f32_kernel<TPW>), 160 * 1024) != hipSuccess) return NERF_AMD_EHIP;
+        hipLaunchKernelGGL(mlp_f32_kernel<TPW>, dim3((unsigned)blocks), dim3(512), lds, s, a);
+        return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
+    };
+    if (widest <= 256) return go(std::integral_constant<int, 1>{});
+    if (widest <= 512) return go(std::integral_constant<int, 2>{});
+    return go(std::integral_constant<int, F32_MAX_TILES_PER_WAVE>{});
 }
 
 }  // namespace na
