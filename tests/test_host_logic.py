@@ -436,3 +436,19 @@ def test_library_adam_is_a_torch_adam_and_survives_copies():
     p[0].grad = torch.ones(4)
     with pytest.raises(_lib.NerfAmdError):            # host tensors: no CPU path behind the library optimizer
         o.step()
+
+
+def test_deferred_gradient_trap_is_plain_autograd():
+    """nerf.attach_deferred_grad (what a model outside the training kernels returns when gradients were requested): the
+    values pass through untouched, the result has history, and backward raises NerfAmdError with the stored reason -- on
+    any device, tensors or dicts of tensors."""
+    from nerf_shared_amd import nerf
+    x = torch.arange(6, dtype=torch.float32).reshape(2, 3)
+    anchor = torch.ones(1, requires_grad=True)
+    out = nerf.attach_deferred_grad({"rgb_map": x, "acc_map": x[:, 0]}, (anchor, "no backward kernels for this model"))
+    assert sorted(out) == ["acc_map", "rgb_map"] and torch.equal(out["rgb_map"], x)
+    assert out["rgb_map"].requires_grad and out["acc_map"].grad_fn is not None
+    with pytest.raises(_lib.NerfAmdError, match="no backward kernels for this model"):
+        (out["rgb_map"].sum() + out["acc_map"].sum()).backward()
+    assert anchor.grad is None
+    assert nerf.attach_deferred_grad(x, None) is x                     # nothing requested: nothing attached
