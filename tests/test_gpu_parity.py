@@ -599,8 +599,27 @@ def staged_check(dev, cfg, arch, batch, seeds, use_pytest, label, precision="fp3
     dz = np.abs(out["z_vals"].numpy() - z_ref.numpy())
     span = float(cfg["far"] - cfg["near"]) if not cfg["ndc"] else 1.0
     assert (dz[well_sorted] < 5e-6 * span).mean() > 0.999, (label, (dz[well_sorted] < 5e-6 * span).mean())
-    assert dz.max() < 2e-3 * span, (label, dz.max())
-    close_frac(out["z_std"], torch.std(z_samples, dim=-1, unbiased=False), atol=5e-6 * span, rtol=1e-4, frac=0.9)
+    # The loose bound for everything else.  Where the bin mass is tiny the reference's own formula is discontinuous:
+    # `denom < 1e-5 -> 1` (utils.py:110) flips on the last bit of a cumsum difference -- an empty bin of an opaque ray has
+    # pdf = 1e-5 / (sum w + 62e-5), right at the threshold -- and moves the sample from the bin's edge to anywhere inside
+    # it; in the sorted row every depth it passes shifts one place.  One bin width bounds both.
+    bin_w = (z_mid[:, 1:] - z_mid[:, :-1]).max(-1)[0].numpy()[:, None] if Nc > 2 else np.full((R, 1), span)
+    assert (dz <= bin_w * 1.001 + 1e-6 * span).all(), (label, float((dz - bin_w).max()))
+    # z_std (render_utils.py:168) is the spread of the fine samples alone.  Against the oracle's samples it can only be
+    # compared on rays without an ill-conditioned sample (the u = 1 sample of an opaque ray is one: its bin is empty and it
+    # sits at either end of it); on EVERY ray it must be the spread of the samples this run drew, which are the merged row
+    # minus the coarse depths.
+    all_well = well.all(-1)
+    if all_well.any():
+        close_frac(out["z_std"][all_well], torch.std(z_samples, dim=-1, unbiased=False)[all_well], atol=5e-6 * span, rtol=1e-4,
+                   frac=0.9)
+    zg, zc = out["z_vals"].numpy(), z_c.numpy()
+    drawn = np.ones(zg.shape, bool)
+    for r_ in range(R):
+        drawn[r_, np.searchsorted(zg[r_], zc[r_], side="left")] = False
+    assert (drawn.sum(-1) == Ni).all(), label
+    own = zg[drawn].reshape(R, Ni).astype(np.float64)
+    close(out["z_std"], own.std(-1), atol=5e-6 * span, rtol=1e-4)
     # fine pass on the GPU's own z_vals
     z = out["z_vals"]
     pts = batch[:, None, 0:3] + batch[:, None, 3:6] * z[..., None]
