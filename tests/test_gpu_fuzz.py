@@ -94,3 +94,58 @@ def test_random_configuration_bf16_invariants(dev, i):
     d = (ref["rgb_map"] - got["rgb_map"]).abs()
     assert float((d < gate).float().mean()) >= 0.97, (float(d.max()), float(d.mean()))
     assert float(d.mean()) < 0.2 * gate, float(d.mean())
+
+
+# ------------------------------------------------------------------ training kernels on awkward sizes
+import test_gpu_backward as B  # noqa: E402
+
+SIZES = [(1, 1), (1, 2), (3, 11), (1, 31), (1, 32), (33, 1), (5, 51), (16, 16), (257, 1), (7, 73), (40, 25), (17, 241),
+         (64, 128), (100, 97)]
+
+
+@pytest.mark.parametrize("k", range(len(SIZES)))
+def test_field_gradients_on_awkward_point_counts(dev, k):
+    """Parameter and input gradients of NeRF.forward against torch.autograd on the kernel's rounding model for point
+    counts around every granularity of the training kernels: one point, 32-point chunks of the weight-gradient products,
+    256-point tiles of the dX chain, more chunks than workgroups and fewer; the architecture rotates through the four
+    instantiated families."""
+    R, S = SIZES[k]
+    arch = [B.VD, B.NOVD, B.VD15, B.NOVD4][k % 4]
+    rng = np.random.default_rng(500 + k)
+    pts = torch.from_numpy(rng.uniform(-2, 2, size=(R, S, 3)).astype(np.float32))
+    vd = torch.from_numpy(rng.normal(size=(R, 3)).astype(np.float32))
+    vd = vd / vd.norm(dim=-1, keepdim=True) if arch["use_viewdirs"] else None
+    coef = torch.from_numpy(rng.normal(size=(R, S, 4 if arch["use_viewdirs"] else arch["output_ch"])).astype(np.float32))
+    m, cpu = B._models(dev, 30 + k, 1.0, arch)
+    p_ref = pts.clone().requires_grad_(True)
+    out_b = B.bf16_field(cpu, p_ref, vd, arch["multires"], arch["multires_views"])
+    (out_b * coef).sum().backward()
+    p_gpu = pts.to(dev).requires_grad_(True)
+    out = m(p_gpu, vd.to(dev) if vd is not None else None)
+    (out * coef.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    assert B.rel_err(out, out_b) < 1e-3
+    worst = 0.0
+    for name, p in m.named_parameters():
+        if cpu[name].grad is None:
+            assert p.grad is None, name
+            continue
+        g = p.grad.detach().cpu()
+        assert torch.isfinite(g).all(), name
+        ref = cpu[name].grad
+        # a tensor whose reference gradient is zero (ReLU-dead rows at one point) must be zero here too
+        if float(ref.norm()) == 0.0:
+            assert float(g.norm()) == 0.0, name
+            continue
+        if name in ("alpha_linear.bias", "rgb_linear.bias", "output_linear.bias"):
+            # a head's bias gradient is the plain sum of dL/draw over the points, taken on bf16 operands like every other
+            # product: its error scales with the column's norm, not with a sum that may cancel (257 points: -1.39 of 219)
+            col = coef[..., 3] if name == "alpha_linear.bias" else coef[..., :3] if name == "rgb_linear.bias" else coef
+            assert float((g - ref).abs().max()) <= 2.0 ** -6 * float(col.norm()), (name, R, S)
+            continue
+        e = B.rel_err(g, ref)
+        worst = max(worst, e)
+        assert e < 3e-2, (name, R, S, e)
+    gp = p_gpu.grad.detach().cpu()
+    assert torch.isfinite(gp).all() and B.rel_err(gp, p_ref.grad) < 5e-2, (R, S, B.rel_err(gp, p_ref.grad))
+    print("sizes", R, S, "worst parameter-gradient error", worst)
