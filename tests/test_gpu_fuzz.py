@@ -149,3 +149,60 @@ def test_field_gradients_on_awkward_point_counts(dev, k):
     gp = p_gpu.grad.detach().cpu()
     assert torch.isfinite(gp).all() and B.rel_err(gp, p_ref.grad) < 5e-2, (R, S, B.rel_err(gp, p_ref.grad))
     print("sizes", R, S, "worst parameter-gradient error", worst)
+
+
+def draw_train_case(i):
+    rng = np.random.default_rng(9000 + i)
+    vd = bool(rng.random() < 0.6)
+    arch = dict(B.VD if vd else B.NOVD)
+    if rng.random() < 0.3:
+        arch.update(multires=15, multires_views=6)
+    near = float(rng.choice([0.5, 2.0, 4.0]))
+    cfg = dict(B.BASE, N_samples=int(rng.integers(2, 121)), N_importance=0, use_viewdirs=vd,
+               perturb=float(rng.random() < 0.5), raw_noise_std=float(rng.random() < 0.4), lindisp=bool(rng.random() < 0.3),
+               white_bkgd=bool(rng.random() < 0.5), near=near, far=near + float(rng.choice([1.0, 4.0, 6.5])))
+    R = int(rng.choice([1, 5, 64, 97, 300]))
+    H = W = 400
+    idx = np.sort(rng.choice(H * W, size=R, replace=False))
+    ro, rd = synth.rays_np(H, W, synth.lego_intrinsics(H, W), synth.pose_spherical(float(rng.uniform(-180, 180))), idx)
+    batch = torch.from_numpy(synth.ray_batch_np(ro, rd, cfg["near"], cfg["far"], vd))
+    target = torch.from_numpy(rng.uniform(0, 1, size=(R, 3)).astype(np.float32))
+    return cfg, arch, batch, target, int(rng.integers(0, 40)), float(rng.choice([0.3, 1.0]))
+
+
+@pytest.mark.parametrize("i", range(16))
+def test_random_single_pass_training_gradients(dev, monkeypatch, i):
+    """The reference's loss through one pass of render_rays (N_importance = 0: no resampling, so the comparison is
+    not at the mercy of sample_pdf's conditioning) for random sample counts, ray counts, jitter, sigma noise, lindisp,
+    background and model family: loss and every parameter gradient against torch.autograd on the oracle with the
+    kernel's roundings."""
+    from nerf_shared_amd import render_utils
+    cfg, arch, batch, target, seed, lift = draw_train_case(i)
+    m, cpu = B._models(dev, seed, 1.0, arch)
+    with torch.no_grad():               # default-scale weights give sigma <= 0 almost everywhere: lift the density bias
+        head = "alpha_linear.bias" if arch["use_viewdirs"] else "output_linear.bias"
+        dict(m.named_parameters())[head][-1 if arch["use_viewdirs"] else 3] += lift
+        cpu[head][-1 if arch["use_viewdirs"] else 3] += lift
+    kw = dict(pytest=True) if (cfg["perturb"] > 0 or cfg["raw_noise_std"] > 0) else {}
+    out = render_utils.Renderer(**cfg).render_rays(batch.to(dev), m, None, **kw)
+    loss = ((out["rgb_map"] - target.to(dev)) ** 2).mean()
+    loss.backward()
+    monkeypatch.setattr(B.O, "nerf_forward", lambda sd, a, pts, vd, netchunk=0: B.bf16_field(sd, pts, vd, arch["multires"],
+                                                                                             arch["multires_views"]))
+    o = B.O.render_rays(B.O.RenderCfg(**cfg), batch, (cpu, B.O.Arch(**arch)), None, **kw)
+    ref_loss = ((o["rgb_map"] - target) ** 2).mean()
+    ref_loss.backward()
+    monkeypatch.undo()
+    assert abs(float(loss) - float(ref_loss)) < 3e-3 * max(1.0, abs(float(ref_loss))), (cfg, float(loss), float(ref_loss))
+    worst = 0.0
+    for name, p in m.named_parameters():
+        if cpu[name].grad is None:
+            assert p.grad is None, name
+            continue
+        g, ref = p.grad.detach().cpu(), cpu[name].grad
+        assert torch.isfinite(g).all(), name
+        if float(ref.norm()) == 0.0:
+            continue
+        worst = max(worst, B.rel_err(g, ref))
+    print("train fuzz", i, cfg, batch.shape[0], "worst %.4f" % worst)
+    assert worst < 8e-2, (cfg, arch, worst)
