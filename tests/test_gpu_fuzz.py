@@ -206,3 +206,44 @@ def test_random_single_pass_training_gradients(dev, monkeypatch, i):
         worst = max(worst, B.rel_err(g, ref))
     print("train fuzz", i, cfg, batch.shape[0], "worst %.4f" % worst)
     assert worst < 8e-2, (cfg, arch, worst)
+
+
+@pytest.mark.parametrize("i", range(12))
+def test_random_batch_sizes_through_the_one_call_path_equal_the_chunk_loop(dev, i):
+    """nerf_amd_render_batch regroups the rays into 32768-ray launches and runs the per-ray kernels on a side stream;
+    the chunk-at-a-time path is one render_rays call per API chunk.  For ray counts around the launch-group size and
+    chunk sizes that divide nothing, every output of the two is the same bits -- in all three precisions, with and
+    without random draws, fine model or not."""
+    _, render_utils, utils = P.amd()
+    Rn = render_utils.Renderer
+    rng = np.random.default_rng(12000 + i)
+    N = int([1, 2, 255, 4097, 32767, 32768, 32769, 65535, 65537, 98305, 20011, 77777][i])
+    chunk = int(rng.choice([257, 1000, 4096, 12000, 32768, 40000, 100000]))
+    precision = ["bf16", "fp32_split", "fp32"][i % 3]
+    if precision == "fp32" and N > 40000:
+        N = N // 3 + 1                                  # the exact kernel is 13x slower: keep the case short
+    cfg = dict(P.BASE, N_samples=int(rng.integers(8, 65)), N_importance=int(rng.choice([0, 1, 17, 64, 128])),
+               perturb=float(rng.random() < 0.5), raw_noise_std=float(rng.random() < 0.4), lindisp=bool(rng.random() < 0.3),
+               white_bkgd=bool(rng.random() < 0.5))
+    seeded = cfg["perturb"] > 0 or cfg["raw_noise_std"] > 0
+    retraw = bool(rng.random() < 0.5)
+    K = synth.lego_intrinsics(400, 400)
+    batch = utils.make_ray_batch(400, 400, K, synth.pose_spherical(float(rng.uniform(-180, 180))), 2.0, 6.0, True, False,
+                                 device=dev, pix0=int(rng.integers(0, 160000 - N)), n=N)
+    c, f = P.gpu_model(dev, 1, 3.0, precision, **P.VD), P.gpu_model(dev, 19, 3.0, precision, **P.VD)
+    fine = f if (cfg["N_importance"] > 0 and rng.random() < 0.8) else None
+    r = Rn(**cfg)
+    outs = []
+    for pipe in (True, False):
+        Rn.pipeline_batch = pipe
+        try:
+            if seeded:
+                torch.manual_seed(77 + i)
+            outs.append(r.render_batch(c, fine, batch, chunk=chunk, retraw=retraw))
+            torch.cuda.synchronize()
+        finally:
+            Rn.pipeline_batch = True
+    assert sorted(outs[0]) == sorted(outs[1])
+    for k in outs[0]:
+        assert outs[0][k].shape[0] == N, (k, outs[0][k].shape)
+        assert torch.equal(torch.nan_to_num(outs[0][k]), torch.nan_to_num(outs[1][k])), (N, chunk, precision, cfg, k)
