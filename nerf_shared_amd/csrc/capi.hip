@@ -445,7 +445,9 @@ int plan_chunk(const nerf_amd_render_cfg *cfg, const nerf_amd_model *coarse, con
     if (!cfg || !coarse || !io || R < 0) return fail(NERF_AMD_EINVAL, "null argument");
     const int Nc = cfg->N_samples, Ni = cfg->N_importance, Nf = Nc + Ni;
     if (Nc < 1 || Ni < 0) return fail(NERF_AMD_EINVAL, "bad sample counts");
-    if (Ni > 0 && Nc < 3) return fail(NERF_AMD_EINVAL, "hierarchical sampling needs N_samples >= 3");
+    // fewer than three coarse samples leave sample_pdf without an interior weight: the reference's cdf is then EMPTY
+    // (zeros_like(cdf[..., :1]) of an empty cumsum, utils.py:78-79) and its gather raises an index error
+    if (Ni > 0 && Nc < 3) return fail(NERF_AMD_EINVAL, "hierarchical sampling needs N_samples >= 3 (with fewer the reference's sample_pdf fails too: empty cdf)");
     if (Ni > 0 && resample_lds_bytes(Nc, Ni, true) > LDS_LIMIT_BYTES)      // refuse before anything is launched
         return fail(NERF_AMD_EINVAL, lds_msg("render_rays (compositing + resampling)", resample_lds_bytes(Nc, Ni, true)));
     if (!io->rays || (io->ray_ch != 8 && io->ray_ch != 11)) return fail(NERF_AMD_EINVAL, "rays must be [R,8] or [R,11]");

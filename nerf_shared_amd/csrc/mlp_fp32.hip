@@ -2,7 +2,8 @@
 // standalone positional encoding.
 //
 // Replaces Embedder.embed (/root/reference/nerf_shared/nerf.py:16-41) and
-// NeRF.forward + NeRF.MLP (nerf.py:96-134) for every D / W (2..1024, any value) /
+// NeRF.forward + NeRF.MLP (nerf.py:96-134) for every D / W (2..1024, any value; 32 points per workgroup instead of 64
+// where the feature rows would not fit LDS) /
 // skips / multires / viewdirs combination the reference constructor accepts.
 // This is the parity path (v_mfma_f32_32x32x2_f32 is a bit-exact fp32 fma
 // chain) and the fallback for architectures the fused bf16 kernel does not
@@ -54,8 +55,9 @@ int launch_embed(const float *x, int64_t n, int multires, float *out, hipStream_
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
 
-// One workgroup (8 waves) evaluates 64 points = two 32-point column halves.  Activations live in ONE LDS
-// buffer [feature row][64 points] fp32 and layers update it in place: every wave first computes all of its
+// One workgroup (8 waves) evaluates 64 points = two 32-point column halves (HALVES = 2), or one half when the model's
+// feature rows x 64 points would not fit the CU's 160 KiB (HALVES = 1: W above ~540, up to 1024 with the largest
+// encodings).  Activations live in ONE LDS buffer [feature row][PTS points] fp32 and layers update it in place: every wave first computes all of its
 // output tiles of a layer into registers (tile t belongs to wave t % 8; both column halves share the weight
 // fragment loaded from L2, which is what bounds this kernel), a barrier ends the reads, the tiles are
 // written over the layer's input rows, a second barrier publishes them.  The encoded xyz and view rows are
@@ -64,21 +66,22 @@ constexpr int F32_MAX_TILES_PER_WAVE = 4;            // n_out <= 8 * 4 * 32 = 10
 
 // TPW: 32-row output tiles per wave (n_out <= 8 * 32 * TPW): the accumulators of all of a wave's tiles stay in registers from
 // the compute phase to the write-back, so the instantiation for W <= 256 holds 32 of them instead of 128.
-template <int TPW>
+template <int TPW, int HALVES>
 __global__ __launch_bounds__(512) void mlp_f32_kernel(MlpArgs a) {
+    constexpr int PTS = 32 * HALVES;                     // points per workgroup = floats per LDS row
     extern __shared__ __attribute__((aligned(16))) float act[];
     const int rows = a.lds_rows;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pt = lane & 31, h = lane >> 5;
 
-    for (int i = tid; i < rows * 64; i += 512) act[i] = 0.0f;
+    for (int i = tid; i < rows * PTS; i += 512) act[i] = 0.0f;
     __syncthreads();
 
-    // ---- encode this tile's 64 points
-    const int64_t p0 = (int64_t)blockIdx.x * 64;
+    // ---- encode this tile's points
+    const int64_t p0 = (int64_t)blockIdx.x * PTS;
     const int n_in_rows = a.input_ch + a.input_ch_views;
-    for (int i = tid; i < n_in_rows * 64; i += 512) {
-        const int row = i >> 6, q = i & 63;
+    for (int i = tid; i < n_in_rows * PTS; i += 512) {
+        const int row = i / PTS, q = i & (PTS - 1);
         int64_t p = p0 + q;
         if (p >= a.P) p = a.P - 1;
         const int64_t ray = (int64_t)((uint32_t)p / (uint32_t)a.S);
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(512) void mlp_f32_kernel(MlpArgs a) {
             v[0] = d[0]; v[1] = d[1]; v[2] = d[2];
             val = embed_feature(v, row - a.input_ch, a.i_embed);
         }
-        act[dst * 64 + q] = val;
+        act[dst * PTS + q] = val;
     }
     __syncthreads();
 
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(512) void mlp_f32_kernel(MlpArgs a) {
             // layer's first barrier (which wave 0 joins after its own tile) still precedes any overwrite of those rows.
             if (wave == 0) {
                 f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-                const float *xcol = act + L.in_row * 64 + lane;
+                const float *xcol = act + L.in_row * PTS + (lane & (PTS - 1));   // HALVES = 1: lanes 32..63 repeat 0..31
                 const float *wrow = a.stream_f32 + L.frag_off + 4 * (lane & 3);        // rows 0..3 of tile 0; rows 4..7 are 16 floats on
                 const int groups8 = (L.n_in + 7) >> 3;
                 const bool two = L.n_out > 4;
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(512) void mlp_f32_kernel(MlpArgs a) {
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {              // k = 8g + 2i, 8g + 2i + 1 (columns past n_in are zero in the stream)
-                        const float x0 = xcol[(8 * g + 2 * i) * 64], x1 = xcol[(8 * g + 2 * i + 1) * 64];
+                        const float x0 = xcol[(8 * g + 2 * i) * PTS], x1 = xcol[(8 * g + 2 * i + 1) * PTS];
                         d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(we[i], x0, d0, 0, 0, 0);
                         d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wo[i], x1, d0, 0, 0, 0);
                         if (two) {
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(512) void mlp_f32_kernel(MlpArgs a) {
                     }
                 }
                 const int64_t p = p0 + lane;
-                if (p < a.P) {
+                if (lane < PTS && p < a.P) {
 #pragma unroll
                     for (int o = 0; o < 8; ++o)
                         if (o < L.n_out) {
@@ -157,9 +160,9 @@ __global__ __launch_bounds__(512) void mlp_f32_kernel(MlpArgs a) {
             }
             continue;
         }
-        const float *in = act + L.in_row * 64 + pt;
+        const float *in = act + L.in_row * PTS + pt;
         const int tiles = (L.n_out + 31) >> 5, groups = (L.n_in + 7) >> 3;
-        f32x16 acc[TPW][2];
+        f32x16 acc[TPW][HALVES];
 #pragma unroll
         for (int u = 0; u < TPW; ++u) {
             const int t = wave + 8 * u;
@@ -167,17 +170,19 @@ __global__ __launch_bounds__(512) void mlp_f32_kernel(MlpArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float bias = a.bias_f32[L.bias_off + 32 * t + acc_row(r, h)];
-                    acc[u][0][r] = bias; acc[u][1][r] = bias;
+#pragma unroll
+                    for (int c = 0; c < HALVES; ++c) acc[u][c][r] = bias;
                 }
                 const f32x4 *wf = reinterpret_cast<const f32x4 *>(a.stream_f32 + L.frag_off + (int64_t)t * groups * 256) + lane;
 #pragma unroll 2
                 for (int g = 0; g < groups; ++g) {
                     const f32x4 w = wf[(int64_t)g * 64];
-                    const float *bp = in + (8 * g + h) * 64;
+                    const float *bp = in + (8 * g + h) * PTS;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {              // rows 8g + h + 2k: the k-th pair of this 8-row group
-                        acc[u][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[k], bp[128 * k], acc[u][0], 0, 0, 0);
-                        acc[u][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[k], bp[128 * k + 32], acc[u][1], 0, 0, 0);
+#pragma unroll
+                        for (int c = 0; c < HALVES; ++c)
+                            acc[u][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[k], bp[2 * PTS * k + 32 * c], acc[u][c], 0, 0, 0);
                     }
                 }
             }
@@ -194,26 +199,26 @@ __global__ __launch_bounds__(512) void mlp_f32_kernel(MlpArgs a) {
             if (t < tiles) {
                 if (L.relu) {
 #pragma unroll
-                    for (int c = 0; c < 2; ++c)
+                    for (int c = 0; c < HALVES; ++c)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[u][c][r] = fmaxf(acc[u][c][r], 0.0f);
                 }
                 const bool complete = 32 * t + 32 <= L.n_out;
                 if (L.out_row >= 0 && complete) {
-                    float *dst = act + (L.out_row + 32 * t + 4 * h) * 64 + pt;
+                    float *dst = act + (L.out_row + 32 * t + 4 * h) * PTS + pt;
 #pragma unroll
-                    for (int c = 0; c < 2; ++c)
+                    for (int c = 0; c < HALVES; ++c)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2)) * 64 + 32 * c] = acc[u][c][r];
+                        for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2)) * PTS + 32 * c] = acc[u][c][r];
                 } else {
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) {
+                    for (int c = 0; c < HALVES; ++c) {
                         const int64_t p = p0 + 32 * c + pt;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int row = 32 * t + acc_row(r, h);
                             if (row < L.n_out) {
-                                if (L.out_row >= 0) act[(L.out_row + row) * 64 + 32 * c + pt] = acc[u][c][r];
+                                if (L.out_row >= 0) act[(L.out_row + row) * PTS + 32 * c + pt] = acc[u][c][r];
                                 else if (p < a.P) a.out[(int64_t)a.out_ch * p + L.out_col + row] = acc[u][c][r];
                             }
                         }
@@ -228,21 +233,29 @@ __global__ __launch_bounds__(512) void mlp_f32_kernel(MlpArgs a) {
 int launch_mlp_f32(const MlpArgs &a, hipStream_t s) {
     if (a.P <= 0) return NERF_AMD_OK;
     if (a.P >= (int64_t)1 << 31) return NERF_AMD_EINVAL;
-    const size_t lds = (size_t)a.lds_rows * 64 * sizeof(float);
-    if (lds > 160 * 1024) return NERF_AMD_EUNSUPPORTED;
     if (a.W > 8 * F32_MAX_TILES_PER_WAVE * 32) return NERF_AMD_EUNSUPPORTED;
-    const int64_t blocks = (a.P + 63) / 64;
+    // 64 points per workgroup while the activation rows fit the CU's LDS, 32 for the widest models (build_program bounds the rows)
+    const bool half = (size_t)a.lds_rows * 64 * sizeof(float) > 160 * 1024;
+    const int pts = half ? 32 : 64;
+    const size_t lds = (size_t)a.lds_rows * pts * sizeof(float);
+    if (lds > 160 * 1024) return NERF_AMD_EUNSUPPORTED;
+    const int64_t blocks = (a.P + pts - 1) / pts;
     const int widest = a.W > a.out_ch ? a.W : a.out_ch;      // rows of the widest layer
-    auto go = [&](auto tpw_) -> int {
-        constexpr int TPW = decltype(tpw_)::value;
+    auto go = [&](auto tpw_, auto halves_) -> int {
+        constexpr int TPW = decltype(tpw_)::value, HALVES = decltype(halves_)::value;
         static DynamicLdsOptIn opt_in;     // the size depends on the model: raise the limit to the CU's 160 KiB once per device
-        if (opt_in.ensure(reinterpret_cast<const void *>(mlp_f32_kernel<TPW>), 160 * 1024) != hipSuccess) return NERF_AMD_EHIP;
-        hipLaunchKernelGGL(mlp_f32_kernel<TPW>, dim3((unsigned)blocks), dim3(512), lds, s, a);
+        if (opt_in.ensure(reinterpret_cast<const void *>(mlp_f32_kernel<TPW, HALVES>), 160 * 1024) != hipSuccess) return NERF_AMD_EHIP;
+        hipLaunchKernelGGL((mlp_f32_kernel<TPW, HALVES>), dim3((unsigned)blocks), dim3(512), lds, s, a);
         return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
     };
-    if (widest <= 256) return go(std::integral_constant<int, 1>{});
-    if (widest <= 512) return go(std::integral_constant<int, 2>{});
-    return go(std::integral_constant<int, F32_MAX_TILES_PER_WAVE>{});
+    using std::integral_constant;
+    if (half) {
+        if (widest <= 512) return go(integral_constant<int, 2>{}, integral_constant<int, 1>{});
+        return go(integral_constant<int, F32_MAX_TILES_PER_WAVE>{}, integral_constant<int, 1>{});
+    }
+    if (widest <= 256) return go(integral_constant<int, 1>{}, integral_constant<int, 2>{});
+    if (widest <= 512) return go(integral_constant<int, 2>{}, integral_constant<int, 2>{});
+    return go(integral_constant<int, F32_MAX_TILES_PER_WAVE>{}, integral_constant<int, 2>{});
 }
 
 }  // namespace na

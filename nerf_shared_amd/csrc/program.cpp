@@ -43,6 +43,8 @@ int build_program(const nerf_amd_arch &a, Program &p, const char **err) {
     // ---- fp32 generic program
     {
         p.lds_rows = (p.input_ch + W + p.input_ch_views + 8 + 1) & ~1;   // +8: k-groups of 8 may read past the last valid row
+        // the fp32 kernel keeps every feature row of 64 (or, for the widest models, 32) points in the CU's 160 KiB of LDS
+        if ((int64_t)p.lds_rows * 32 * 4 > 160 * 1024) { *err = "W + encoding widths exceed the 1280 feature rows the exact kernel can hold in LDS"; return -1; }
         int cur = 0;
         int64_t foff = 0, boff = 0;
         auto push = [&](int tensor, int in_row, int out_row, int out_col, int relu, bool flip) {

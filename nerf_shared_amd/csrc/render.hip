@@ -139,6 +139,9 @@ __device__ __forceinline__ void composite_ray(const float *raw, int raw_ch, cons
             if (noise) sigma = sigma + noise[r * S + s];
             sigma = fmaxf(sigma, 0.0f);
             alpha = 1.0f - expf(-sigma * dist);
+            // One sample: the reference's `dists` comes out EMPTY (the 1e10 tail is expanded to dists[..., :1].shape = [R, 0],
+            // render_utils.py:256-258), so do alpha and the weights; every sum over them is 0: background colour, acc 0, disp NaN.
+            if (S == 1) alpha = 0.0f;
             term = (double)(1.0f - alpha + 1e-10f);
         }
         const double incl = wave_incl_prod(term, lane);
@@ -239,6 +242,7 @@ __global__ __launch_bounds__(64 * RAYS_PER_WG) void composite_bwd_kernel(
             if (noise) sigma = sigma + noise[r * S + s];
             sigma = fmaxf(sigma, 0.0f);
             alpha = 1.0f - expf(-sigma * dist);
+            if (S == 1) alpha = 0.0f;                          // as in the forward: no weights, no gradient
             term = (double)(1.0f - alpha + 1e-10f);
         }
         const double incl = wave_incl_prod(term, lane);
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(64 * RAYS_PER_WG) void composite_bwd_kernel(
             o[1] = gg * w * cg * (1.0f - cg);
             o[2] = gb * w * cb * (1.0f - cb);
             const float oma = 1.0f - a;
-            const float core = sig > 0.0f ? oma * (v * T - (float)later / (oma + 1e-10f)) : 0.0f;   // dL/dalpha * (1 - alpha)
+            const float core = (sig > 0.0f && S > 1) ? oma * (v * T - (float)later / (oma + 1e-10f)) : 0.0f;   // dL/dalpha * (1 - alpha)
             o[3] = dist * core;
             for (int c = 4; c < raw_ch; ++c) o[c] = 0.0f;
             gdn += core * sig * (dist / dnorm);                  // dL/ddist * dz
@@ -389,7 +393,7 @@ __global__ __launch_bounds__(64 * RAYS_PER_WG) void sample_pdf_kernel(const floa
 int launch_sample_pdf(const float *bins, const float *weights, const float *u, const float *t_lin,
                       int64_t R, int n_bins, int n_samples, float *samples, hipStream_t s) {
     if (R <= 0 || n_samples <= 0) return NERF_AMD_OK;
-    if (n_bins < 2) return NERF_AMD_EINVAL;
+    if (n_bins < 2) return NERF_AMD_EINVAL;      // one bin edge, no weights: the reference's cdf is empty and its gather fails
     const int64_t blocks = (R + RAYS_PER_WG - 1) / RAYS_PER_WG;
     const size_t lds = sample_pdf_lds_bytes(n_bins);
     static DynamicLdsOptIn opt_in;

@@ -386,7 +386,7 @@ class Renderer(torch.nn.Module):
         if retraw:
             ret['raw'] = raw
         if retweights:
-            ret['weights'] = weights
+            ret['weights'] = weights if z.shape[1] > 1 else weights[:, :0]     # one sample: see raw2outputs
             ret['z_vals'] = z
         if Ni > 0:
             ret.update(rgb0=rgb0, disp0=disp0, acc0=acc0, z_std=z_std)
@@ -442,6 +442,8 @@ class Renderer(torch.nn.Module):
         out_ch = 4 if coarse_model.use_viewdirs else coarse_model.output_ch
         outs = self._alloc_outputs(rays.shape[0], rays.device, out_ch, retraw, retweights)
         self._launch(rays, coarse_model, fine_model, outs, retraw, retweights, pytest)
+        if retweights and outs['weights'].shape[1] == 1:
+            outs['weights'] = outs['weights'][:, :0]                           # one sample: see raw2outputs
         ret = nerf_mod.attach_deferred_grad(outs, deferred)
         if DEBUG:
             for k in ret:
@@ -594,9 +596,16 @@ class Renderer(torch.nn.Module):
         if self.raw_noise_std > 0.:
             noise = (_pytest_uniform([R, S], dev) if pytest else torch.randn([R, S], device=dev)) * self.raw_noise_std
         if torch.is_grad_enabled() and (raw.requires_grad or rays_d.requires_grad):
-            return _Raw2OutputsFn.apply(raw.contiguous().float(), z, rays_d.contiguous().float(), noise, bool(self.white_bkgd))
-        with torch.no_grad():
-            return _Raw2OutputsFn.apply(raw_c, z, d, noise, bool(self.white_bkgd))
+            out = _Raw2OutputsFn.apply(raw.contiguous().float(), z, rays_d.contiguous().float(), noise, bool(self.white_bkgd))
+        else:
+            with torch.no_grad():
+                out = _Raw2OutputsFn.apply(raw_c, z, d, noise, bool(self.white_bkgd))
+        if S == 1:
+            # With one sample the reference's `dists` is empty (it expands the 1e10 tail to dists[..., :1].shape = [R, 0],
+            # render_utils.py:256-258), and so are alpha and the weights: the kernels return the sums over nothing
+            # (background colour, acc 0, disp NaN, zero gradients) and the weights come back as [R, 0].
+            out = (out[0], out[1], out[2], out[3][:, :0], out[4])
+        return out
 
     def render_from_batch_poses(self, H, W, K, chunk, batch_c2w, coarse_model, fine_model,
                                 retraw, save_directory, b_combine_as_video=False, tb_writer=None, io_workers=4):

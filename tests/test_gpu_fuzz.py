@@ -247,3 +247,185 @@ def test_random_batch_sizes_through_the_one_call_path_equal_the_chunk_loop(dev, 
     for k in outs[0]:
         assert outs[0][k].shape[0] == N, (k, outs[0][k].shape)
         assert torch.equal(torch.nan_to_num(outs[0][k]), torch.nan_to_num(outs[1][k])), (N, chunk, precision, cfg, k)
+
+
+# ------------------------------------------------------------------ the pieces, on shapes nobody picked
+def draw_arch(i):
+    rng = np.random.default_rng(15000 + i)
+    D = int(rng.integers(1, 10))
+    W = int(rng.choice([2, 3, 8, 31, 64, 100, 129, 256, 300, 512, 777]))
+    skips = sorted({int(s) for s in rng.integers(0, D + 2, size=int(rng.integers(0, 3))) if s != D - 1})
+    return dict(D=D, W=W, output_ch=int(rng.integers(1, 10)), skips=skips, use_viewdirs=bool(rng.random() < 0.5),
+                multires=int(rng.integers(0, 13)), multires_views=int(rng.integers(0, 7)),
+                i_embed=-1 if rng.random() < 0.15 else 0)
+
+
+@pytest.mark.parametrize("i", range(24))
+def test_random_architectures_on_the_exact_kernel(dev, i):
+    """nerf.py:62-94 builds a network from any D, W, skips, multires, output_ch, i_embed.  Random ones -- depth 1..9,
+    widths from 2 to 777, several skips (also out of range: the reference ignores those), multires 0 (embedding = x),
+    the identity embedder, odd W // 2 view layers -- against the oracle in the fp32 tolerances, whatever precision was
+    asked for (anything but the 8x256 family runs on the exact kernel)."""
+    arch = draw_arch(i)
+    rng = np.random.default_rng(16000 + i)
+    shape = [(1, 1), (3, 5), (41, 7), (200, 13)][i % 4]
+    pts = torch.from_numpy(rng.uniform(-2, 2, size=shape + (3,)).astype(np.float32))
+    vd = None
+    if arch["use_viewdirs"]:
+        vd = torch.nn.functional.normalize(torch.from_numpy(rng.normal(size=(shape[0], 3)).astype(np.float32)), dim=-1)
+    sharpen = 2.0 if arch["W"] >= 31 else 1.0
+    ref = P.O.nerf_forward(*P.cpu_model(i, sharpen, **arch), pts, vd)
+    scale = max(1.0, float(ref.abs().max()))
+    for prec in ("fp32", "bf16", "fp32_split")[:1 + 2 * (i % 2)]:
+        out = P.gpu_model(dev, i, sharpen, prec, **arch)(pts.to(dev), vd.to(dev) if vd is not None else None)
+        assert out.shape == ref.shape, (arch, out.shape, ref.shape)
+        P.close(out, ref, atol=1e-4 * scale, rtol=1e-4)
+
+
+def test_a_skip_after_the_last_layer_fails_as_it_does_in_the_reference(dev):
+    """skips containing D - 1 concatenates the input in front of the heads, whose nn.Linear sizes do not expect it: the
+    reference raises at the first forward (nerf.py:117-118 against :85-94).  Here it must not run either."""
+    arch = dict(P.VD, D=4, skips=[3])
+    with pytest.raises(Exception):
+        m = P.amd()[0].NeRF(**arch).to(dev)
+        m(torch.zeros(2, 3, 3, device=dev), torch.ones(2, 3, device=dev))
+        torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("i", range(10))
+def test_random_embedders(dev, i):
+    nerf, _, _ = P.amd()
+    rng = np.random.default_rng(17000 + i)
+    L = int(rng.integers(0, 17))
+    shape = tuple(int(s) for s in rng.integers(1, 40, size=int(rng.integers(1, 4)))) + (3,)
+    x = torch.from_numpy((rng.uniform(-1, 1, size=shape) * float(rng.choice([1.0, 4.0, 40.0]))).astype(np.float32))
+    fn, dim = nerf.get_embedder(L, 0)
+    got = fn(x.to(dev))
+    ref = P.O.embed(x, L)
+    assert dim == ref.shape[-1] and got.shape == ref.shape
+    # sin / cos of 2^(L-1) x: the argument is exact in fp32 (a power of two times x); libm and the device differ by ulps
+    P.close(got, ref, atol=2e-6)
+    ident, d3 = nerf.get_embedder(L, -1)
+    assert d3 == 3 and torch.equal(ident(x.to(dev)).cpu(), x)
+
+
+@pytest.mark.parametrize("i", range(16))
+def test_random_sample_pdf_shapes(dev, i):
+    _, _, utils = P.amd()
+    rng = np.random.default_rng(18000 + i)
+    R, nb, N = int(rng.choice([1, 3, 64, 257])), int(rng.integers(2, 400)), int(rng.integers(1, 300))
+    det = bool(rng.random() < 0.5)
+    bins = np.sort(rng.uniform(2, 6, size=(R, nb)).astype(np.float32), -1)
+    w = rng.uniform(0, 1, size=(R, nb - 1)).astype(np.float32) ** float(rng.choice([1.0, 4.0, 12.0]))
+    w[rng.random(w.shape) < rng.choice([0.0, 0.3, 0.8])] = 0.0
+    if R > 1:
+        w[0] = 0.0                                                      # an all-zero row: uniform pdf
+    bins_t, w_t = torch.from_numpy(bins), torch.from_numpy(w)
+    got = utils.sample_pdf(bins_t.to(dev), w_t.to(dev), N, det=det, pytest=not det).cpu()
+    u = P.O.pytest_u_for_sample_pdf(R, N, det) if not det else torch.linspace(0., 1., N).expand(R, N)
+    ref = P.O.sample_pdf(bins_t, w_t, N, det=det, u=u.contiguous())
+    assert got.shape == ref.shape == (R, N)
+    well = P.pdf_denominators(bins_t, w_t, u) > 1e-3
+    d = (got - ref).abs().numpy()
+    if well.any():
+        assert (d[well] < 2e-5).mean() > 0.999, (R, nb, N, det, float(d[well].max()))
+    widest = np.diff(bins, axis=-1).max(-1)[:, None] if nb > 1 else np.zeros((R, 1), np.float32)
+    assert (d <= widest * 1.001 + 4e-6).all(), (R, nb, N, det, float(d.max()))
+    assert float(got.min()) >= bins.min() - 1e-6 and float(got.max()) <= bins.max() + 1e-6
+
+
+@pytest.mark.parametrize("i", range(16))
+def test_random_raw2outputs_shapes(dev, i):
+    _, render_utils, _ = P.amd()
+    rng = np.random.default_rng(19000 + i)
+    R, S, C = int(rng.choice([1, 2, 63, 300])), int(rng.choice([1, 2, 3, 64, 100, 192, 513, 1500])), int(rng.choice([4, 4, 5, 9]))
+    white, noise = bool(rng.random() < 0.5), float(rng.random() < 0.4)
+    raw = torch.from_numpy((rng.normal(size=(R, S, C)) * float(rng.choice([0.3, 3.0, 30.0]))).astype(np.float32))
+    z = torch.from_numpy(np.sort(rng.uniform(0.1, 9, size=(R, S)).astype(np.float32), -1))
+    if S > 3:
+        z[:, 2] = z[:, 1]                                               # a zero-length interval
+    rd = torch.from_numpy(rng.normal(size=(R, 3)).astype(np.float32))
+    if R > 1:
+        raw[0, :, 3] = -1.0                                             # an empty ray: acc 0, disp NaN (render_utils.py:285)
+    r = render_utils.Renderer(**dict(P.BASE, white_bkgd=white, raw_noise_std=noise))
+    got = [t.cpu() for t in r.raw2outputs(raw.to(dev), z.to(dev), rd.to(dev), pytest=noise > 0)]
+    nz = P.O.pytest_uniform([R, S]) * noise if noise > 0 else None
+    ref = P.O.raw2outputs(raw, z, rd, white, nz)
+    for name, a, b in zip(("rgb", "disp", "acc", "weights", "depth"), got, ref):
+        assert a.shape == b.shape, (name, a.shape, b.shape)
+        assert torch.equal(torch.isnan(a), torch.isnan(b)), (name, R, S)
+        if b.numel():                                                  # (one sample: the reference's weights are [R, 0])
+            P.close(torch.nan_to_num(a), torch.nan_to_num(b), atol=4e-6 * max(1.0, float(torch.nan_to_num(b).abs().max())), rtol=3e-5)
+
+
+@pytest.mark.parametrize("i", range(10))
+def test_random_cameras(dev, i):
+    _, _, utils = P.amd()
+    rng = np.random.default_rng(20000 + i)
+    H, W = int(rng.integers(1, 90)), int(rng.integers(1, 90))
+    K = np.array([[rng.uniform(20, 900), 0, rng.uniform(0, W)], [0, rng.uniform(20, 900), rng.uniform(0, H)], [0, 0, 1]])
+    c2w = synth.pose_spherical(float(rng.uniform(-180, 180)), float(rng.uniform(-80, 10)), float(rng.uniform(1, 6)))
+    if i % 2:
+        c2w = c2w[:3]
+    ro, rd = utils.get_rays(H, W, K, torch.from_numpy(np.asarray(c2w, np.float32)).to(dev))
+    ro_ref, rd_ref = P.O.get_rays(H, W, K, torch.from_numpy(np.asarray(c2w, np.float32)))
+    assert ro.shape == (H, W, 3) and rd.shape == (H, W, 3)
+    P.close(ro, ro_ref, atol=0)
+    P.close(rd, rd_ref, atol=1e-6, rtol=1e-6)
+    focal, near = float(K[0][0]), float(rng.choice([1.0, 0.5]))
+    rd_safe = rd_ref.clone()
+    rd_safe[..., 2] = -rd_safe[..., 2].abs() - 0.05                     # forward-facing: d_z away from 0
+    o1, d1 = utils.ndc_rays(H, W, focal, near, ro_ref.to(dev), rd_safe.to(dev))
+    o2, d2 = P.O.ndc_rays(H, W, focal, near, ro_ref, rd_safe)
+    P.close(o1, o2, atol=2e-6 * max(1.0, float(o2.abs().max())), rtol=2e-6)
+    P.close(d1, d2, atol=2e-6 * max(1.0, float(d2.abs().max())), rtol=2e-6)
+
+
+def test_one_and_two_coarse_samples_follow_the_reference(dev):
+    """The degenerate ends of the sample counts, as the reference behaves there: one sample -- `dists` is empty
+    (render_utils.py:256-258 expands the 1e10 tail to an empty shape), the weights are [R, 0], the image is the
+    background, disp is NaN; two samples without importance sampling -- a regular render; importance sampling on fewer
+    than three coarse samples -- the reference's sample_pdf raises (empty cdf), and so does this."""
+    _, render_utils, _ = P.amd()
+    from nerf_shared_amd._lib import NerfAmdError
+    K = synth.lego_intrinsics(40, 40)
+    ro, rd = synth.rays_np(40, 40, K, synth.LEGO_C2W, np.arange(0, 1600, 97))
+    batch = torch.from_numpy(synth.ray_batch_np(ro, rd, 2.0, 6.0, True))
+    cpu, gpu = P.cpu_model(1, 3.0, **P.VD), P.gpu_model(dev, 1, 3.0, "fp32", **P.VD)
+    for Nc, white in ((1, True), (1, False), (2, True)):
+        cfg = dict(P.BASE, N_samples=Nc, N_importance=0, white_bkgd=white)
+        ref = P.O.render_rays(P.O.RenderCfg(**cfg), batch, cpu, None, retraw=True, retweights=True)
+        out = render_utils.Renderer(**cfg).render_rays(batch.to(dev), gpu, None, retraw=True, retweights=True)
+        assert sorted(out) == sorted(ref)
+        for k in ref:
+            assert tuple(out[k].shape) == tuple(ref[k].shape), (Nc, k, out[k].shape, ref[k].shape)
+            assert torch.equal(torch.isnan(out[k].cpu()), torch.isnan(ref[k])), (Nc, k)
+            P.close(torch.nan_to_num(out[k]), torch.nan_to_num(ref[k]), atol=2e-4, rtol=2e-4)
+    for Nc in (1, 2):
+        cfg = dict(P.BASE, N_samples=Nc, N_importance=4)
+        with pytest.raises(RuntimeError):
+            P.O.render_rays(P.O.RenderCfg(**cfg), batch, cpu, cpu)
+        with pytest.raises(NerfAmdError, match="N_samples >= 3"):
+            render_utils.Renderer(**cfg).render_rays(batch.to(dev), gpu, gpu)
+    # and through autograd: one sample has no path from raw to anything -- zero gradients, like the reference's
+    raw = torch.randn(6, 1, 4, device=dev, requires_grad=True)
+    r = render_utils.Renderer(**P.BASE)
+    rgb, disp, acc, w, depth = r.raw2outputs(raw, torch.full((6, 1), 3.0, device=dev), torch.randn(6, 3, device=dev))
+    assert w.shape == (6, 0) and bool((rgb == 1).all()) and bool((acc == 0).all()) and bool(torch.isnan(disp).all())
+    (rgb.sum() + acc.sum() + depth.sum()).backward()
+    assert raw.grad is not None and bool((raw.grad == 0).all())
+
+
+def test_the_widest_models_run_on_half_tiles(dev):
+    """W = 1024 with the largest encodings is 1 279 feature rows: 64 points of them do not fit the CU's LDS, 32 do
+    (mlp_fp32.hip, HALVES = 1); W = 600 needs it too, W = 512 does not.  All against the oracle."""
+    rng = np.random.default_rng(3)
+    pts = torch.from_numpy(rng.uniform(-1, 1, size=(33, 3, 3)).astype(np.float32))
+    vd = torch.nn.functional.normalize(torch.from_numpy(rng.normal(size=(33, 3)).astype(np.float32)), dim=-1)
+    for arch in (dict(D=2, W=1024, output_ch=4, skips=[0], use_viewdirs=True, multires=20, multires_views=20),
+                 dict(D=3, W=600, output_ch=9, skips=[], use_viewdirs=False, multires=10, multires_views=4),
+                 dict(D=3, W=512, output_ch=4, skips=[1], use_viewdirs=True, multires=16, multires_views=16)):
+        v = vd if arch["use_viewdirs"] else None
+        ref = P.O.nerf_forward(*P.cpu_model(2, 1.0, **arch), pts, v)
+        out = P.gpu_model(dev, 2, 1.0, "fp32", **arch)(pts.to(dev), v.to(dev) if v is not None else None)
+        P.close(out, ref, atol=1e-4 * max(1.0, float(ref.abs().max())), rtol=1e-4)
