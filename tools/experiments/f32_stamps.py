@@ -28,10 +28,10 @@ def build():
     os.makedirs(OUT, exist_ok=True)
     s = open(os.path.join(CSRC, "mlp_fp32.hip")).read()
     s = sub(s, "namespace na {\n", "namespace na {\n__device__ unsigned long long g_f32_stamps[64];\n")
-    s = sub(s, "    for (int i = tid; i < rows * 64; i += 512) act[i] = 0.0f;\n    __syncthreads();\n",
+    s = sub(s, "    for (int i = tid; i < rows * PTS; i += 512) act[i] = 0.0f;\n    __syncthreads();\n",
             "    unsigned long long t_prev = __builtin_amdgcn_s_memtime();\n"
             "    unsigned long long acc_t[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};\n"
-            "    for (int i = tid; i < rows * 64; i += 512) act[i] = 0.0f;\n    __syncthreads();\n")
+            "    for (int i = tid; i < rows * PTS; i += 512) act[i] = 0.0f;\n    __syncthreads();\n")
     s = sub(s, "    for (int li = 0; li < a.n_layers; ++li) {\n        const LayerF32 L = a.layers[li];",
             "    { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc_t[13] += t - t_prev; t_prev = t; }\n"
             "    for (int li = 0; li < a.n_layers; ++li) {\n"
