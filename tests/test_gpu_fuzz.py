@@ -429,3 +429,63 @@ def test_the_widest_models_run_on_half_tiles(dev):
         ref = P.O.nerf_forward(*P.cpu_model(2, 1.0, **arch), pts, v)
         out = P.gpu_model(dev, 2, 1.0, "fp32", **arch)(pts.to(dev), v.to(dev) if v is not None else None)
         P.close(out, ref, atol=1e-4 * max(1.0, float(ref.abs().max())), rtol=1e-4)
+
+
+@pytest.mark.parametrize("i", range(12))
+def test_random_calls_of_render(dev, i):
+    """Renderer.render as main.py and the demos call it: c2w= or rays=, c2w_staticcam, NDC, with and without view
+    directions, any image size and any chunk -- random combinations against the oracle's render (fp32 mode: coarse
+    maps tight, fine maps by the fraction criterion of the end-to-end goldens), shapes of every returned tensor
+    included.  retraw rotates."""
+    _, render_utils, _ = P.amd()
+    rng = np.random.default_rng(21000 + i)
+    H, W = int(rng.integers(1, 30)), int(rng.integers(1, 30))
+    vd, ndc = bool(rng.random() < 0.7), bool(rng.random() < 0.3)
+    cfg = dict(P.BASE, N_samples=int(rng.integers(3, 40)), N_importance=int(rng.choice([0, 5, 24])), use_viewdirs=vd, ndc=ndc,
+               white_bkgd=bool(rng.random() < 0.5), lindisp=bool(rng.random() < 0.2) and not ndc)
+    if ndc:
+        cfg.update(near=0.0, far=1.0)
+        K = np.array([[40.0, 0, 0.5 * W], [0, 40.0, 0.5 * H], [0, 0, 1]])
+        c2w = np.array([[1, 0, 0, 0.05], [0, 1, 0, -0.02], [0, 0, 1, 0.1]], np.float32)
+    else:
+        K = synth.lego_intrinsics(max(H, 2), max(W, 2))
+        c2w = np.asarray(synth.pose_spherical(float(rng.uniform(-180, 180)), float(rng.uniform(-60, -10)), 4.0), np.float32)[:3]
+    chunk = int(rng.integers(1, H * W + 12)) if H * W > 40 else int(rng.integers(1, 60))
+    arch = dict(P.VD if vd else P.NOVD)
+    cpu_c, cpu_f = P.cpu_model(1, 3.0, **arch), P.cpu_model(12, 3.0, **arch)
+    gpu_c, gpu_f = P.gpu_model(dev, 1, 3.0, "fp32", **arch), P.gpu_model(dev, 12, 3.0, "fp32", **arch)
+    fine = bool(rng.random() < 0.8)
+    retraw = bool(i % 2)
+    kw, kw_ref = {}, {}
+    c2w_t = torch.from_numpy(c2w)
+    if rng.random() < 0.5:
+        kw["c2w"], kw_ref["c2w"] = c2w_t.to(dev) if i % 3 == 0 else c2w_t, c2w_t
+        if vd and rng.random() < 0.4:
+            cam = torch.from_numpy(np.asarray(synth.pose_spherical(float(rng.uniform(-180, 180))), np.float32)[:3])
+            kw["c2w_staticcam"], kw_ref["c2w_staticcam"] = cam, cam
+    else:
+        ro, rd = P.O.get_rays(H, W, K, c2w_t)
+        kw["rays"], kw_ref["rays"] = torch.stack([ro, rd], 0).to(dev), (ro, rd)
+    ref = P.O.render(P.O.RenderCfg(**cfg), H, W, K, cpu_c, cpu_f if fine else None, chunk=chunk, retraw=retraw, **kw_ref)
+    out = render_utils.Renderer(**cfg).render(H, W, K, gpu_c, gpu_f if fine else None, chunk=chunk, retraw=retraw, **kw)
+    assert len(out) == 4 and sorted(out[3]) == sorted(ref[3]), (sorted(out[3]), sorted(ref[3]))
+    for a, b, name in zip(out[:3], ref[:3], ("rgb", "disp", "acc")):
+        assert tuple(a.shape) == tuple(b.shape), (name, a.shape, b.shape)
+    for k, b in ref[3].items():
+        assert tuple(out[3][k].shape) == tuple(b.shape), (k, out[3][k].shape, b.shape)
+    two_pass = cfg["N_importance"] > 0
+    if two_pass:
+        for k in ("rgb0", "acc0"):
+            P.close(out[3][k], ref[3][k], atol=2e-4, rtol=2e-4)
+        nan = torch.isnan(ref[3]["disp0"])
+        assert torch.equal(torch.isnan(out[3]["disp0"]).cpu(), nan)
+        P.close(torch.nan_to_num(out[3]["disp0"]), torch.nan_to_num(ref[3]["disp0"]), atol=2e-4, rtol=2e-4)
+        P.close_frac(out[0], ref[0], atol=2e-4, frac=0.85)
+        P.close_frac(out[2], ref[2], atol=2e-4, frac=0.85)
+    else:
+        P.close(out[0], ref[0], atol=2e-4, rtol=2e-4)
+        P.close(out[2], ref[2], atol=2e-4, rtol=2e-4)
+        assert torch.equal(torch.isnan(out[1]).cpu(), torch.isnan(ref[1]))
+        P.close(torch.nan_to_num(out[1]), torch.nan_to_num(ref[1]), atol=2e-4, rtol=2e-4)
+        if retraw:
+            P.close(out[3]["raw"], ref[3]["raw"], atol=2e-4, rtol=2e-4)
