@@ -489,3 +489,40 @@ def test_random_calls_of_render(dev, i):
         P.close(torch.nan_to_num(out[1]), torch.nan_to_num(ref[1]), atol=2e-4, rtol=2e-4)
         if retraw:
             P.close(out[3]["raw"], ref[3]["raw"], atol=2e-4, rtol=2e-4)
+
+
+@pytest.mark.parametrize("i", range(10))
+def test_random_single_pass_ray_gradients(dev, monkeypatch, i):
+    """dL/d(rays_o, rays_d) through Renderer.render(rays=...) with frozen networks (demo_est_rel_pose.py:87-98) for random
+    single-pass configurations -- any sample and ray count, lindisp, both backgrounds, with and without view branch,
+    non-unit directions -- against torch.autograd on the oracle with the kernel's roundings."""
+    from nerf_shared_amd import render_utils
+    cfg, arch, batch, target, seed, lift = draw_train_case(100 + i)
+    cfg = dict(cfg, perturb=0.0, raw_noise_std=0.0)
+    m, cpu = B._models(dev, seed, 2.0, arch)
+    head = "alpha_linear.bias" if arch["use_viewdirs"] else "output_linear.bias"
+    with torch.no_grad():
+        dict(m.named_parameters())[head][-1 if arch["use_viewdirs"] else 3] += lift
+        cpu[head][-1 if arch["use_viewdirs"] else 3] += lift
+    m.requires_grad_(False)
+    scale = 1.0 + 0.1 * i
+    ro = batch[:, 0:3].clone().to(dev).requires_grad_(True)
+    rd = (batch[:, 3:6] * scale).clone().to(dev).requires_grad_(True)
+    rgb, disp, acc, extras = render_utils.Renderer(**cfg).render(400, 400, None, m, None, chunk=97, rays=(ro, rd), retraw=False)
+    ((rgb - target.to(dev)) ** 2).mean().backward()
+    monkeypatch.setattr(B.O, "nerf_forward", lambda sd, a, pts, vd, netchunk=0: B.bf16_field(sd, pts, vd, arch["multires"],
+                                                                                             arch["multires_views"]))
+    o = batch[:, 0:3].clone().requires_grad_(True)
+    d = (batch[:, 3:6] * scale).clone().requires_grad_(True)
+    out = B.O.render(B.O.RenderCfg(**cfg), 400, 400, None, ({k: v.detach() for k, v in cpu.items()}, B.O.Arch(**arch)), None,
+                     chunk=97, rays=(o, d), retraw=False)
+    ((out[0] - target) ** 2).mean().backward()
+    monkeypatch.undo()
+    for name, g, ref in (("rays_o", ro.grad.cpu(), o.grad), ("rays_d", rd.grad.cpu(), d.grad)):
+        assert torch.isfinite(g).all(), name
+        if float(ref.norm()) == 0.0:
+            assert float(g.norm()) == 0.0, name
+            continue
+        e = B.rel_err(g, ref)
+        print("ray-gradient fuzz", i, name, "%.4f" % e, cfg["N_samples"], batch.shape[0], arch["use_viewdirs"], arch["multires"])
+        assert e < 8e-2, (name, e, cfg, arch)
