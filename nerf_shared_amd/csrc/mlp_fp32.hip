@@ -81,7 +81,7 @@ __global__ __launch_bounds__(512) void mlp_f32_kernel(MlpArgs a) {
     const int64_t p0 = (int64_t)blockIdx.x * PTS;
     const int n_in_rows = a.input_ch + a.input_ch_views;
     for (int i = tid; i < n_in_rows * PTS; i += 512) {
-        const int row = i / PTS, q = i & (PTS - 1);
+        const int row = i >> (HALVES == 2 ? 6 : 5), q = i & (PTS - 1);
         int64_t p = p0 + q;
         if (p >= a.P) p = a.P - 1;
         const int64_t ray = (int64_t)((uint32_t)p / (uint32_t)a.S);
