@@ -15,6 +15,7 @@ gradients are requested: outputs never silently come back without autograd histo
 import ctypes
 import weakref
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -443,3 +444,19 @@ class NeRF(nn.Module):
         view_dir = torch.ones_like(points[..., 0, :]) if self.use_viewdirs else None
         output = self.forward(points, view_dir, chunk)
         return output[..., -1]
+
+    def load_weights_from_keras(self, weights):
+        """The weight list of a Keras NeRF (kernel [in, out], bias per layer, in the order pts_linears, feature,
+        views, rgb, alpha) into this model (nerf.py:146-173): kernels transposed to nn.Linear's [out, in].  Like the
+        reference it covers the view-branch model only and replaces `.data`; the packed device copy is refreshed on
+        the next call."""
+        assert self.use_viewdirs, "Not implemented if use_viewdirs=False"
+        targets = [self.pts_linears[i] for i in range(self.D)] + [self.feature_linear, self.views_linears[0],
+                                                                   self.rgb_linear, self.alpha_linear]
+        for j, lin in enumerate(targets):
+            w = torch.from_numpy(np.transpose(weights[2 * j]))
+            b = torch.from_numpy(np.transpose(weights[2 * j + 1]))
+            lin.weight.data = w.to(lin.weight.device)
+            lin.bias.data = b.to(lin.bias.device)
+        self.__dict__.pop('_mods_cache', None)
+        self.weights_changed()

@@ -452,3 +452,26 @@ def test_deferred_gradient_trap_is_plain_autograd():
         (out["rgb_map"].sum() + out["acc_map"].sum()).backward()
     assert anchor.grad is None
     assert nerf.attach_deferred_grad(x, None) is x                     # nothing requested: nothing attached
+
+
+def test_load_weights_from_keras_maps_the_list_like_the_reference():
+    """nerf.py:146-173: kernels [in, out] transposed, list order pts_linears (2 per layer), feature, views, rgb, alpha;
+    only for the view-branch model (the reference asserts)."""
+    import numpy as np
+    import torch
+    from nerf_shared_amd import nerf, synth
+    arch = dict(D=8, W=256, output_ch=5, skips=[4], use_viewdirs=True)
+    sd = synth.make_state_dict(3, 1.0, **{**arch, "skips": (4,)})
+    order = ["pts_linears.%d" % i for i in range(8)] + ["feature_linear", "views_linears.0", "rgb_linear", "alpha_linear"]
+    keras = []
+    for name in order:
+        keras += [np.ascontiguousarray(sd[name + ".weight"].T), sd[name + ".bias"].copy()]
+    m = nerf.NeRF(**arch)
+    m.load_weights_from_keras(keras)
+    got = m.state_dict()
+    for name in order:
+        assert torch.equal(got[name + ".weight"], torch.from_numpy(sd[name + ".weight"])), name
+        assert torch.equal(got[name + ".bias"], torch.from_numpy(sd[name + ".bias"])), name
+    assert m._packed_key is None
+    with pytest.raises(AssertionError):
+        nerf.NeRF(D=8, W=256, use_viewdirs=False).load_weights_from_keras(keras)
