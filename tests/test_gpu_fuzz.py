@@ -9,6 +9,8 @@ reproducible configuration.  The exact-fp32 kernel and the split-precision kerne
 kernel is checked for what does not depend on its rounding (depth ordering, finite outputs, weights that sum to acc)
 and for staying near the fp32 kernel on all but a few rays.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -19,6 +21,9 @@ from nerf_shared_amd import synth
 pytestmark = pytest.mark.gpu
 
 dev = P.dev
+
+# NERF_AMD_FUZZ_SCALE=10 runs ten times as many cases of every sweep (tests/run_fuzz_sweep.sh; the default is the suite's share)
+SCALE = max(1, int(os.environ.get("NERF_AMD_FUZZ_SCALE", "1")))
 
 
 def draw_case(i):
@@ -55,7 +60,7 @@ def draw_case(i):
     return cfg, arch, (H, W, K, c2w, idx), seeds, use_pytest
 
 
-@pytest.mark.parametrize("i", range(48))
+@pytest.mark.parametrize("i", range(48 * SCALE))
 @pytest.mark.parametrize("precision", ["fp32", "fp32_split"])
 def test_random_configuration_against_the_oracle(dev, i, precision):
     if precision == "fp32_split" and i % 2:
@@ -68,7 +73,7 @@ def test_random_configuration_against_the_oracle(dev, i, precision):
                                                    rays=int(batch.shape[0]), multires=arch["multires"]))
 
 
-@pytest.mark.parametrize("i", range(48))
+@pytest.mark.parametrize("i", range(48 * SCALE))
 def test_random_configuration_bf16_invariants(dev, i):
     _, render_utils, _ = P.amd()
     cfg, arch, (H, W, K, c2w, idx), seeds, use_pytest = draw_case(i)
@@ -93,7 +98,7 @@ def test_random_configuration_bf16_invariants(dev, i):
     gate = 1e-2 if seeds[2] == 1.0 else 5e-2
     d = (ref["rgb_map"] - got["rgb_map"]).abs()
     assert float((d < gate).float().mean()) >= 0.97, (float(d.max()), float(d.mean()))
-    assert float(d.mean()) < 0.2 * gate, float(d.mean())
+    assert float(d.median()) < 0.1 * gate, float(d.median())
 
 
 # ------------------------------------------------------------------ training kernels on awkward sizes
@@ -170,7 +175,7 @@ def draw_train_case(i):
     return cfg, arch, batch, target, int(rng.integers(0, 40)), float(rng.choice([0.3, 1.0]))
 
 
-@pytest.mark.parametrize("i", range(16))
+@pytest.mark.parametrize("i", range(16 * SCALE))
 def test_random_single_pass_training_gradients(dev, monkeypatch, i):
     """The reference's loss through one pass of render_rays (N_importance = 0: no resampling, so the comparison is
     not at the mercy of sample_pdf's conditioning) for random sample counts, ray counts, jitter, sigma noise, lindisp,
@@ -208,7 +213,7 @@ def test_random_single_pass_training_gradients(dev, monkeypatch, i):
     assert worst < 8e-2, (cfg, arch, worst)
 
 
-@pytest.mark.parametrize("i", range(12))
+@pytest.mark.parametrize("i", range(12 * SCALE))
 def test_random_batch_sizes_through_the_one_call_path_equal_the_chunk_loop(dev, i):
     """nerf_amd_render_batch regroups the rays into 32768-ray launches and runs the per-ray kernels on a side stream;
     the chunk-at-a-time path is one render_rays call per API chunk.  For ray counts around the launch-group size and
@@ -217,7 +222,7 @@ def test_random_batch_sizes_through_the_one_call_path_equal_the_chunk_loop(dev, 
     _, render_utils, utils = P.amd()
     Rn = render_utils.Renderer
     rng = np.random.default_rng(12000 + i)
-    N = int([1, 2, 255, 4097, 32767, 32768, 32769, 65535, 65537, 98305, 20011, 77777][i])
+    N = int([1, 2, 255, 4097, 32767, 32768, 32769, 65535, 65537, 98305, 20011, 77777][i]) if i < 12 else int(rng.integers(1, 100000))
     chunk = int(rng.choice([257, 1000, 4096, 12000, 32768, 40000, 100000]))
     precision = ["bf16", "fp32_split", "fp32"][i % 3]
     if precision == "fp32" and N > 40000:
@@ -260,7 +265,7 @@ def draw_arch(i):
                 i_embed=-1 if rng.random() < 0.15 else 0)
 
 
-@pytest.mark.parametrize("i", range(24))
+@pytest.mark.parametrize("i", range(24 * SCALE))
 def test_random_architectures_on_the_exact_kernel(dev, i):
     """nerf.py:62-94 builds a network from any D, W, skips, multires, output_ch, i_embed.  Random ones -- depth 1..9,
     widths from 2 to 777, several skips (also out of range: the reference ignores those), multires 0 (embedding = x),
@@ -292,7 +297,7 @@ def test_a_skip_after_the_last_layer_fails_as_it_does_in_the_reference(dev):
         torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("i", range(10))
+@pytest.mark.parametrize("i", range(10 * SCALE))
 def test_random_embedders(dev, i):
     nerf, _, _ = P.amd()
     rng = np.random.default_rng(17000 + i)
@@ -309,7 +314,7 @@ def test_random_embedders(dev, i):
     assert d3 == 3 and torch.equal(ident(x.to(dev)).cpu(), x)
 
 
-@pytest.mark.parametrize("i", range(16))
+@pytest.mark.parametrize("i", range(16 * SCALE))
 def test_random_sample_pdf_shapes(dev, i):
     _, _, utils = P.amd()
     rng = np.random.default_rng(18000 + i)
@@ -334,7 +339,7 @@ def test_random_sample_pdf_shapes(dev, i):
     assert float(got.min()) >= bins.min() - 1e-6 and float(got.max()) <= bins.max() + 1e-6
 
 
-@pytest.mark.parametrize("i", range(16))
+@pytest.mark.parametrize("i", range(16 * SCALE))
 def test_random_raw2outputs_shapes(dev, i):
     _, render_utils, _ = P.amd()
     rng = np.random.default_rng(19000 + i)
@@ -358,7 +363,7 @@ def test_random_raw2outputs_shapes(dev, i):
             P.close(torch.nan_to_num(a), torch.nan_to_num(b), atol=4e-6 * max(1.0, float(torch.nan_to_num(b).abs().max())), rtol=3e-5)
 
 
-@pytest.mark.parametrize("i", range(10))
+@pytest.mark.parametrize("i", range(10 * SCALE))
 def test_random_cameras(dev, i):
     _, _, utils = P.amd()
     rng = np.random.default_rng(20000 + i)
@@ -431,7 +436,7 @@ def test_the_widest_models_run_on_half_tiles(dev):
         P.close(out, ref, atol=1e-4 * max(1.0, float(ref.abs().max())), rtol=1e-4)
 
 
-@pytest.mark.parametrize("i", range(12))
+@pytest.mark.parametrize("i", range(12 * SCALE))
 def test_random_calls_of_render(dev, i):
     """Renderer.render as main.py and the demos call it: c2w= or rays=, c2w_staticcam, NDC, with and without view
     directions, any image size and any chunk -- random combinations against the oracle's render (fp32 mode: coarse
@@ -491,7 +496,7 @@ def test_random_calls_of_render(dev, i):
             P.close(out[3]["raw"], ref[3]["raw"], atol=2e-4, rtol=2e-4)
 
 
-@pytest.mark.parametrize("i", range(10))
+@pytest.mark.parametrize("i", range(10 * SCALE))
 def test_random_single_pass_ray_gradients(dev, monkeypatch, i):
     """dL/d(rays_o, rays_d) through Renderer.render(rays=...) with frozen networks (demo_est_rel_pose.py:87-98) for random
     single-pass configurations -- any sample and ray count, lindisp, both backgrounds, with and without view branch,
