@@ -98,7 +98,7 @@ def test_random_configuration_bf16_invariants(dev, i):
     gate = 1e-2 if seeds[2] == 1.0 else 5e-2
     d = (ref["rgb_map"] - got["rgb_map"]).abs()
     assert float((d < gate).float().mean()) >= 0.97, (float(d.max()), float(d.mean()))
-    assert float(d.median()) < 0.1 * gate, float(d.median())
+    assert float(d.median()) < (2e-3 if seeds[2] == 1.0 else 2e-2), float(d.median())   # the golden table's median gates
 
 
 # ------------------------------------------------------------------ training kernels on awkward sizes
