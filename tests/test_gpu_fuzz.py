@@ -531,3 +531,47 @@ def test_random_single_pass_ray_gradients(dev, monkeypatch, i):
         e = B.rel_err(g, ref)
         print("ray-gradient fuzz", i, name, "%.4f" % e, cfg["N_samples"], batch.shape[0], arch["use_viewdirs"], arch["multires"])
         assert e < 8e-2, (name, e, cfg, arch)
+
+
+def test_concurrent_host_threads_render_the_same_bits(dev):
+    """The C ABI is re-entrant (include/nerf_amd.h): four host threads, each with its own stream, models and ray batch,
+    render repeatedly at the same time -- through the side-stream lane pool, the per-call workspaces and the weight
+    packs -- and every result equals the same render done alone beforehand, bit for bit."""
+    import threading
+    _, render_utils, utils = P.amd()
+    K = synth.lego_intrinsics(400, 400)
+    jobs = []
+    for t in range(4):
+        cfg = dict(P.BASE, N_samples=[64, 32, 48, 64][t], N_importance=[128, 64, 0, 96][t], white_bkgd=bool(t % 2),
+                   lindisp=(t == 3))
+        prec = ["bf16", "fp32_split", "bf16", "bf16"][t]
+        c, f = P.gpu_model(dev, 1 + t, 3.0, prec, **P.VD), P.gpu_model(dev, 11 + t, 3.0, prec, **P.VD)
+        batch = utils.make_ray_batch(400, 400, K, synth.pose_spherical(40.0 * t), 2.0, 6.0, True, False, device=dev,
+                                     pix0=20000 * t, n=[70000, 9000, 40000, 33000][t])
+        r = render_utils.Renderer(**cfg)
+        want = r.render_batch(c, f if cfg["N_importance"] else None, batch, chunk=[32768, 4096, 10000, 33000][t])
+        jobs.append((r, c, f if cfg["N_importance"] else None, batch, [32768, 4096, 10000, 33000][t], want))
+    torch.cuda.synchronize()
+    errors = []
+
+    def work(t):
+        r, c, f, batch, chunk, want = jobs[t]
+        try:
+            s = torch.cuda.Stream(dev)
+            with torch.cuda.stream(s), torch.no_grad():
+                batch.record_stream(s)
+                for it in range(6):
+                    got = r.render_batch(c, f, batch, chunk=chunk)
+                    s.synchronize()
+                    for k in want:
+                        if not torch.equal(torch.nan_to_num(got[k]), torch.nan_to_num(want[k])):
+                            errors.append((t, it, k))
+        except Exception as e:                      # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:5]
