@@ -32,7 +32,10 @@ The JSON line also carries
                   rocprofv3 --pmc passes) is reported only from a profiles/ summary made from THIS build
                   of the kernels (csrc hash match), else null.
   cpu_baseline -- the CPU oracle (torch-CPU restatement of the reference, "port") on this box's host cores:
-                  all cores granted to the process and 1 thread, on bounded samples (N = 1 only).
+                  all cores granted to the process and 1 thread, on bounded samples (N = 1 only).  Its `check`
+                  entry is the metric's "PSNR vs ref": the rays of the 4096-ray batch the CPU leg timed, rendered by the
+                  bf16 / fp32_split / fp32 modes and compared with the CPU image (PSNR, max |d rgb|, max |d acc|)
+                  on weights whose field has content.
 """
 import argparse
 import ctypes
@@ -84,6 +87,8 @@ def camera(w, synth):
         poses = synth.circle_poses(w["poses"])
     return K, poses
 
+
+CHECK_SEEDS, CHECK_SHARPEN = (1, 19), 3.0      # weights of cpu_baseline.check: a field with content (tests' referee set c19)
 
 FIELD_KERNEL_SOURCES = ("mlp_bf16_s16.hip", "mlp_bf16.hip", "mlp_fp32.hip", "mlp_split.hip", "pipeline.h", "program.h", "program.cpp",
                         "pack.hip", "kernels.h", "launch_util.h", "Makefile")
@@ -226,6 +231,15 @@ def cpu_baseline(torch, synth, w, full_c1=True):
         if full_c1:
             out["c1"] = full_view_c1(best_threads)
         torch.set_num_threads(best_threads)
+        # The referee image for main's `check`: the same 4096 rays on weights whose field has CONTENT (the timed workload's
+        # default-scale random weights render an empty, all-white view -- every mode would agree with it to the last bit):
+        # the x3-sharpened sets of the PSNR referee in tests/ (coarse seed 1, fine seed 19: an opaque object).
+        ro, rd = synth.rays_np(H, W, K, poses[0], np.arange(H * W // 2, H * W // 2 + 4096))
+        batch = torch.from_numpy(synth.ray_batch_np(ro, rd, cfg.near, cfg.far, True))
+        ref_models = [(O.state_dict_to_torch(synth.make_state_dict(sd, CHECK_SHARPEN, **{**ARCH, "skips": (4,)})), O.Arch(**ARCH))
+                      for sd in CHECK_SEEDS]
+        res = O.render_rays(cfg, batch, ref_models[0], ref_models[1])
+        out["_check"] = (batch, {k: res[k] for k in ("rgb_map", "acc_map")})
     return out
 
 
@@ -479,7 +493,37 @@ def main():
         }
         out.update(sub)
         if world == 1 and not args.no_cpu_baseline and key in ("c1", "c2"):
-            out["cpu_baseline"] = cpu_baseline(torch, synth, w, full_c1=not args.no_subrecords)
+            cpu = cpu_baseline(torch, synth, w, full_c1=not args.no_subrecords)
+            chk = cpu.pop("_check", None)
+            if chk is not None:
+                # BASELINE.json's metric also says "PSNR vs ref": the 4096-ray batch the CPU leg just rendered (perturb 0, the
+                # bench's own weights), rendered by every GPU mode and compared with the CPU image -- the oracle as checker
+                import math
+                batch, ref = chk
+                rr = render_utils.Renderer(**renderer_cfg(w, 0.0))
+                cm = []
+                for seed in CHECK_SEEDS:
+                    m = nerf.NeRF(**ARCH)
+                    m.load_state_dict(synth.torch_state_dict(seed, CHECK_SHARPEN, **{**ARCH, "skips": (4,)}))
+                    cm.append(m.to(dev).requires_grad_(False))
+                check = {"rays": int(batch.shape[0]),
+                         "against": "the CPU oracle's fp32 image of the same rays (perturb 0)",
+                         "weights": "x%g-sharpened random weights, seeds %d / %d: a field with content (the timed workload's "
+                                    "default-scale weights render an empty view)" % (CHECK_SHARPEN, CHECK_SEEDS[0], CHECK_SEEDS[1]),
+                         "ref_rgb_variance": float(ref["rgb_map"].var()), "ref_acc_mean": float(ref["acc_map"].mean()),
+                         "modes": {}}
+                for prec in ("bf16", "fp32_split", "fp32"):
+                    for m in cm:
+                        m.precision = prec
+                    with torch.no_grad():
+                        o = rr.render_rays(batch.to(dev), cm[0], cm[1])
+                    d = o["rgb_map"].cpu().double() - ref["rgb_map"].double()
+                    mse = float((d ** 2).mean())
+                    check["modes"][prec] = {"psnr_db": (-10.0 * math.log10(mse)) if mse > 0 else None,
+                                            "max_abs_rgb": float(d.abs().max()),
+                                            "max_abs_acc": float((o["acc_map"].cpu().double() - ref["acc_map"].double()).abs().max())}
+                cpu["check"] = check
+            out["cpu_baseline"] = cpu
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -62,3 +62,24 @@ def test_more_rccl_ranks_than_gpus_is_refused_before_any_collective():
     p = run_bench({}, "--gpus", "2", "--steps", "1", "--warmup", "0")
     assert p.returncode != 0 and p.stdout.strip() == ""
     assert "2 ranks over RCCL need 2 GPUs, 1 visible" in p.stderr
+
+
+def test_default_line_carries_the_roofline_the_cpu_baseline_and_a_meaningful_psnr_check():
+    """`python bench.py` as the driver runs it at N = 1 (short: 3 steps, no sub-records): one JSON line with the contract's
+    keys, `roofline` and `cpu_baseline`; and `cpu_baseline.check` -- the metric's "PSNR vs ref" -- on weights whose field has
+    content (an all-white view would score infinity whatever the kernels do): fp32-class modes above 50 dB against the CPU
+    image, bf16 above 33 dB."""
+    p = run_bench({}, "--steps", "3", "--warmup", "1", "--no-subrecords")
+    line = result_line(p)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["dtype"] == "bf16" and line["value"] > 1e6
+    rf = line["roofline"]
+    assert rf["bound"] == "mfma" and 0.3 < rf["frac"] < 1.0 and rf["launches"] == 30
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 50 and cb["cores"] >= 1 and "sample" in cb
+    chk = cb["check"]
+    assert chk["rays"] == 4096 and chk["ref_rgb_variance"] > 1e-2, chk
+    m = chk["modes"]
+    assert m["fp32"]["psnr_db"] > 50 and m["fp32_split"]["psnr_db"] > 50 and m["bf16"]["psnr_db"] > 33, m
