@@ -60,7 +60,7 @@ def draw_case(i):
     return cfg, arch, (H, W, K, c2w, idx), seeds, use_pytest
 
 
-@pytest.mark.parametrize("i", range(48 * SCALE))
+@pytest.mark.parametrize("i", range(24 * SCALE))
 @pytest.mark.parametrize("precision", ["fp32", "fp32_split"])
 def test_random_configuration_against_the_oracle(dev, i, precision):
     if precision == "fp32_split" and i % 2:
@@ -73,7 +73,7 @@ def test_random_configuration_against_the_oracle(dev, i, precision):
                                                    rays=int(batch.shape[0]), multires=arch["multires"]))
 
 
-@pytest.mark.parametrize("i", range(48 * SCALE))
+@pytest.mark.parametrize("i", range(24 * SCALE))
 def test_random_configuration_bf16_invariants(dev, i):
     _, render_utils, _ = P.amd()
     cfg, arch, (H, W, K, c2w, idx), seeds, use_pytest = draw_case(i)
