@@ -1,8 +1,9 @@
 #!/bin/bash
 # The randomised sweeps of tests/test_gpu_fuzz.py at ten times (or $1 times) the suite's case count, on the GPU box:
-#   bash tests/run_fuzz_sweep.sh [scale] -> gpurun_out/fuzz_sweep.log, gpurun_out/fuzz_sweep_summary.json
+#   bash tests/run_fuzz_sweep.sh [scale] [seed family] -> gpurun_out/fuzz_sweep.log, gpurun_out/fuzz_sweep_summary.json
 # (lives under tests/ because it drives the oracle; nothing here is part of the product)
 SCALE=${1:-10}
+export NERF_AMD_FUZZ_SEED=${2:-0}
 mkdir -p gpurun_out
 NERF_AMD_FUZZ_SCALE=$SCALE NERF_AMD_QUIET=1 python -m pytest tests/test_gpu_fuzz.py -q -m gpu -p no:cacheprovider \
     --junitxml=gpurun_out/fuzz_sweep.xml > gpurun_out/fuzz_sweep.log 2>&1
@@ -30,7 +31,8 @@ for f in glob.glob("gpurun_out/parity_fuzz_*.json"):
     w["cases"] += 1
     for k in ("raw_max", "rgb_max", "z_well_max", "z_max"):
         w[k] = max(w[k], float(v.get(k, 0.0)))
-out = {"tests": int(suite.get("tests")), "failures": int(suite.get("failures")) + int(suite.get("errors")),
+import os
+out = {"family": int(os.environ.get("NERF_AMD_FUZZ_SEED", "0")), "tests": int(suite.get("tests")), "failures": int(suite.get("failures")) + int(suite.get("errors")),
        "skipped": int(suite.get("skipped")), "seconds": float(suite.get("time")), "per_sweep": per,
        "staged_worst_over_all_cases": worst}
 for d in per.values():
