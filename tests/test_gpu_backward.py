@@ -88,6 +88,20 @@ class _RoundBf16(torch.autograd.Function):
         return g
 
 
+class _RoundGradBf16(torch.autograd.Function):
+    """Identity in the forward, the incoming gradient rounded to bf16 in the backward: dL/draw enters the kernels'
+    backward chain as a bf16 MFMA operand (the dX chain and the head products, bias columns included), so a head's bias
+    gradient is the sum of ROUNDED terms -- which matters exactly when that sum cancels (a scalar like alpha_linear.bias)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
+
+
 def bf16_field(sd, pts, vd, Lx=10, Ld=4):
     """NeRF.MLP (nerf.py:110-134) with the kernel's roundings: weights, encodings and
     every hidden activation rounded to bf16, fp32 accumulation, fp32 bias/ReLU.  Differentiable.
@@ -101,13 +115,13 @@ def bf16_field(sd, pts, vd, Lx=10, Ld=4):
         if i == 4:
             h = torch.cat([e, h], -1)
     if vd is None:
-        out = lin("output_linear", h)
+        out = _RoundGradBf16.apply(lin("output_linear", h))
         return out.reshape(list(pts.shape[:-1]) + [out.shape[-1]])
     d = rb(O.embed(vd[:, None].expand(pts.shape).reshape(-1, 3), Ld))
     sigma = lin("alpha_linear", h)
     feat = rb(lin("feature_linear", h))
     hv = rb(torch.relu(lin("views_linears.0", torch.cat([feat, d], -1))))
-    return torch.cat([lin("rgb_linear", hv), sigma], -1).reshape(list(pts.shape[:-1]) + [4])
+    return _RoundGradBf16.apply(torch.cat([lin("rgb_linear", hv), sigma], -1)).reshape(list(pts.shape[:-1]) + [4])
 
 
 NOVD = dict(D=8, W=256, output_ch=5, skips=[4], use_viewdirs=False, multires=10, multires_views=4)   # create_nerf_models without --use_viewdirs
