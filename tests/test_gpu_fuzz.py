@@ -515,13 +515,13 @@ def test_random_calls_of_render(dev, i):
     if two_pass:
         for k in ("rgb0", "acc0"):
             P.close(out[3][k], ref[3][k], atol=2e-4, rtol=2e-4)
-        P.close_disp(out[3]["disp0"], ref[3]["disp0"], ref[3]["acc0"], cfg["N_samples"], atol=2e-4, rtol=2e-4, raw_tol=2e-4)
+        P.close_disp(out[3]["disp0"], ref[3]["disp0"], ref[3]["acc0"], cfg["N_samples"], atol=2e-4, rtol=2e-4, raw_tol=2e-4, far=cfg["far"])
         P.close_frac(out[0], ref[0], atol=2e-4, frac=0.85)
         P.close_frac(out[2], ref[2], atol=2e-4, frac=0.85)
     else:
         P.close(out[0], ref[0], atol=2e-4, rtol=2e-4)
         P.close(out[2], ref[2], atol=2e-4, rtol=2e-4)
-        P.close_disp(out[1], ref[1], ref[2], cfg["N_samples"], atol=2e-4, rtol=2e-4, raw_tol=2e-4)
+        P.close_disp(out[1], ref[1], ref[2], cfg["N_samples"], atol=2e-4, rtol=2e-4, raw_tol=2e-4, far=cfg["far"])
         if retraw:
             P.close(out[3]["raw"], ref[3]["raw"], atol=2e-4, rtol=2e-4)
 

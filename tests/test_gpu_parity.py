@@ -78,17 +78,21 @@ def close_frac(a, b, atol, rtol=0.0, frac=0.97, mask=None):
     assert ok.size == 0 or ok.mean() >= frac, "only %.4f of elements within tolerance (need %.2f)" % (ok.mean(), frac)
 
 
-def close_disp(a, b, acc, n_samples, atol, rtol, raw_tol=0.0):
+def close_disp(a, b, acc, n_samples, atol, rtol, raw_tol=0.0, far=None):
     """disp = 1 / max(1e-10, depth / acc) (render_utils.py:284) is a ratio of two sums of the same weights, and every
     weight carries the absolute error of 1 - exp(-x) near x = 0 (an ulp of 1.0, whatever libm or the device computes): the
     ratio's relative error is about 2 * n_samples * eps / acc.  For an opaque ray that is nothing; for a nearly empty one
     (acc 1e-3) it is percents -- in the reference too.  Tolerance = the stage's own + that conditioning term.
     raw_tol: when the two sides composite DIFFERENT raw values (end-to-end comparisons: the field outputs agree to
-    raw_tol), the weights move by about raw_tol in absolute terms and the ratio by raw_tol / acc."""
+    raw_tol), the weights move by about raw_tol in absolute terms and the ratio by raw_tol / acc.  far: the largest depth --
+    the depth sum's absolute error is that of the weights times up to `far`, so a ray whose mass sits at tiny depths (NDC:
+    disp in the thousands) carries far * disp / acc of relative error on top."""
     a, b, acc = (t.detach().cpu().double().numpy() if isinstance(t, torch.Tensor) else np.asarray(t, np.float64) for t in (a, b, acc))
     assert (np.isnan(a) == np.isnan(b)).all()
     ok = ~np.isnan(b)
     cond = (4.0 * n_samples * 1.2e-7 + raw_tol) / np.maximum(np.abs(acc[ok]), 1e-30)
+    if far is not None:
+        cond = cond * (1.0 + far * np.abs(b[ok]))
     tol = atol + np.abs(b[ok]) * (rtol + cond)
     bad = np.abs(a[ok] - b[ok]) > tol
     assert not bad.any(), ("disp", int(bad.sum()), float(np.abs(a[ok] - b[ok])[bad].max()), float(acc[ok][bad].min()))
@@ -601,7 +605,7 @@ def staged_check(dev, cfg, arch, batch, seeds, use_pytest, label, precision="fp3
     ref0 = O.render_rays(O.RenderCfg(**cfg0), batch, coarse_cpu, None, retraw=True, retweights=True, pytest=use_pytest)
     for k in ref0:
         if k == "disp_map":
-            close_disp(out0[k], ref0[k], ref0["acc_map"], Nc, atol=G5_TOL[k], rtol=2e-4, raw_tol=G5_TOL["raw"])
+            close_disp(out0[k], ref0[k], ref0["acc_map"], Nc, atol=G5_TOL[k], rtol=2e-4, raw_tol=G5_TOL["raw"], far=cfg["far"])
         else:
             close(out0[k], ref0[k], atol=G5_TOL[k], rtol=2e-4)
     for k0, k in (("rgb_map", "rgb0"), ("disp_map", "disp0"), ("acc_map", "acc0")):
@@ -617,7 +621,8 @@ def staged_check(dev, cfg, arch, batch, seeds, use_pytest, label, precision="fp3
     well_sorted = np.take_along_axis(np.concatenate([np.ones((R, Nc), bool), well], -1), order.numpy(), -1)
     dz = np.abs(out["z_vals"].numpy() - z_ref.numpy())
     span = float(cfg["far"] - cfg["near"]) if not cfg["ndc"] else 1.0
-    assert (dz[well_sorted] < 5e-6 * span).mean() > 0.999, (label, (dz[well_sorted] < 5e-6 * span).mean())
+    n_off = int((dz[well_sorted] >= 5e-6 * span).sum())      # (a few may sit at the end of an empty bin: see the bound below)
+    assert n_off <= max(3, int(1e-3 * well_sorted.sum())), (label, n_off, int(well_sorted.sum()))
     # The loose bound for everything else.  Where the bin mass is tiny the reference's own formula is discontinuous:
     # `denom < 1e-5 -> 1` (utils.py:110) flips on the last bit of a cumsum difference -- an empty bin of an opaque ray has
     # pdf = 1e-5 / (sum w + 62e-5), right at the threshold -- and moves the sample from the bin's edge to anywhere inside
