@@ -103,7 +103,8 @@ def test_random_configuration_bf16_invariants(dev, i):
     # sign switches that sample fully on or off -- DESIGN.md section 5 counts those rays on whole frames)
     gate = 1e-2 if seeds[2] == 1.0 else 5e-2
     d = (ref["rgb_map"] - got["rgb_map"]).abs()
-    assert float((d < gate).float().mean()) >= 0.97, (float(d.max()), float(d.mean()))
+    off_rays = int((d >= gate).any(-1).sum())
+    assert off_rays <= max(1, int(0.03 * d.shape[0])), (off_rays, d.shape[0], float(d.max()), float(d.mean()))
     assert float(d.median()) < (2e-3 if seeds[2] == 1.0 else 2e-2), float(d.median())   # the golden table's median gates
 
 
@@ -214,7 +215,7 @@ def test_random_single_pass_training_gradients(dev, monkeypatch, i):
     rgb_k = B.O.raw2outputs(raw_k, out["z_vals"].detach().cpu(), batch[:, 3:6], cfg["white_bkgd"], noise)[0]
     ((rgb_k - target) ** 2).mean().backward()
     g_k = raw_k.grad.to(torch.bfloat16).float().reshape(-1, raw_k.shape[-1]).sum(0)
-    g_norm = float(raw_k.grad[..., 3].norm())
+    g_norm, g_max = float(raw_k.grad[..., 3].norm()), float(raw_k.grad[..., 3].abs().max())
     sig = -1 if arch["use_viewdirs"] else 3
     worst, table = 0.0, []
     for name, p in m.named_parameters():
@@ -230,7 +231,9 @@ def test_random_single_pass_training_gradients(dev, monkeypatch, i):
         if name == head:
             # the density entry against its own referee (above), the other channels' entries as a vector like any tensor
             d = abs(float(g[sig]) - float(g_k[3]))
-            assert d <= 2e-2 * abs(float(g_k[3])) + 2.0 ** -11 * g_norm, (name, float(g[sig]), float(g_k[3]), float(ref[sig]), g_norm, cfg)
+            # (+ one term rounding to the other bf16 neighbour: the two evaluations of dL/draw differ in their last fp32 bits)
+            assert d <= 2e-2 * abs(float(g_k[3])) + 2.0 ** -11 * g_norm + 2.0 ** -8 * g_max, \
+                (name, float(g[sig]), float(g_k[3]), float(ref[sig]), g_norm, g_max, cfg)
             if g.numel() > 1:
                 keep = [j for j in range(g.numel()) if j != sig % g.numel()]
                 worst = max(worst, B.rel_err(g[keep], ref[keep]))
@@ -526,7 +529,8 @@ def test_random_calls_of_render(dev, i):
         P.close(out[2], ref[2], atol=2e-4, rtol=2e-4)
         P.close_disp(out[1], ref[1], ref[2], cfg["N_samples"], atol=2e-4, rtol=2e-4, raw_tol=2e-4, far=cfg["far"])
         if retraw:
-            P.close(out[3]["raw"], ref[3]["raw"], atol=2e-4, rtol=2e-4)
+            # (a raw value near zero in a field whose outputs reach +-100 is a sum of terms that size: its absolute error follows them)
+            P.close(out[3]["raw"], ref[3]["raw"], atol=2e-4 * max(1.0, float(ref[3]["raw"].abs().max()) / 10.0), rtol=2e-4)
 
 
 @pytest.mark.parametrize("i", range(10 * SCALE))
