@@ -231,20 +231,33 @@ def test_gather_rows_gloo_world2(tmp_path):
     assert codes == [0, 0]
 
 
+def device_isa(stem, tmp_path):
+    """Device assembly of csrc/<stem>.hip: the file the library build left beside the object (csrc/Makefile, -save-temps) when
+    it is newer than the source and every header, else a fresh `hipcc -S` (minutes for the field kernel)."""
+    import shutil
+    csrc = os.path.join(REPO, "nerf_shared_amd", "csrc")
+    src = os.path.join(csrc, stem + ".hip")
+    kept = os.path.join(csrc, "build", stem + "-hip-amdgcn-amd-amdhsa-gfx950.s")
+    deps = [src, os.path.join(csrc, "Makefile")] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")] + \
+           [os.path.join(REPO, "include", "nerf_amd.h")]
+    if os.path.exists(kept) and os.path.getmtime(kept) >= max(os.path.getmtime(d) for d in deps):
+        return kept
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    asm = str(tmp_path / (stem + ".s"))
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", src, "-o", asm],
+                   check=True, capture_output=True, timeout=900)
+    return asm
+
+
 def test_backward_kernel_vmcnt_ledger_matches_its_isa(tmp_path):
     """The dX-chain kernel's ring syncs count compiler-issued stores into their vmcnt waits
     (csrc/pipeline.h LEDGER).  Replay the compiled instruction stream and check that no sync
     publishes a weight block whose DMA could still be in flight."""
-    import shutil
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        pytest.skip("hipcc not available")
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import check_vmcnt
-    src = os.path.join(REPO, "nerf_shared_amd", "csrc", "mlp_bwd_s16.hip")
-    asm = str(tmp_path / "bwd.s")
-    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", src, "-o", asm],
-                   check=True, capture_output=True, timeout=600)
+    asm = device_isa("mlp_bwd_s16", tmp_path)
     # one instantiation per supported encoding pair; fragments = LayoutB<KE, KD>::F_END, 16 per ring block
     for tag, frags in (("mlp_bwd_s16_kernelILi10ELi4E", 1184), ("mlp_bwd_s16_kernelILi15ELi6E", 1224)):
         stats = check_vmcnt.check(asm, tag, verbose=False)
@@ -259,16 +272,9 @@ def test_field_kernel_keeps_its_weight_read_ahead(tmp_path):
     The machine scheduler once sank half of those reads back to their first use (38 % with zero MFMAs in between),
     which no test of the RESULTS can see; csrc pins them with scheduling groups (mlp_bf16_s16.hip sched_step).  Check the
     compiled ISA of the default inference kernel: nearly every fragment read is issued >= 4 MFMAs before its MFMA."""
-    import shutil
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        pytest.skip("hipcc not available")
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import isa_readahead
-    src = os.path.join(REPO, "nerf_shared_amd", "csrc", "mlp_bf16_s16.hip")
-    asm = str(tmp_path / "s16.s")
-    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", src, "-o", asm],
-                   check=True, capture_output=True, timeout=900)
+    asm = device_isa("mlp_bf16_s16", tmp_path)
     for tag, n_mfma in (("mlp_bf16_s16p_kernelILi10ELi4ELb1E", 2344),):
         hist = isa_readahead.main(asm, tag)
         total = sum(hist.values())
