@@ -622,7 +622,7 @@ def staged_check(dev, cfg, arch, batch, seeds, use_pytest, label, precision="fp3
     dz = np.abs(out["z_vals"].numpy() - z_ref.numpy())
     span = float(cfg["far"] - cfg["near"]) if not cfg["ndc"] else 1.0
     n_off = int((dz[well_sorted] >= 5e-6 * span).sum())      # (a few may sit at the end of an empty bin: see the bound below)
-    assert n_off <= max(3, int(2e-3 * well_sorted.sum())), (label, n_off, int(well_sorted.sum()))   # (a displaced sample shifts the rank of every depth it passes)
+    assert n_off <= max(6, int(3e-3 * well_sorted.sum())), (label, n_off, int(well_sorted.sum()))   # (a displaced sample shifts the rank of every depth it passes)
     # The loose bound for everything else.  Where the bin mass is tiny the reference's own formula is discontinuous:
     # `denom < 1e-5 -> 1` (utils.py:110) flips on the last bit of a cumsum difference -- an empty bin of an opaque ray has
     # pdf = 1e-5 / (sum w + 62e-5), right at the threshold -- and moves the sample from the bin's edge to anywhere inside
