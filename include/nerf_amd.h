@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NERF_AMD_ABI_VERSION 5
+#define NERF_AMD_ABI_VERSION 6
 
 #define NERF_AMD_OK            0
 #define NERF_AMD_EINVAL       -1   /* bad argument / unsupported shape        */
@@ -99,7 +99,8 @@ int  nerf_amd_model_out_ch(const nerf_amd_model *m);       /* 4 with viewdirs, e
  * CPU tests check the fragment layout without a GPU).  Weights/biases are HOST
  * pointers here.  `stream_out` receives n_frags*512 uint16 (bf16 bits) and
  * `bias_out` the fp32 bias table; pass NULL to query sizes only. */
-int  nerf_amd_pack_bf16_host(const nerf_amd_arch *arch, int shape /* 32: 32x32x16 stream, 16: 16x16x32 stream */,
+int  nerf_amd_pack_bf16_host(const nerf_amd_arch *arch, int shape /* 32: 32x32x16 stream, 16: 16x16x32 stream, 17: transposed
+                                (backward) stream, 18 / 19: the split-precision forward / transposed streams (fp16 hi, lo fragments) */,
                              const float *const *weights,
                              const float *const *biases, int n_tensors,
                              uint16_t *stream_out, int64_t *n_frags, float *bias_out, int64_t *n_bias);
@@ -166,19 +167,24 @@ int nerf_amd_raw2outputs_backward(const float *raw, int32_t raw_ch, const float 
  * reference ships), or without view branch (the output_linear models of nerf.py:91-94,131-132 -- the default
  * use_viewdirs=False of config_parser.py:50 -- multires 10 or 15, output_ch <= 16: raw / g_raw are [P, output_ch],
  * rays are [R,8], viewdirs NULL); gradients of the parameters,
- * of the points / rays (through the positional encoding) and of the view directions; bf16 operands /
- * fp32 accumulation.
- *   forward_train : the fused bf16 forward (explicit pts + viewdirs, or rays + z_vals with pts = o + d z) that also saves every
+ * of the points / rays (through the positional encoding) and of the view directions.
+ * `precision` (the same value in the three calls of one evaluation):
+ *   NERF_AMD_PREC_BF16        bf16 operands / fp32 accumulation (the fast default)
+ *   NERF_AMD_PREC_FP32_SPLIT  the reference's arithmetic class: every operand of the forward, of the dX chain and of the
+ *                             weight-gradient products an fp16 (hi, lo) pair, three MFMAs per product, fp32 accumulation;
+ *                             dL/draw is scaled by a power of two taken from its own maximum (csrc/split.h) and the scale
+ *                             comes off exactly at the end.  Gradients agree with fp32 autograd to ~1e-6 relative.
+ *   forward_train : the fused forward (explicit pts + viewdirs, or rays + z_vals with pts = o + d z) that also saves every
  *                   layer's activations in `workspace` (nerf_amd_train_workspace bytes, 256-B aligned)
  *   backward      : dL/draw [P,4] -> gradients of every nn.Linear weight [out,in] and bias [out]
  *                   (fp32 device tensors in nerf_amd_model_update order, overwritten)
  * ------------------------------------------------------------------------ */
-int     nerf_amd_model_supports_training(const nerf_amd_model *m);
-int64_t nerf_amd_train_workspace(const nerf_amd_model *m, int64_t n_points);
+int     nerf_amd_model_supports_training(const nerf_amd_model *m, int precision);
+int64_t nerf_amd_train_workspace(const nerf_amd_model *m, int64_t n_points, int precision);
 int     nerf_amd_field_forward_train(const nerf_amd_model *m, const float *pts /* [R*S,3] or NULL */,
                                      const float *viewdirs /* [R,3], with pts */, const float *rays /* [R,11|8], without pts */,
                                      int32_t ray_ch, const float *z_vals, int64_t R, int32_t S, float *raw,
-                                     void *workspace, int64_t workspace_bytes, void *stream);
+                                     void *workspace, int64_t workspace_bytes, int precision, void *stream);
 int     nerf_amd_field_backward(const nerf_amd_model *m, const float *g_raw /* [R*S,4|output_ch] */,
                                 const float *pts, const float *viewdirs, const float *rays, int32_t ray_ch,
                                 const float *z_vals, int64_t R, int32_t S /* the forward_train inputs */,
@@ -186,7 +192,7 @@ int     nerf_amd_field_backward(const nerf_amd_model *m, const float *g_raw /* [
                                 float *const *grad_biases, int n_tensors,
                                 float *g_pts /* [R*S,3] overwritten, pts mode, or NULL */,
                                 float *g_rays /* [R,6] dL/d(o,d), accumulated (pass zeros), rays mode, or NULL */,
-                                float *g_viewdirs /* [R,3] accumulated (pass zeros), or NULL */, void *stream);
+                                float *g_viewdirs /* [R,3] accumulated (pass zeros), or NULL */, int precision, void *stream);
 
 /* ------------------------------------------------------------------------
  * a11  utils.sample_pdf                       utils.py:74-117

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NERF_AMD_LIB selects another build of the same library (diagnostic builds such as -DNERF_AMD_STAMPS)
 LIB_PATH = os.environ.get("NERF_AMD_LIB") or os.path.join(_HERE, "libnerf_amd.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 PREC_FP32, PREC_BF16, PREC_FP32_SPLIT = 0, 1, 2
 MAX_SKIPS = 8
 
@@ -94,12 +94,12 @@ def _load():
         "nerf_amd_coarse_z": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_int, c_int, c_void_p, c_void_p]),
         "nerf_amd_resample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p,
                                       c_void_p]),
-        "nerf_amd_model_supports_training": (c_int, [c_void_p]),
-        "nerf_amd_train_workspace": (c_int64, [c_void_p, c_int64]),
+        "nerf_amd_model_supports_training": (c_int, [c_void_p, c_int]),
+        "nerf_amd_train_workspace": (c_int64, [c_void_p, c_int64, c_int]),
         "nerf_amd_field_forward_train": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32,
-                                                 c_void_p, c_void_p, c_int64, c_void_p]),
+                                                 c_void_p, c_void_p, c_int64, c_int, c_void_p]),
         "nerf_amd_field_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32,
-                                            c_void_p, c_int64, pp_f, pp_f, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                            c_void_p, c_int64, pp_f, pp_f, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
         "nerf_amd_get_rays_backward": (c_int, [c_int32, c_int32, POINTER(c_double), c_int64, c_int64, c_void_p, c_void_p,
                                                c_void_p, c_void_p]),
         "nerf_amd_to8b": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),

@@ -13,7 +13,9 @@
 
 #include "kernels.h"
 #include "launch_util.h"
+#include "pipeline.h"
 #include "program.h"
+#include "split.h"
 
 #include <utility>
 
@@ -32,10 +34,8 @@ __device__ __forceinline__ int slot_to_feature(int kind, int s, int L) {
     return kind == PERM_ACC ? acc16_col(ks, q, j) : gen16_col(ks, q, j, L);
 }
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 struct DwArgs {
@@ -44,6 +44,8 @@ struct DwArgs {
     int64_t P;
     float *slab;                         // per-workgroup partial results: [grid][OT*IT*256 + OT*16 (+ IT*256 + 16 with a head)] fp32
     const uint16_t *H;                   // head gradients transposed inside 32-point chunks (kernels.h g_rawt), or NULL
+    // split-precision products (dw2s_body): the planes of fp16 lo rows of G, X and H (the pointers above are the hi planes)
+    const uint16_t *G_lo, *X_lo, *H_lo;
 };
 
 struct DwReduceArgs {
@@ -56,11 +58,13 @@ struct DwReduceArgs {
     int HT;                              // 0 or 1
     float *head_dW, *head_db;
     int head_row0, head_rows, head_ld;
+    const float *inv_scale;              // split precision: 1 / loss scale (a device scalar, split.h), or NULL
 };
 __host__ __device__ inline int dw_slab_floats(int OT, int IT, int HT) { return OT * IT * 256 + OT * 16 + HT * (IT * 256 + 16); }
 
 // Element e of a job's summed slabs -> its place in the nn.Linear gradients.
 __device__ __forceinline__ void dw_scatter(const DwReduceArgs &a, int e, float acc) {
+    if (a.inv_scale) acc *= *a.inv_scale;        // a power of two: exact
     const int n_main = a.OT * a.IT * 256;
     if (e < n_main) {
         const int r = e & 3, lane = (e >> 2) & 63, tile = e >> 8;
@@ -505,6 +509,293 @@ __device__ __forceinline__ void dw_head_body(const DwArgs &a, const int wg, cons
     if (wave == 0 && (lane & 15) == 0) *reinterpret_cast<f32x4 *>(slab + IT * 256 + 4 * (lane >> 4)) = accb;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Split-precision weight gradients (NERF_AMD_PREC_FP32_SPLIT, split.h): G and X arrive as planes of fp16 hi rows and fp16
+// lo rows (lo = residual x 2^11), exactly as the training forward and the dX chain hold them.  dW = G^T X keeps ONE
+// accumulator per tile:
+//     acc += G_hi X_hi  +  (2^-11 G_hi) X_lo  +  G_lo (2^-11 X_hi)
+// where the two rescaled hi operands are made in registers (one packed fp16 multiply per register; where that product
+// falls below fp16's normal range it loses bits of a term that is itself 2^-11 of the sum -- measured on the CPU before
+// this was written, tools/experiments/split_bwd_sim.py "dW sym": 1e-6 of fp32 autograd at the loss scale split.h picks,
+// 1.6e-4 even when it is 2^14 off).  Bias gradients: G_hi . 1 + G_lo . 2^-11.  The chunk image is twice the bf16 one
+// (64 KiB for a 256 x 256 product), so the ring holds two chunks: one in flight while one is consumed.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int DW2S_NS(int OT, int IT) {
+    const int n = (128 * 1024) / (2 * 32 * 32 * (OT + IT));
+    return n < 2 ? 2 : (n > 12 ? 12 : n);
+}
+#define MFMA_F16(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x32_f16(a_, b_, c_, 0, 0, 0)
+
+template <int OT, int IT, int WO, int WI, bool HEAD = false>
+__device__ __forceinline__ void dw2s_body(const DwArgs &a, const int wg, const int nwg) {
+    static_assert(WO * WI == 8 && OT % WO == 0 && IT % WI == 0 && OT >= 4 && IT >= 2, "bad shape");
+    constexpr int TO = OT / WO, TI = IT / WI;
+    static_assert(!HEAD || TI == 2 * WO, "the head's X tiles are dealt two to a wave");
+    constexpr int RG = OT * 32, RX = IT * 32;                   // row bytes of one plane (unpadded)
+    constexpr int PG = OT * 2, PX = IT * 2;                     // 16-byte pieces per row
+    constexpr int IMG_G = 32 * RG, IMG_X = 32 * RX;             // one plane of one chunk
+    constexpr int IMG_GX = 2 * (IMG_G + IMG_X);                 // G_hi, G_lo, X_hi, X_lo
+    constexpr int IMG = IMG_GX + (HEAD ? 2048 : 0);             // + the head operand's two planes
+    constexpr int NI = 2 * (OT + IT), CNT = (NI + 7) / 8;       // 1-KiB DMA instructions per chunk; per wave (the last ones may repeat)
+    constexpr int NS = DW2S_NS(OT, IT);
+    static_assert((NS - 2) * (CNT + (HEAD ? 2 : 0)) <= 63, "vmcnt field is 6 bits");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wo = wave / WI, wi = wave % WI;
+    const uint32_t ring = (uint32_t)(uintptr_t)smem;
+
+    const int64_t n_chunks = (a.P + 31) / 32;
+    const int64_t n_local = wg < n_chunks ? (n_chunks - wg + nwg - 1) / nwg : 0;     // chunks wg, wg + nwg, ...
+    // The ring DMA as buffer_load ... lds: a buffer resource per plane (scalar), ONE per-lane 32-bit offset per piece that
+    // does not depend on the chunk (row inside the chunk x row bytes + swizzled position), the chunk as the scalar offset --
+    // no 64-bit per-lane address arithmetic inside the loop, and rows past the arrays' end read as zero instead of needing a
+    // clamp.  This wave's pieces of a chunk: j = wave, wave + 8, ... of the NI pieces G_hi | G_lo | X_hi | X_lo (indices past NI
+    // repeat the last one: every wave issues exactly CNT, which keeps the counted waits compile-time constants).
+    typedef __attribute__((ext_vector_type(4))) unsigned rsrc_t;
+    const unsigned g_bytes = (unsigned)(pad_points(a.P) * a.ldg * 2), x_bytes = (unsigned)(pad_points(a.P) * a.ldx * 2);
+    const rsrc_t rs_plane[4] = {make_rsrc(a.G, g_bytes), make_rsrc(a.G_lo, g_bytes), make_rsrc(a.X, x_bytes), make_rsrc(a.X_lo, x_bytes)};
+    unsigned voff[CNT], lds_off[CNT];
+    int plane[CNT];
+#pragma unroll
+    for (int k = 0; k < CNT; ++k) {
+        int j = wave + 8 * k;
+        if (j >= NI) j = NI - 1;
+        const bool is_g = j < 2 * OT;
+        const int jp = is_g ? j : j - 2 * OT;                   // piece inside the two planes of G (or of X)
+        const int n_pl = is_g ? OT : IT;                        // pieces per plane
+        const bool lo = jp >= n_pl;
+        const int jj = lo ? jp - n_pl : jp;
+        const int e = 64 * jj + lane;                           // 16-byte piece of the plane's image
+        const int rg = e / PG, posg = e % PG, rx = e / PX, posx = e % PX;
+        const unsigned vg = (unsigned)(rg * a.ldg * 2 + ((posg ^ dw_swz<PG>(rg)) << 4));
+        const unsigned vx = (unsigned)(rx * a.ldx * 2 + ((posx ^ dw_swz<PX>(rx)) << 4));
+        voff[k] = is_g ? vg : vx;
+        lds_off[k] = __builtin_amdgcn_readfirstlane((is_g ? 0 : 2 * IMG_G) + (lo ? (is_g ? IMG_G : IMG_X) : 0) + 1024 * jj);
+        plane[k] = __builtin_amdgcn_readfirstlane((is_g ? 0 : 2) + (lo ? 1 : 0));
+    }
+    rsrc_t rs_head[2];
+    unsigned voff_head = 0;
+    if constexpr (HEAD) {
+        rs_head[0] = make_rsrc(a.H, (unsigned)(n_chunks * 256));
+        rs_head[1] = make_rsrc(a.H_lo, (unsigned)(n_chunks * 256));
+        voff_head = ((lane >> 4) * 4 + (lane & 3)) * 16;        // lane (i, g) <- 16 bytes of (group g, column i & 3)
+    }
+    auto dma_buf = [&](unsigned vo, const rsrc_t &rs, unsigned so, uint32_t lds_base) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\t" "s_mov_b32 m0, %3\n\t" "s_nop 0\n\t" "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t" "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(vo), "s"(rs), "s"(lds_base), "s"(so) : "memory");
+    };
+    auto issue_chunk = [&](int64_t i) {
+        int64_t ch = wg + i * nwg;
+        if (ch >= n_chunks) ch = n_chunks - 1;                  // past the end: a harmless re-read that is never consumed
+        const uint32_t slot = ring + (uint32_t)(i % NS) * IMG;
+        const unsigned so_g = __builtin_amdgcn_readfirstlane((unsigned)(ch * 32 * a.ldg * 2));
+        const unsigned so_x = __builtin_amdgcn_readfirstlane((unsigned)(ch * 32 * a.ldx * 2));
+#pragma unroll
+        for (int k = 0; k < CNT; ++k) {
+            const int pl = plane[k];
+            const rsrc_t rs = pl == 0 ? rs_plane[0] : pl == 1 ? rs_plane[1] : pl == 2 ? rs_plane[2] : rs_plane[3];
+            dma_buf(voff[k], rs, pl < 2 ? so_g : so_x, __builtin_amdgcn_readfirstlane(slot + lds_off[k]));
+        }
+        if constexpr (HEAD) {
+            if (wave == 0) {                                    // the chunk's head operand, both planes
+                const unsigned so_h = __builtin_amdgcn_readfirstlane((unsigned)(ch * 256));
+                dma_buf(voff_head, rs_head[0], so_h, __builtin_amdgcn_readfirstlane(slot + IMG_GX));
+                dma_buf(voff_head, rs_head[1], so_h, __builtin_amdgcn_readfirstlane(slot + IMG_GX + 1024));
+            }
+        }
+    };
+
+    f32x4 acc[TO][TI], accb[TO];
+    f32x4 acch[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, acchb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int x = 0; x < TO; ++x) {
+        accb[x] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int y = 0; y < TI; ++y) acc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    f16x8 ones, ones_s;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ones[j] = (_Float16)1.0f; ones_s[j] = (_Float16)SPLIT_INV; }
+    const _Float16 kinv = (_Float16)SPLIT_INV;
+    using PGc = std::integral_constant<int, PG>;
+    using PXc = std::integral_constant<int, PX>;
+
+    if (n_local > 0) {
+#pragma unroll
+        for (int i = 0; i < NS - 1; ++i) issue_chunk(i);
+        for (int64_t i = 0; i < n_local; ++i) {
+            // chunk i has landed (this wave's pieces; younger chunks stay in flight), everyone agrees, then the slot of
+            // chunk i-1 -- which every wave finished reading before it came here -- is refilled with chunk i+NS-1
+            if (HEAD && wave == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * (CNT + 2)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * CNT) : "memory");
+            issue_chunk(i + NS - 1);
+            const uint32_t g_hi = ring + (uint32_t)(i % NS) * IMG, g_lo = g_hi + IMG_G, x_hi = g_hi + 2 * IMG_G, x_lo = x_hi + IMG_X;
+            const int64_t ch = wg + i * nwg;
+            if (ch == n_chunks - 1 && (a.P & 31)) {             // the last chunk: rows past P hold the padding points' data
+                const int first = (int)(a.P & 31);
+                const int per_g = (32 - first) * PG, per_x = (32 - first) * PX;     // 16-byte pieces to clear per plane
+                for (int e = tid; e < 2 * (per_g + per_x); e += 512) {
+                    uint32_t off;
+                    if (e < per_g) off = g_hi + first * RG + e * 16;
+                    else if (e < 2 * per_g) off = g_lo + first * RG + (e - per_g) * 16;
+                    else if (e < 2 * per_g + per_x) off = x_hi + first * RX + (e - 2 * per_g) * 16;
+                    else off = x_lo + first * RX + (e - 2 * per_g - per_x) * 16;
+                    *(__attribute__((address_space(3))) u32x4 *)(uintptr_t)off = (u32x4){0u, 0u, 0u, 0u};
+                }
+                __syncthreads();
+            }
+            // (an opaque copy of the lane id per chunk: otherwise the 24 swizzled operand addresses of the body are loop
+            // invariants, get hoisted and spill)
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));
+            auto frag = [&](auto pieces_, uint32_t img, int col0) {
+                return __builtin_bit_cast(f16x8, tr_frag_swz<decltype(pieces_)::value>(img, col0, lane_o));
+            };
+            f16x8 A[TO], Ah = {}, Ahs = {}, Al_h = {};
+            if constexpr (HEAD) {
+                typedef __attribute__((address_space(3))) const f16x8 lds_f16x8;
+                Ah = *(lds_f16x8 *)(uintptr_t)(g_hi + IMG_GX + lane * 16);
+                Al_h = *(lds_f16x8 *)(uintptr_t)(g_hi + IMG_GX + 1024 + lane * 16);
+                if ((lane & 15) >= 4) { Ah = f16x8{}; Al_h = f16x8{}; }     // rows 4..15 of the head tile do not exist
+                Ahs = Ah * kinv;
+            }
+            // Only the G-side operands stay in registers; the X-side fragments are re-read from LDS for every term (three
+            // transposing reads per X tile and chunk instead of two: LDS has the bandwidth, the register file has no room
+            // for TI more fragments beside the TO x TI accumulators).  Straight-line code: every wave computes the bias
+            // column and the head's bias column (only the waves that own them write them out).
+            // ---- hi x hi
+#pragma unroll
+            for (int x = 0; x < TO; ++x) {
+                A[x] = frag(PGc{}, g_hi, (wo * TO + x) * 16);
+                accb[x] = MFMA_F16(A[x], ones, accb[x]);
+            }
+            static_for_dw<TI>([&](auto y_) {
+                constexpr int y = y_;
+                const f16x8 bh = frag(PXc{}, x_hi, (wi * TI + y) * 16);
+#pragma unroll
+                for (int x = 0; x < TO; ++x) acc[x][y] = MFMA_F16(A[x], bh, acc[x][y]);
+            });
+            // ---- (2^-11 G_hi) x X_lo
+#pragma unroll
+            for (int x = 0; x < TO; ++x) A[x] = A[x] * kinv;
+            static_for_dw<TI>([&](auto y_) {
+                constexpr int y = y_;
+                const f16x8 bl = frag(PXc{}, x_lo, (wi * TI + y) * 16);
+#pragma unroll
+                for (int x = 0; x < TO; ++x) acc[x][y] = MFMA_F16(A[x], bl, acc[x][y]);
+            });
+            // ---- G_lo x (2^-11 X_hi)
+#pragma unroll
+            for (int x = 0; x < TO; ++x) {
+                A[x] = frag(PGc{}, g_lo, (wo * TO + x) * 16);
+                accb[x] = MFMA_F16(A[x], ones_s, accb[x]);
+            }
+            static_for_dw<TI>([&](auto y_) {
+                constexpr int y = y_;
+                const f16x8 bs = frag(PXc{}, x_hi, (wi * TI + y) * 16) * kinv;
+#pragma unroll
+                for (int x = 0; x < TO; ++x) acc[x][y] = MFMA_F16(A[x], bs, acc[x][y]);
+            });
+            if constexpr (HEAD) {                               // this wave's two X tiles of the head product: 2 wo, 2 wo + 1 of its TI
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int col = (wi * TI + 2 * wo + t) * 16;
+                    const f16x8 bh = frag(PXc{}, x_hi, col), bl = frag(PXc{}, x_lo, col);
+                    acch[t] = MFMA_F16(Ah, bh, acch[t]);
+                    acch[t] = MFMA_F16(Ahs, bl, acch[t]);
+                    acch[t] = MFMA_F16(Al_h, bh * kinv, acch[t]);
+                }
+                acchb = MFMA_F16(Ah, ones, acchb);
+                acchb = MFMA_F16(Al_h, ones_s, acchb);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the trailing re-reads: no DMA may outlive the workgroup
+    }
+    // ---- this workgroup's partial tile as a register dump, laid out exactly like dw2_body's
+    float *slab = a.slab + (int64_t)wg * dw_slab_floats(OT, IT, HEAD ? 1 : 0);
+#pragma unroll
+    for (int x = 0; x < TO; ++x)
+#pragma unroll
+        for (int y = 0; y < TI; ++y)
+            *reinterpret_cast<f32x4 *>(slab + (((wo * TO + x) * IT + (wi * TI + y)) * 64 + lane) * 4) = acc[x][y];
+    if (wi == 0 && (lane & 15) == 0) {
+#pragma unroll
+        for (int x = 0; x < TO; ++x)
+            *reinterpret_cast<f32x4 *>(slab + OT * IT * 256 + (wo * TO + x) * 16 + 4 * (lane >> 4)) = accb[x];
+    }
+    if constexpr (HEAD) {
+        float *hs = slab + OT * IT * 256 + OT * 16;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            *reinterpret_cast<f32x4 *>(hs + ((wi * TI + 2 * wo + t) * 64 + lane) * 4) = acch[t];
+        if (wave == 0 && (lane & 15) == 0) *reinterpret_cast<f32x4 *>(hs + IT * 256 + 4 * (lane >> 4)) = acchb;
+    }
+}
+
+// A head product alone in split precision (rgb_linear): the two planes of X rows + the head operand's two planes.
+template <int IT>
+__device__ __forceinline__ void dw_head_split_body(const DwArgs &a, const int wg, const int nwg) {
+    static_assert(IT == 8, "one 16-column X tile per wave");
+    constexpr int RX = IT * 32, PX = IT * 2, IMG_X = 32 * RX, IMG = 2 * IMG_X + 2048;
+    constexpr int NS = 7;                                       // 7 x 18 KiB
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t ring = (uint32_t)(uintptr_t)smem;
+    const int64_t n_chunks = (a.P + 31) / 32;
+    const int64_t n_local = wg < n_chunks ? (n_chunks - wg + nwg - 1) / nwg : 0;
+    auto issue_chunk = [&](int64_t i) {
+        int64_t ch = wg + i * nwg;
+        if (ch >= n_chunks) ch = n_chunks - 1;
+        const uint32_t slot = ring + (uint32_t)(i % NS) * IMG;
+        const int e = 64 * wave + lane;                         // 16-byte piece of a plane's X image: this wave's 1 KiB
+        const int r = e / PX, pos = e % PX;
+        int64_t p = ch * 32 + r;
+        if (p >= pad_points(a.P)) p = pad_points(a.P) - 1;
+        const int64_t off = (p * a.ldx) * 2 + ((pos ^ dw_swz<PX>(r)) << 4);
+        dma_piece(reinterpret_cast<const char *>(a.X) + off, slot + 1024 * wave);
+        dma_piece(reinterpret_cast<const char *>(a.X_lo) + off, slot + IMG_X + 1024 * wave);
+        if (wave == 0) {
+            const int64_t ho = ch * 256 + ((lane >> 4) * 4 + (lane & 3)) * 16;
+            dma_piece(reinterpret_cast<const char *>(a.H) + ho, slot + 2 * IMG_X);
+            dma_piece(reinterpret_cast<const char *>(a.H_lo) + ho, slot + 2 * IMG_X + 1024);
+        }
+    };
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
+    f16x8 ones, ones_s;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ones[j] = (_Float16)1.0f; ones_s[j] = (_Float16)SPLIT_INV; }
+    const _Float16 kinv = (_Float16)SPLIT_INV;
+    if (n_local > 0) {
+#pragma unroll
+        for (int i = 0; i < NS - 1; ++i) issue_chunk(i);
+        for (int64_t i = 0; i < n_local; ++i) {
+            if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * 4) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * 2) : "memory");
+            issue_chunk(i + NS - 1);
+            const uint32_t x_hi = ring + (uint32_t)(i % NS) * IMG, x_lo = x_hi + IMG_X;
+            typedef __attribute__((address_space(3))) const f16x8 lds_f16x8;
+            f16x8 Ah = *(lds_f16x8 *)(uintptr_t)(x_hi + 2 * IMG_X + lane * 16);
+            f16x8 Al = *(lds_f16x8 *)(uintptr_t)(x_hi + 2 * IMG_X + 1024 + lane * 16);
+            if ((lane & 15) >= 4) { Ah = f16x8{}; Al = f16x8{}; }
+            // rows past P of the last chunk hold the padding points' saved activations: finite, and their dL/draw is zero
+            const f16x8 Bh = __builtin_bit_cast(f16x8, tr_frag_swz<PX>(x_hi, wave * 16, lane));
+            const f16x8 Bl = __builtin_bit_cast(f16x8, tr_frag_swz<PX>(x_lo, wave * 16, lane));
+            acc = MFMA_F16(Ah, Bh, acc);
+            acc = MFMA_F16(Ah * kinv, Bl, acc);
+            acc = MFMA_F16(Al, Bh * kinv, acc);
+            if (wave == 0) { accb = MFMA_F16(Ah, ones, accb); accb = MFMA_F16(Al, ones_s, accb); }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    float *slab = a.slab + (int64_t)wg * dw_slab_floats(0, IT, 1);
+    *reinterpret_cast<f32x4 *>(slab + (wave * 64 + lane) * 4) = acc;
+    if (wave == 0 && (lane & 15) == 0) *reinterpret_cast<f32x4 *>(slab + IT * 256 + 4 * (lane >> 4)) = accb;
+}
+
 template <int OT, int IT, int WO, int WI>
 __global__ __launch_bounds__(512, 2) void dw2_kernel(DwArgs a) {
     dw2_body<OT, IT, WO, WI>(a, blockIdx.x, gridDim.x);
@@ -651,6 +942,79 @@ __global__ __launch_bounds__(512, 2) void dw_multi_kernel(DwMulti m) {
     }
 }
 
+// The same one launch for the split-precision products (dw2s_body): job shapes 0..5 as above, 6: <16,8,4,2> (the xyz
+// encoding of a multires-15 model, rows padded to 128 slots), 7: <8,4,8,1> (its view-direction encoding).
+__global__ __launch_bounds__(512, 2) void dw_multi_split_kernel(DwMulti m) {
+    int j = 0;
+    while (j + 1 < m.n && (int)blockIdx.x >= m.job[j + 1].first_block) ++j;
+    j = __builtin_amdgcn_readfirstlane(j);
+    const DwJob &J = m.job[j];
+    const int wg = (int)blockIdx.x - J.first_block;
+    switch (J.shape) {
+    case 0: dw2s_body<16, 16, 4, 2>(J.a, wg, J.n_blocks); break;
+    case 1: dw2s_body<8, 16, 4, 2>(J.a, wg, J.n_blocks); break;
+    case 2: dw2s_body<16, 4, 8, 1>(J.a, wg, J.n_blocks); break;
+    case 3: dw2s_body<8, 2, 8, 1>(J.a, wg, J.n_blocks); break;
+    case 4: dw2s_body<16, 16, 4, 2, true>(J.a, wg, J.n_blocks); break;
+    case 6: dw2s_body<16, 8, 4, 2>(J.a, wg, J.n_blocks); break;
+    case 7: dw2s_body<8, 4, 8, 1>(J.a, wg, J.n_blocks); break;
+    default: dw_head_split_body<8>(J.a, wg, J.n_blocks); break;
+    }
+}
+constexpr size_t dw_split_lds(int OT, int IT, bool head) { return (size_t)DW2S_NS(OT, IT) * (2 * 32 * 32 * (OT + IT) + (head ? 2048 : 0)); }
+
+// output_linear's weight gradient in split precision (models without view branch, nerf.py:131-132): G = NO <= 4 columns
+// of dL/draw itself (fp32, unscaled), X = the two planes of h8; fp32 FMA loops like dw_small_body.
+template <int NO>
+__global__ __launch_bounds__(256) void dw_small_split_kernel(const float *G, int ldg, int g_col0, const uint16_t *Xh, const uint16_t *Xl,
+                                                             int ldx, int n_in, int64_t P, float *slab) {
+    __shared__ float red[NO][256 + 1];
+    const int groups = n_in / 8, rows_par = 256 / groups;
+    const int cg = threadIdx.x % groups, ty = threadIdx.x / groups;
+    const int wg = blockIdx.x, nwg = gridDim.x;
+    float acc[NO][8], bs[NO];
+#pragma unroll
+    for (int k = 0; k < NO; ++k) {
+        bs[k] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
+    }
+    for (int64_t r0 = (int64_t)wg * 256; r0 < P; r0 += (int64_t)nwg * 256) {
+        const int64_t r1 = r0 + 256 < P ? r0 + 256 : P;
+#pragma unroll 4
+        for (int64_t p = r0 + ty; p < r1; p += rows_par) {
+            const f16x8 xh = *reinterpret_cast<const f16x8 *>(Xh + p * ldx + cg * 8);
+            const f16x8 xl = *reinterpret_cast<const f16x8 *>(Xl + p * ldx + cg * 8);
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = __builtin_fmaf((float)xl[j], SPLIT_INV, (float)xh[j]);
+#pragma unroll
+            for (int k = 0; k < NO; ++k) {
+                const float g = G[p * ldg + g_col0 + k];
+                if (cg == 0) bs[k] += g;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[k][j] += g * x[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NO; ++k) red[k][threadIdx.x] = 0.f;
+    if (threadIdx.x < NO) red[threadIdx.x][256] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NO; ++k) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(&red[k][cg * 8 + j], acc[k][j]);
+        if (cg == 0) atomicAdd(&red[k][256], bs[k]);
+    }
+    __syncthreads();
+    float *row = slab + (int64_t)wg * (NO * n_in + NO);
+    if ((int)threadIdx.x < n_in)
+#pragma unroll
+        for (int k = 0; k < NO; ++k) row[k * n_in + threadIdx.x] = red[k][threadIdx.x];
+    if (threadIdx.x < NO) row[NO * n_in + threadIdx.x] = red[threadIdx.x][256];
+}
+
 // A job's slabs are few here (~23), so one thread sums one element over all of them (512 elements per block, no LDS, no
 // barrier; 8x fewer blocks than the 64-element jobs of dw_reduce_block, whose count is what bounds that kernel).
 constexpr int DWR_BLOCK = 512;
@@ -671,7 +1035,9 @@ __global__ __launch_bounds__(DWR_BLOCK) void dw_reduce_multi_kernel(DwReduceMult
 namespace {
 struct TrainWs {
     uint16_t *sv_e, *sv_d, *sv_h, *sv_feat, *sv_hv, *g_rawb, *g_rawt, *g_hv, *g_feat, *g_h;
+    uint16_t *sv_e_lo, *sv_d_lo, *sv_h_lo, *sv_feat_lo, *sv_hv_lo, *g_rawt_lo, *g_hv_lo, *g_feat_lo, *g_h_lo;   // split: the lo planes
     uint8_t *sv_bits;
+    float *g_scale;     // split: GRAD_SCALE_PARTS partial maxima of |dL/draw|, then S and 1 / S (split.h)
     float *slab;        // 2 x DW_GRID partial [256 x 256 + 256] fp32 results of a weight-gradient product (alternating:
                         // the reduction of one product runs beside the next product)
 };
@@ -679,23 +1045,29 @@ constexpr size_t SLAB_FLOATS = (size_t)256 * (256 * 256 + 256);
 constexpr int DW_GRID = 256;
 size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 
-int64_t carve(const Program &p, int64_t P_points, char *base, TrainWs *w) {
+// Rows of a saved xyz-encoding row: 32 per k-step; the split-precision arrays pad a three-k-step encoding (multires 15) to
+// 128 so that its weight-gradient product keeps power-of-two rows (dw2s_body; the extra slots map to no weight column).
+int enc_row_slots(int k16, bool split) { return split && k16 == 3 ? 128 : 32 * k16; }
+
+int64_t carve(const Program &p, int64_t P_points, char *base, TrainWs *w, bool split) {
     const size_t P = (size_t)pad_points(P_points);     // rows for the last workgroup's padding points too
     size_t off = 0;
     auto take = [&](size_t bytes) { char *q = base ? base + off : nullptr; off += al(bytes); return q; };
-    const size_t e = 32 * p.KE16, d = 32 * p.KD16;
+    auto lo = [&](size_t bytes) { return split ? (uint16_t *)take(bytes) : nullptr; };
+    const size_t e = enc_row_slots(p.KE16, split), d = 32 * p.KD16;
     TrainWs t;
-    t.sv_e = (uint16_t *)take(P * e * 2);
-    t.sv_d = (uint16_t *)take(P * d * 2);
-    t.sv_h = (uint16_t *)take((size_t)8 * P * 256 * 2);
-    t.sv_feat = (uint16_t *)take(P * 256 * 2);
-    t.sv_hv = (uint16_t *)take(P * 128 * 2);
+    t.sv_e = (uint16_t *)take(P * e * 2);              t.sv_e_lo = lo(P * e * 2);
+    t.sv_d = (uint16_t *)take(P * d * 2);              t.sv_d_lo = lo(P * d * 2);
+    t.sv_h = (uint16_t *)take((size_t)8 * P * 256 * 2); t.sv_h_lo = lo((size_t)8 * P * 256 * 2);
+    t.sv_feat = (uint16_t *)take(P * 256 * 2);         t.sv_feat_lo = lo(P * 256 * 2);
+    t.sv_hv = (uint16_t *)take(P * 128 * 2);           t.sv_hv_lo = lo(P * 128 * 2);
     t.sv_bits = (uint8_t *)take(P * (8 * 32 + 16));
     t.g_rawb = (uint16_t *)take(P * 16 * 2);           // [P, 4] with a view branch, [P, 16] without
-    t.g_rawt = (uint16_t *)take(P * 4 * 2);
-    t.g_hv = (uint16_t *)take(P * 128 * 2);
-    t.g_feat = (uint16_t *)take(P * 256 * 2);
-    t.g_h = (uint16_t *)take((size_t)8 * P * 256 * 2);
+    t.g_rawt = (uint16_t *)take(P * 4 * 2);            t.g_rawt_lo = lo(P * 4 * 2);
+    t.g_hv = (uint16_t *)take(P * 128 * 2);            t.g_hv_lo = lo(P * 128 * 2);
+    t.g_feat = (uint16_t *)take(P * 256 * 2);          t.g_feat_lo = lo(P * 256 * 2);
+    t.g_h = (uint16_t *)take((size_t)8 * P * 256 * 2); t.g_h_lo = lo((size_t)8 * P * 256 * 2);
+    t.g_scale = (float *)take((GRAD_SCALE_PARTS + 2) * sizeof(float));
     t.slab = (float *)take(2 * SLAB_FLOATS * sizeof(float));
     if (w) *w = t;
     return (int64_t)off;
@@ -709,14 +1081,17 @@ bool train_supported(const Program &p) {
     return (a.multires == 10 || a.multires == 15) && p.out_ch <= 16;       // output_linear models (nerf.py:91-94)
 }
 
-int64_t train_workspace_bytes(const Program &p, int64_t P) { return carve(p, P, nullptr, nullptr); }
+int64_t train_workspace_bytes(const Program &p, int64_t P, bool split) { return carve(p, P, nullptr, nullptr, split); }
 
-void train_fill_args(const Program &p, int64_t P, void *workspace, MlpArgs *a) {
+void train_fill_args(const Program &p, int64_t P, void *workspace, MlpArgs *a, bool split) {
     TrainWs w;
-    carve(p, P, static_cast<char *>(workspace), &w);
+    carve(p, P, static_cast<char *>(workspace), &w, split);
     a->sv_e = w.sv_e; a->sv_d = w.sv_d; a->sv_h = w.sv_h; a->sv_feat = w.sv_feat; a->sv_hv = w.sv_hv;
     a->sv_bits = w.sv_bits;
     a->g_rawb = w.g_rawb; a->g_rawt = w.g_rawt; a->g_hv = w.g_hv; a->g_feat = w.g_feat; a->g_h = w.g_h;
+    a->sv_e_lo = w.sv_e_lo; a->sv_d_lo = w.sv_d_lo; a->sv_h_lo = w.sv_h_lo; a->sv_feat_lo = w.sv_feat_lo; a->sv_hv_lo = w.sv_hv_lo;
+    a->g_rawt_lo = w.g_rawt_lo; a->g_hv_lo = w.g_hv_lo; a->g_feat_lo = w.g_feat_lo; a->g_h_lo = w.g_h_lo;
+    a->g_scale = w.g_scale;
 }
 
 // The products of one training step in order.  Product k dumps its slabs into buffer k % 2 on the caller's stream; its
@@ -896,6 +1271,7 @@ static int weight_grad(DwSeq &s, int64_t P, float *slab, const uint16_t *X, int 
     a.G = G; a.ldg = n_out_slots; a.X = X; a.ldx = n_in_slots; a.P = P; a.slab = slab; a.H = head ? head->H : nullptr;
     DwReduceArgs r;
     r.slab = slab; r.n_slabs = 0; r.OT = 0; r.IT = 0;
+    a.G_lo = a.X_lo = a.H_lo = nullptr; r.inv_scale = nullptr;
     r.HT = head ? 1 : 0; r.head_dW = head ? head->dW : nullptr; r.head_db = head ? head->db : nullptr;
     r.head_row0 = head ? head->row0 : 0; r.head_rows = head ? head->rows : 0; r.head_ld = head ? head->ld : 0;
     if (head && !(s.multi && n_out_slots == 256 && n_in_slots == 256)) return NERF_AMD_EINVAL;
@@ -916,11 +1292,12 @@ static int head_grad(DwSeq &s, int64_t P, const uint16_t *X, int n_in_slots, int
     if (!s.multi || n_in_slots != 128 || s.mj.n >= DW_MAX_JOBS) return NERF_AMD_EINVAL;
     DwJob &J = s.mj.job[s.mj.n];
     J.a.G = nullptr; J.a.ldg = 0; J.a.X = X; J.a.ldx = n_in_slots; J.a.P = P; J.a.slab = nullptr; J.a.H = head.H;
+    J.a.G_lo = J.a.X_lo = J.a.H_lo = nullptr;
     J.shape = 5;
     DwReduceArgs &r = s.mr.r[s.mj.n];
     r.slab = nullptr; r.n_slabs = 0; r.OT = 0; r.IT = n_in_slots / 16;
     r.dW = nullptr; r.ld_dw = 0; r.col_off = 0; r.db = nullptr;
-    r.out_kind = PERM_NAT; r.in_kind = in_kind; r.in_L = 0; r.n_valid = 0; r.m_valid = m_valid;
+    r.out_kind = PERM_NAT; r.in_kind = in_kind; r.in_L = 0; r.n_valid = 0; r.m_valid = m_valid; r.inv_scale = nullptr;
     r.HT = 1; r.head_dW = head.dW; r.head_db = head.db; r.head_row0 = head.row0; r.head_rows = head.rows; r.head_ld = head.ld;
     ++s.mj.n;
     return NERF_AMD_OK;
@@ -929,9 +1306,14 @@ static int head_grad(DwSeq &s, int64_t P, const uint16_t *X, int n_in_slots, int
 // Parameter gradients of the view-branch model from the saved activations and the
 // pre-activation gradients the dX-chain kernel left in the workspace.  Every product overwrites
 // its destination (no accumulation into gw / gb).
-int train_param_grads(const Program &p, int64_t P, void *workspace, float *const *gw, float *const *gb, int device, hipStream_t stream) {
+static int train_param_grads_split(const Program &p, int64_t P, const TrainWs &w, float *const *gw, float *const *gb, hipStream_t stream,
+                                   const float *g_raw);
+
+int train_param_grads(const Program &p, int64_t P, void *workspace, float *const *gw, float *const *gb, int device, hipStream_t stream,
+                      bool split, const float *g_raw) {
     TrainWs w;
-    carve(p, P, static_cast<char *>(workspace), &w);
+    carve(p, P, static_cast<char *>(workspace), &w, split);
+    if (split) return train_param_grads_split(p, P, w, gw, gb, stream, g_raw);
     const int D = p.arch.D, W = p.arch.W, E = 32 * p.KE16, Dd = 32 * p.KD16, ic = p.input_ch, icv = p.input_ch_views;
     const bool vd = p.arch.use_viewdirs != 0;
     if (W != 256 || (E != 64 && E != 96) || (vd && Dd != 32 && Dd != 64)) return NERF_AMD_EUNSUPPORTED;
@@ -1053,6 +1435,130 @@ int train_param_grads(const Program &p, int64_t P, void *workspace, float *const
     if (s.overlap || s.lanes) lane_release(device, s.ev);
     if (rc) return rc;
     if (!fold_heads && !heads_first && !heads_tail) heads(stream, w.slab);
+    return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
+}
+
+// The split-precision counterpart: every streaming product of the model (and, with a view branch, both head products) as
+// jobs of ONE dw_multi_split_kernel launch, one reduction launch that also takes the loss scale off; output_linear's
+// gradient (no view branch) from fp32 FMA kernels on dL/draw itself.
+static int train_param_grads_split(const Program &p, int64_t P, const TrainWs &w, float *const *gw, float *const *gb, hipStream_t stream,
+                                   const float *g_raw) {
+    const int D = p.arch.D, W = p.arch.W, E = enc_row_slots(p.KE16, true), Dd = 32 * p.KD16, ic = p.input_ch, icv = p.input_ch_views;
+    const bool vd = p.arch.use_viewdirs != 0;
+    if (W != 256 || (E != 64 && E != 128) || (vd && Dd != 32 && Dd != 64)) return NERF_AMD_EUNSUPPORTED;
+    const int Lx = p.arch.multires, Ld = p.arch.multires_views;
+    const int64_t HS = pad_points(P) * 256;
+    DwMulti mj;
+    DwReduceMulti mr;
+    mj.n = 0;
+    size_t lds = 0;
+    int rc = NERF_AMD_OK;
+    struct Plane { const uint16_t *hi, *lo; };
+    // dW[:, col_off : col_off + m_valid] (+ db) of one Linear from G [P, n_out_slots] and X [P, n_in_slots] (hi / lo planes)
+    auto product = [&](Plane X, int n_in_slots, int in_kind, int in_L, int m_valid, Plane G, int n_out_slots, int n_valid, float *dW,
+                       int ld_dw, int col_off, float *db, int head_row0 = -1, int head_rows = 0, int head_ld = 0, float *head_dW = nullptr,
+                       float *head_db = nullptr) {
+        if (rc) return;
+        if (mj.n >= DW_MAX_JOBS) { rc = NERF_AMD_EINVAL; return; }
+        const bool head = head_row0 >= 0;
+        int shape = -1, OT = n_out_slots / 16, IT = n_in_slots / 16;
+        if (OT == 16 && IT == 16) shape = head ? 4 : 0;
+        else if (OT == 8 && IT == 16) shape = 1;
+        else if (OT == 16 && IT == 4) shape = 2;
+        else if (OT == 8 && IT == 2) shape = 3;
+        else if (OT == 16 && IT == 8) shape = 6;
+        else if (OT == 8 && IT == 4) shape = 7;
+        else if (OT == 0 && IT == 8 && head) shape = 5;
+        if (shape < 0 || (head && shape != 4 && shape != 5)) { rc = NERF_AMD_EUNSUPPORTED; return; }
+        DwJob &J = mj.job[mj.n];
+        J.a.G = G.hi; J.a.G_lo = G.lo; J.a.ldg = n_out_slots; J.a.X = X.hi; J.a.X_lo = X.lo; J.a.ldx = n_in_slots; J.a.P = P;
+        J.a.slab = nullptr; J.a.H = head ? w.g_rawt : nullptr; J.a.H_lo = head ? w.g_rawt_lo : nullptr;
+        J.shape = shape;
+        DwReduceArgs &r = mr.r[mj.n];
+        r.slab = nullptr; r.n_slabs = 0; r.OT = OT; r.IT = IT;
+        r.dW = dW; r.ld_dw = ld_dw; r.col_off = col_off; r.db = db;
+        r.out_kind = shape == 5 ? PERM_NAT : PERM_ACC; r.in_kind = in_kind; r.in_L = in_L; r.n_valid = n_valid; r.m_valid = m_valid;
+        r.HT = head ? 1 : 0; r.head_dW = head_dW; r.head_db = head_db; r.head_row0 = head ? head_row0 : 0; r.head_rows = head_rows; r.head_ld = head_ld;
+        r.inv_scale = w.g_scale + GRAD_SCALE_PARTS + 1;
+        const size_t need = shape == 5 ? (size_t)7 * (2 * 32 * 32 * 8 + 2048) : dw_split_lds(OT, IT, head);
+        if (need > lds) lds = need;
+        ++mj.n;
+    };
+    for (int l = 0; l < D; ++l) {
+        const Plane G{w.g_h + l * HS, w.g_h_lo + l * HS};
+        const Plane Xe{w.sv_e, w.sv_e_lo}, Xh{w.sv_h + (l > 0 ? l - 1 : 0) * HS, w.sv_h_lo + (l > 0 ? l - 1 : 0) * HS};
+        const int n_in = p.tensors[l].n_in;
+        if (l == 0) {
+            product(Xe, E, PERM_GEN, Lx, ic, G, W, W, gw[l], n_in, 0, gb[l]);
+        } else if (n_in == W + ic) {      // the layer after the skip: [input_pts | h]
+            product(Xe, E, PERM_GEN, Lx, ic, G, W, W, gw[l], n_in, 0, nullptr);
+            product(Xh, W, PERM_ACC, 0, W, G, W, W, gw[l], n_in, ic, gb[l]);
+        } else {
+            product(Xh, W, PERM_ACC, 0, W, G, W, W, gw[l], n_in, 0, gb[l]);
+        }
+    }
+    const Plane h8{w.sv_h + (D - 1) * HS, w.sv_h_lo + (D - 1) * HS};
+    if (vd) {
+        const Plane Gf{w.g_feat, w.g_feat_lo}, Ghv{w.g_hv, w.g_hv_lo};
+        // feature_linear, with alpha_linear's gradient (same X = h8) riding along as a head tile: row 3 of dL/draw's columns
+        product(h8, W, PERM_ACC, 0, W, Gf, W, W, gw[D], W, 0, gb[D], 3, 1, W, gw[D + 1], gb[D + 1]);
+        // views_linears.0: [feature | dirs]
+        product(Plane{w.sv_feat, w.sv_feat_lo}, W, PERM_ACC, 0, W, Ghv, W / 2, W / 2, gw[D + 2], W + icv, 0, gb[D + 2]);
+        product(Plane{w.sv_d, w.sv_d_lo}, Dd, PERM_GEN, Ld, icv, Ghv, W / 2, W / 2, gw[D + 2], W + icv, W, nullptr);
+        // rgb_linear: rows 0..2 of dL/draw's columns over the view layer's output
+        product(Plane{w.sv_hv, w.sv_hv_lo}, W / 2, PERM_ACC, 0, W / 2, Plane{nullptr, nullptr}, 0, 0, nullptr, 0, 0, nullptr, 0, 3, W / 2,
+                gw[D + 3], gb[D + 3]);
+    }
+    if (rc) return rc;
+    // ---- the one launch: workgroups in proportion to the bytes per point of a product, DW_GRID in all
+    static DynamicLdsOptIn opt_in;
+    if (opt_in.ensure(reinterpret_cast<const void *>(dw_multi_split_kernel), 135168) != hipSuccess) return NERF_AMD_EHIP;
+    const int64_t n_chunks = (P + 31) / 32;
+    int wgt[DW_MAX_JOBS], total_w = 0, nb[DW_MAX_JOBS], per[DW_MAX_JOBS], used = 0;
+    for (int j = 0; j < mj.n; ++j) {
+        const DwReduceArgs &r = mr.r[j];
+        wgt[j] = r.OT + r.IT; per[j] = dw_slab_floats(r.OT, r.IT, r.HT);
+        total_w += wgt[j];
+    }
+    for (int j = 0; j < mj.n; ++j) { nb[j] = DW_GRID * wgt[j] / total_w; if (nb[j] < 1) nb[j] = 1; used += nb[j]; }
+    for (int j = 0; used < DW_GRID; j = (j + 1) % mj.n) { ++nb[j]; ++used; }
+    const int cap = n_chunks / 8 < 1 ? 1 : (int)(n_chunks / 8 > DW_GRID ? DW_GRID : n_chunks / 8);
+    float *sl = w.slab;
+    int first = 0, rfirst = 0;
+    for (int j = 0; j < mj.n; ++j) {
+        if (nb[j] > cap) nb[j] = cap;
+        mj.job[j].a.slab = sl;
+        mj.job[j].first_block = first; mj.job[j].n_blocks = nb[j];
+        mr.r[j].slab = sl; mr.r[j].n_slabs = nb[j];
+        mr.first_block[j] = rfirst;
+        sl += (size_t)nb[j] * per[j];
+        first += nb[j];
+        rfirst += (per[j] + DWR_BLOCK - 1) / DWR_BLOCK;
+    }
+    mr.first_block[mj.n] = rfirst;
+    mr.n = mj.n;
+    if (lds > 135168) return NERF_AMD_EINVAL;
+    hipLaunchKernelGGL(dw_multi_split_kernel, dim3((unsigned)first), dim3(512), lds, stream, mj);
+    hipLaunchKernelGGL(dw_reduce_multi_kernel, dim3((unsigned)rfirst), dim3(512), 0, stream, mr);
+    if (!vd) {
+        // output_linear [out_ch, W]: X = h8, G = the columns of dL/draw (fp32), four rows per launch; the slabs go behind
+        // the one launch's (its reduction has consumed them in stream order, and these are 1024 x (4 x 256 + 4) floats)
+        for (int r0 = 0; r0 < p.out_ch; r0 += 4) {
+            const int n = p.out_ch - r0 < 4 ? p.out_ch - r0 : 4;
+            float *dWr = gw[D] + (int64_t)r0 * W, *dbr = gb[D] + r0;
+            int64_t g = (P + 255) / 256;
+            if (g > 1024) g = 1024;
+            float *slab2 = w.slab + SLAB_FLOATS;
+#define NA_LAUNCH_SMALL_SPLIT(NO)                                                                                                        \
+    hipLaunchKernelGGL(dw_small_split_kernel<NO>, dim3((unsigned)g), dim3(256), 0, stream, g_raw, p.out_ch, r0, h8.hi, h8.lo, W, W, P, slab2); \
+    hipLaunchKernelGGL(dw_small_reduce_kernel, dim3((NO * W + NO + 63) / 64), dim3(1024), 0, stream, slab2, (int)g, NO, W, (int)PERM_ACC, dWr, W, dbr)
+            if (n == 1) { NA_LAUNCH_SMALL_SPLIT(1); }
+            else if (n == 2) { NA_LAUNCH_SMALL_SPLIT(2); }
+            else if (n == 3) { NA_LAUNCH_SMALL_SPLIT(3); }
+            else { NA_LAUNCH_SMALL_SPLIT(4); }
+#undef NA_LAUNCH_SMALL_SPLIT
+        }
+    }
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
 

@@ -63,7 +63,8 @@ struct nerf_amd_model {
     LayerF32 *d_layers = nullptr;
     TensorDesc *d_tensors = nullptr;
     uint16_t *stream_bf16 = nullptr, *stream_s16 = nullptr, *stream_bwd = nullptr, *stream_split = nullptr;
-    FragDesc *d_frags_bwd = nullptr, *d_frags_split = nullptr;
+    FragDesc *d_frags_bwd = nullptr, *d_frags_split = nullptr, *d_frags_bwd_split = nullptr;
+    uint16_t *stream_bwd_split = nullptr;
     float *bias_bf16 = nullptr, *stream_f32 = nullptr, *bias_f32 = nullptr, *bias_s16 = nullptr;
     FragDesc *d_frags16 = nullptr;
     TileDesc *d_tiles16 = nullptr;
@@ -95,6 +96,7 @@ int nerf_amd_model_create(const nerf_amd_arch *arch, int device, nerf_amd_model 
     if ((rc = upload(&m->d_frags, p.frags)) || (rc = upload(&m->d_tiles, p.tiles)) ||
         (rc = upload(&m->d_frags16, p.frags16)) || (rc = upload(&m->d_tiles16, p.tiles16)) ||
         (rc = upload(&m->d_frags_bwd, p.frags_bwd)) || (rc = upload(&m->d_frags_split, p.frags_split)) ||
+        (rc = upload(&m->d_frags_bwd_split, p.frags_bwd_split)) ||
         (rc = upload(&m->d_layers, p.layers)) || (rc = upload(&m->d_tensors, p.tensors))) {
         nerf_amd_model_destroy(m);
         return rc;
@@ -108,6 +110,8 @@ int nerf_amd_model_create(const nerf_amd_arch *arch, int device, nerf_amd_model 
         if (e == hipSuccess && !p.frags_bwd.empty())
             e = hipMalloc(reinterpret_cast<void **>(&m->stream_bwd), p.frags_bwd.size() * 1024);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->stream_split), p.frags_split.size() * 1024);
+        if (e == hipSuccess && !p.frags_bwd_split.empty())
+            e = hipMalloc(reinterpret_cast<void **>(&m->stream_bwd_split), p.frags_bwd_split.size() * 1024);
     }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->stream_f32), (size_t)p.f32_stream_floats * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->bias_f32), (size_t)p.f32_bias_floats * sizeof(float));
@@ -136,7 +140,7 @@ int nerf_amd_model_update(nerf_amd_model *m, const float *const *weights, const 
     int rc = launch_pack(p, m->d_frags, m->d_tiles, m->d_layers, m->d_tensors, wt, bt,
                          m->stream_bf16, m->bias_bf16, m->stream_f32, m->bias_f32,
                          m->d_frags16, m->d_tiles16, m->stream_s16, m->bias_s16, m->d_frags_bwd, m->stream_bwd,
-                         m->d_frags_split, m->stream_split, s);
+                         m->d_frags_split, m->stream_split, m->d_frags_bwd_split, m->stream_bwd_split, s);
     if (rc) return fail(rc, "pack launch failed");
     m->packed = true;
     return NERF_AMD_OK;
@@ -145,6 +149,7 @@ int nerf_amd_model_update(nerf_amd_model *m, const float *const *weights, const 
 void nerf_amd_model_destroy(nerf_amd_model *m) {
     if (!m) return;
     (void)hipFree(m->d_frags); (void)hipFree(m->d_tiles); (void)hipFree(m->d_layers); (void)hipFree(m->d_tensors);
+    (void)hipFree(m->d_frags_bwd_split); (void)hipFree(m->stream_bwd_split);
     (void)hipFree(m->d_frags_bwd); (void)hipFree(m->stream_bwd); (void)hipFree(m->d_frags_split); (void)hipFree(m->stream_split);
     (void)hipFree(m->d_frags16); (void)hipFree(m->d_tiles16); (void)hipFree(m->stream_s16); (void)hipFree(m->bias_s16);
     (void)hipFree(m->stream_bf16); (void)hipFree(m->bias_bf16); (void)hipFree(m->stream_f32); (void)hipFree(m->bias_f32);
@@ -165,15 +170,15 @@ int nerf_amd_model_out_ch(const nerf_amd_model *m) { return m ? m->prog.out_ch :
 
 int nerf_amd_pack_bf16_host(const nerf_amd_arch *arch, int shape, const float *const *weights, const float *const *biases,
                             int n_tensors, uint16_t *stream_out, int64_t *n_frags, float *bias_out, int64_t *n_bias) {
-    if (shape != 16 && shape != 32 && shape != 17 && shape != 18)
-        return fail(NERF_AMD_EINVAL, "shape must be 32 (32x32x16 stream), 16 (16x16x32 stream), 17 (backward stream) or 18 (split-precision stream)");
+    if (shape != 16 && shape != 32 && shape != 17 && shape != 18 && shape != 19)
+        return fail(NERF_AMD_EINVAL, "shape must be 32 (32x32x16 stream), 16 (16x16x32 stream), 17 (backward stream), 18 (split-precision stream) or 19 (split-precision backward stream)");
     if (!arch) return fail(NERF_AMD_EINVAL, "null argument");
     Program p;
     const char *err = "";
     if (build_program(*arch, p, &err) != 0) return fail(NERF_AMD_EINVAL, err);
     if (!p.bf16_ok) return fail(NERF_AMD_EUNSUPPORTED, "architecture has no fused bf16 program (needs D=8, W=256, skips=[4])");
-    if (n_frags) *n_frags = (int64_t)(shape == 18 ? p.frags_split.size() : shape == 17 ? p.frags_bwd.size() : shape == 16 ? p.frags16.size() : p.frags.size());
-    if (n_bias) *n_bias = (shape == 17 || shape == 18) ? 0 : shape == 16 ? (int64_t)p.tiles16.size() * 16 : (int64_t)p.tiles.size() * 32;
+    if (n_frags) *n_frags = (int64_t)(shape == 19 ? p.frags_bwd_split.size() : shape == 18 ? p.frags_split.size() : shape == 17 ? p.frags_bwd.size() : shape == 16 ? p.frags16.size() : p.frags.size());
+    if (n_bias) *n_bias = (shape == 17 || shape == 18 || shape == 19) ? 0 : shape == 16 ? (int64_t)p.tiles16.size() * 16 : (int64_t)p.tiles.size() * 32;
     if (stream_out || bias_out) {
         if (!weights || !biases || n_tensors != (int)p.tensors.size()) return fail(NERF_AMD_EINVAL, "bad parameter list");
         pack_bf16_host(p, shape, weights, biases, stream_out, bias_out);
@@ -298,34 +303,44 @@ int nerf_amd_ndc_rays_backward(int32_t H, int32_t W, double focal, float near, c
     return rc ? fail(rc, "ndc_rays backward launch failed") : NERF_AMD_OK;
 }
 
-int nerf_amd_model_supports_training(const nerf_amd_model *m) { return m && train_supported(m->prog) ? 1 : 0; }
+namespace {
+const char *TRAIN_COVER = "training kernels cover D=8, W=256, skips=[4] with view branch (multires 10/4 or 15/6) or without (multires 10 or 15, output_ch <= 16), in NERF_AMD_PREC_BF16 or NERF_AMD_PREC_FP32_SPLIT";
+bool train_precision_ok(int precision) { return precision == NERF_AMD_PREC_BF16 || precision == NERF_AMD_PREC_FP32_SPLIT; }
+}  // namespace
 
-int64_t nerf_amd_train_workspace(const nerf_amd_model *m, int64_t n_points) {
-    if (!m || n_points < 0 || !train_supported(m->prog)) return -1;
-    return train_workspace_bytes(m->prog, n_points);
+int nerf_amd_model_supports_training(const nerf_amd_model *m, int precision) {
+    return m && train_precision_ok(precision) && train_supported(m->prog) ? 1 : 0;
+}
+
+int64_t nerf_amd_train_workspace(const nerf_amd_model *m, int64_t n_points, int precision) {
+    if (!m || n_points < 0 || !train_precision_ok(precision) || !train_supported(m->prog)) return -1;
+    return train_workspace_bytes(m->prog, n_points, precision == NERF_AMD_PREC_FP32_SPLIT);
 }
 
 int nerf_amd_field_forward_train(const nerf_amd_model *m, const float *pts, const float *viewdirs, const float *rays,
                                  int32_t ray_ch, const float *z_vals, int64_t R, int32_t S, float *raw, void *workspace,
-                                 int64_t workspace_bytes, void *stream) {
+                                 int64_t workspace_bytes, int precision, void *stream) {
     if (!m || R < 0 || S < 1) return fail(NERF_AMD_EINVAL, "bad forward_train arguments");
     const bool vd = m->prog.arch.use_viewdirs != 0;
     if (!pts && ray_ch != (vd ? 11 : 8)) return fail(NERF_AMD_EINVAL, vd ? "rays must be [R,11]" : "rays must be [R,8] for a model without view branch");
     if (pts && vd && !viewdirs) return fail(NERF_AMD_EINVAL, "pts mode needs viewdirs [R,3]");
-    if (!train_supported(m->prog)) return fail(NERF_AMD_EUNSUPPORTED, "training kernels cover D=8, W=256, skips=[4] with view branch (multires 10/4 or 15/6) or without (multires 10 or 15, output_ch <= 16)");
+    if (!train_precision_ok(precision) || !train_supported(m->prog)) return fail(NERF_AMD_EUNSUPPORTED, TRAIN_COVER);
     if (!m->packed) return fail(NERF_AMD_EINVAL, "model has no parameters yet");
     if (R == 0) return NERF_AMD_OK;
+    const bool split = precision == NERF_AMD_PREC_FP32_SPLIT;
     const int64_t P = R * S;
-    if ((!pts && (!rays || !z_vals)) || !raw || !workspace || workspace_bytes < train_workspace_bytes(m->prog, P))
+    if ((!pts && (!rays || !z_vals)) || !raw || !workspace || workspace_bytes < train_workspace_bytes(m->prog, P, split))
         return fail(NERF_AMD_EINVAL, "null pointer or workspace too small");
     MlpArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.stream_s16 = m->stream_s16; a.bias_s16 = m->bias_s16;
+    a.stream_s16 = m->stream_s16; a.bias_s16 = m->bias_s16; a.stream_split = m->stream_split;
     if (pts) { a.pts = pts; a.viewdirs = vd ? viewdirs : nullptr; a.vd_stride = 3; }
     else { a.rays = rays; a.ray_stride = ray_ch; a.z_vals = z_vals; a.viewdirs = vd ? rays + 8 : nullptr; a.vd_stride = ray_ch; }
     a.P = P; a.S = S; a.out = raw; a.out_ch = m->prog.out_ch;
-    train_fill_args(m->prog, P, workspace, &a);
-    int rc = launch_mlp_bf16_s16_save(a, m->prog.arch.multires, m->prog.arch.multires_views, vd, m->prog.n_frags16_used, (int)m->prog.tiles16.size(), static_cast<hipStream_t>(stream));
+    train_fill_args(m->prog, P, workspace, &a, split);
+    const nerf_amd_arch &ar = m->prog.arch;
+    int rc = split ? launch_mlp_split_save(a, ar.multires, ar.multires_views, vd, m->prog.n_frags_split_used, (int)m->prog.tiles16.size(), static_cast<hipStream_t>(stream))
+                   : launch_mlp_bf16_s16_save(a, ar.multires, ar.multires_views, vd, m->prog.n_frags16_used, (int)m->prog.tiles16.size(), static_cast<hipStream_t>(stream));
     return rc ? fail(rc, "training forward launch failed") : NERF_AMD_OK;
 }
 
@@ -333,28 +348,31 @@ int nerf_amd_field_backward(const nerf_amd_model *m, const float *g_raw, const f
                             const float *rays, int32_t ray_ch, const float *z_vals, int64_t R, int32_t S,
                             void *workspace, int64_t workspace_bytes, float *const *grad_weights,
                             float *const *grad_biases, int n_tensors, float *g_pts, float *g_rays, float *g_viewdirs,
-                            void *stream) {
+                            int precision, void *stream) {
     const int64_t n_points = R * S;
     if (!m || R < 0 || S < 1 || !grad_weights || !grad_biases) return fail(NERF_AMD_EINVAL, "bad backward arguments");
     const bool vd = m->prog.arch.use_viewdirs != 0;
     if ((!pts && (ray_ch != (vd ? 11 : 8) || !rays || !z_vals)) || (pts && vd && !viewdirs))
         return fail(NERF_AMD_EINVAL, "backward needs the forward's inputs (pts + viewdirs, or rays [R,11] + z_vals; [R,8] without view branch)");
-    if (!train_supported(m->prog)) return fail(NERF_AMD_EUNSUPPORTED, "training kernels cover D=8, W=256, skips=[4] with view branch (multires 10/4 or 15/6) or without (multires 10 or 15, output_ch <= 16)");
+    if (!train_precision_ok(precision) || !train_supported(m->prog)) return fail(NERF_AMD_EUNSUPPORTED, TRAIN_COVER);
     if (n_tensors != (int)m->prog.tensors.size()) return fail(NERF_AMD_EINVAL, "wrong number of gradient tensors");
     if (n_points == 0) return NERF_AMD_OK;
-    if (!g_raw || !workspace || workspace_bytes < train_workspace_bytes(m->prog, n_points))
+    const bool split = precision == NERF_AMD_PREC_FP32_SPLIT;
+    if (!g_raw || !workspace || workspace_bytes < train_workspace_bytes(m->prog, n_points, split))
         return fail(NERF_AMD_EINVAL, "null pointer or workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
     MlpArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.stream_bwd = m->stream_bwd; a.g_raw = g_raw; a.P = n_points; a.S = S; a.out_ch = m->prog.out_ch;
+    a.stream_bwd = m->stream_bwd; a.stream_bwd_split = m->stream_bwd_split; a.g_raw = g_raw; a.P = n_points; a.S = S; a.out_ch = m->prog.out_ch;
     if (pts) { a.pts = pts; a.viewdirs = vd ? viewdirs : nullptr; a.vd_stride = 3; }
     else { a.rays = rays; a.ray_stride = ray_ch; a.z_vals = z_vals; a.viewdirs = vd ? rays + 8 : nullptr; a.vd_stride = ray_ch; }
     a.g_pts = g_pts; a.g_rays = g_rays; a.g_vd = vd ? g_viewdirs : nullptr;
-    train_fill_args(m->prog, n_points, workspace, &a);
-    int rc = launch_mlp_bwd_s16(a, m->prog.arch.multires, m->prog.arch.multires_views, vd, m->prog.n_frags_bwd_used, s);
+    train_fill_args(m->prog, n_points, workspace, &a, split);
+    const nerf_amd_arch &ar = m->prog.arch;
+    int rc = split ? launch_mlp_bwd_split(a, ar.multires, ar.multires_views, vd, m->prog.n_frags_bwd_split_used, s)
+                   : launch_mlp_bwd_s16(a, ar.multires, ar.multires_views, vd, m->prog.n_frags_bwd_used, s);
     if (rc) return fail(rc, "backward kernel launch failed");
-    rc = train_param_grads(m->prog, n_points, workspace, grad_weights, grad_biases, m->device, s);
+    rc = train_param_grads(m->prog, n_points, workspace, grad_weights, grad_biases, m->device, s, split, g_raw);
     return rc ? fail(rc, "weight-gradient GEMMs failed") : NERF_AMD_OK;
 }
 

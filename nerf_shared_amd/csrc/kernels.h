@@ -59,6 +59,13 @@ struct MlpArgs {
     float *g_pts;                  // [P, 3]  dL/dpts (explicit-points mode), overwritten; or NULL
     float *g_rays;                 // [R, 6]  dL/d(origin, direction) accumulated with atomics (rays mode); or NULL
     float *g_vd;                   // [R, 3]  dL/d(view direction) accumulated with atomics; or NULL
+    // split-precision training (split.h): every saved / gradient array above is the plane of fp16 hi rows, these are the
+    // planes of fp16 lo rows (same shapes and slot order); the bit rows are shared
+    uint16_t *sv_e_lo, *sv_d_lo, *sv_h_lo, *sv_feat_lo, *sv_hv_lo;
+    uint16_t *g_rawt_lo, *g_hv_lo, *g_feat_lo, *g_h_lo;
+    const uint16_t *stream_bwd_split;   // transposed-weight stream as fp16 (hi, lo) fragments
+    float *g_scale;                // [GRAD_SCALE_PARTS + 2]: partial maxima of |dL/draw| (gmax_kernel), then the loss scale S
+                                   // and 1 / S as the dX-chain kernel derived them (read by the slab reductions)
 #ifdef NERF_AMD_STAMPS
     unsigned long long *stamps;    // diagnostic build: [workgroups][waves][4] cycle sums (mlp_bf16_s16.hip)
 #endif
@@ -76,6 +83,10 @@ int launch_mlp_f32(const MlpArgs &a, hipStream_t s);
 bool mlp_split_supported(int multires, int multires_views, int use_viewdirs, int out_ch);
 int launch_mlp_split(const MlpArgs &a, int multires, int multires_views, int use_viewdirs, int n_frags_used, int n_tiles,
                      hipStream_t s);
+int launch_mlp_split_save(const MlpArgs &a, int multires, int multires_views, int use_viewdirs, int n_frags_used, int n_tiles,
+                          hipStream_t s);
+// mlp_bwd_split.hip: the dX chain on fp16 pairs; launches gmax_kernel (the loss scale) first
+int launch_mlp_bwd_split(const MlpArgs &a, int multires, int multires_views, int use_viewdirs, int n_frags_used, hipStream_t s);
 int launch_embed(const float *x, int64_t n, int multires, float *out, hipStream_t s);
 
 // Parameter pointers of one model, passed to the pack kernels by value (no host->device copy).
@@ -88,7 +99,7 @@ int launch_pack(const Program &p, const FragDesc *d_frags, const TileDesc *d_til
                 uint16_t *stream_bf16, float *bias_bf16, float *stream_f32, float *bias_f32,
                 const FragDesc *d_frags16, const TileDesc *d_tiles16, uint16_t *stream_s16, float *bias_s16,
                 const FragDesc *d_frags_bwd, uint16_t *stream_bwd, const FragDesc *d_frags_split, uint16_t *stream_split,
-                hipStream_t s);
+                const FragDesc *d_frags_bwd_split, uint16_t *stream_bwd_split, hipStream_t s);
 void pack_bf16_host(const Program &p, int shape, const float *const *w, const float *const *b, uint16_t *stream, float *bias);
 int launch_mlp_bf16_s16(const MlpArgs &a, int multires, int multires_views, int use_viewdirs,
                         int n_frags_used, int n_tiles, hipStream_t s);
@@ -97,10 +108,12 @@ int launch_mlp_bf16_s16_save(const MlpArgs &a, int multires, int multires_views,
 int launch_mlp_bwd_s16(const MlpArgs &a, int multires, int multires_views, int use_viewdirs, int n_frags_used, hipStream_t s);
 
 // backward.hip
+// split: the arrays of NERF_AMD_PREC_FP32_SPLIT training (hi and lo planes, loss-scale slots) instead of the bf16 ones
 bool train_supported(const Program &p);
-int64_t train_workspace_bytes(const Program &p, int64_t P);
-void train_fill_args(const Program &p, int64_t P, void *workspace, MlpArgs *a);
-int train_param_grads(const Program &p, int64_t P, void *workspace, float *const *gw, float *const *gb, int device, hipStream_t s);
+int64_t train_workspace_bytes(const Program &p, int64_t P, bool split);
+void train_fill_args(const Program &p, int64_t P, void *workspace, MlpArgs *a, bool split);
+int train_param_grads(const Program &p, int64_t P, void *workspace, float *const *gw, float *const *gb, int device, hipStream_t s,
+                      bool split, const float *g_raw);
 
 // capi.hip: the library's side stream of a device and a pool of timing-less events (used by nerf_amd_render_batch and
 // by the weight-gradient products, whose slab reductions run beside the next product)

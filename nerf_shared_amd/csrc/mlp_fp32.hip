@@ -123,7 +123,10 @@ __global__ __launch_bounds__(512) void mlp_f32_kernel(MlpArgs a) {
             // only reads rows the previous layer's trailing barrier published and writes to global memory; the next
             // layer's first barrier (which wave 0 joins after its own tile) still precedes any overwrite of those rows.
             if (wave == 0) {
-                f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+                // accumulators start at the bias, like every other layer of the chain and like this head in the widest
+                // instantiation (D register i = output row i; the bias table is zero-padded past n_out)
+                f32x4 d0 = *reinterpret_cast<const f32x4 *>(a.bias_f32 + L.bias_off);
+                f32x4 d1 = *reinterpret_cast<const f32x4 *>(a.bias_f32 + L.bias_off + 4);
                 const float *xcol = act + L.in_row * PTS + (lane & (PTS - 1));   // HALVES = 1: lanes 32..63 repeat 0..31
                 const float *wrow = a.stream_f32 + L.frag_off + 4 * (lane & 3);        // rows 0..3 of tile 0; rows 4..7 are 16 floats on
                 const int groups8 = (L.n_in + 7) >> 3;
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(512) void mlp_f32_kernel(MlpArgs a) {
 #pragma unroll
                     for (int o = 0; o < 8; ++o)
                         if (o < L.n_out) {
-                            float v = (o < 4 ? d0[o & 3] : d1[o & 3]) + a.bias_f32[L.bias_off + o];
+                            float v = o < 4 ? d0[o & 3] : d1[o & 3];
                             if (L.relu) v = fmaxf(v, 0.0f);
                             a.out[(int64_t)a.out_ch * p + L.out_col + o] = v;
                         }

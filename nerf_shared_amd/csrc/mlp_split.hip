@@ -29,50 +29,11 @@
 #include "launch_util.h"
 #include "pipeline.h"
 #include "program.h"
+#include "split.h"
 
 namespace na {
 
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4s;
-
-#define MFMAH(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a_), __builtin_bit_cast(f16x8, b_), c_, 0, 0, 0)
-
-constexpr float SPLIT_SCALE = 2048.0f, SPLIT_INV = 1.0f / 2048.0f;
-
-// x -> (hi, lo): hi = fp16(x) rounded to nearest, lo = fp16 of the (exact) residual scaled by 2^11.  A denormal hi is
-// fine: v_mfma_f32_16x16x32_f16 multiplies fp16 denormals exactly (tools/micro/mfma_f16_denorm.hip), and the residual
-// carries whatever hi could not.
-__device__ __forceinline__ void split_f16(float x, _Float16 &hi, _Float16 &lo) {
-    const _Float16 h = (_Float16)x;
-    hi = h;
-    lo = (_Float16)((x - (float)h) * SPLIT_SCALE);
-}
-
-// Two values at once, on packed registers: hi = (fp16(x0), fp16(x1)) is one v_cvt_pk_f16_f32; each lo is ONE mixed-precision
-// fma that reads its hi straight out of the packed register -- fp16(-2^11 hi + 2^11 x), both products exact, one rounding: the
-// same value as split_f16's, without converting hi back to fp32 (the compiler does not form v_fma_mix from the C expression).
-__device__ __forceinline__ void split_f16_pair(float x0, float x1, f16x2 &hi, f16x2 &lo) {
-    f16x2 h;
-    h[0] = (_Float16)x0; h[1] = (_Float16)x1;
-    typedef __attribute__((ext_vector_type(2))) float f32x2s;
-    const f32x2s sc = f32x2s{x0, x1} * SPLIT_SCALE;          // one v_pk_mul_f32
-    const float kneg = -SPLIT_SCALE;
-    unsigned l;
-    const unsigned hb = __builtin_bit_cast(unsigned, h);
-    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hb), "v"(kneg), "v"(sc[0]));
-    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hb), "v"(kneg), "v"(sc[1]));
-    hi = h;
-    lo = __builtin_bit_cast(f16x2, l);
-}
-
-template <class C, int NR, int NM>
-__device__ __forceinline__ void sched_step_split() {
-    if constexpr ((C::OPT & 4) != 0) {
-        __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);   // DS read
-        __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);   // MFMA
-    }
-}
 
 // Pair of 16-row output tiles T, T+1 over K1 k-steps of x1 and K2 of x2; F0 = first fragment (split numbering).
 // acc[u][0] = hi x hi sums of tile u (starts at the bias), acc[u][1] = the two cross terms (scaled by 2^11).
@@ -187,6 +148,49 @@ __device__ __forceinline__ void encode_split(const float (&x)[3], int h, int b, 
     });
 }
 
+// Training forward: the (hi, lo) fragments of NK k-steps as they are, into a plane of hi rows and a plane of lo rows of
+// ROW fp16 values per point, slot-major like the bf16 training arrays (kernels.h).  Unconditional: rows exist for a
+// workgroup's padding points (pad_points).
+template <int NK, int ROW>
+__device__ __forceinline__ void save_frags_split(uint16_t *hi, uint16_t *lo, const bf16x8 *y, int64_t p, int q) {
+    static_for<NK>([&](auto k_) {
+        constexpr int k = k_;
+        *reinterpret_cast<bf16x8 *>(hi + p * ROW + k * 32 + q * 8) = y[2 * k];
+        *reinterpret_cast<bf16x8 *>(lo + p * ROW + k * 32 + q * 8) = y[2 * k + 1];
+    });
+}
+
+// "activation > 0" bits of a post-ReLU layer in the bit-row layout of mlp_bf16_s16.hip save_bits (dword k/4 of the lane's
+// NK/4 dwords: bit 4 (k%4) + i = element 2i, bit 16 + 4 (k%4) + i = element 2i + 1 of k-step k).  An activation is
+// positive when either half of its pair is non-zero (a value below fp16's smallest denormal lives in lo alone).
+template <int NK>
+__device__ __forceinline__ void save_bits_split(uint8_t *base, const bf16x8 *y, int64_t p, int q) {
+    static_assert(NK == 4 || NK == 8, "one or two dwords of mask bits");
+    unsigned w[NK / 4];
+#pragma unroll
+    for (int i = 0; i < NK / 4; ++i) w[i] = 0;
+    static_for<NK>([&](auto k_) {
+        constexpr int k = k_;
+        const u32x4s vh = __builtin_bit_cast(u32x4s, y[2 * k]), vl = __builtin_bit_cast(u32x4s, y[2 * k + 1]);
+        unsigned t = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned m;
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(vh[i] | vl[i]), "v"(0x00010001u));   // 1 per non-zero half
+            t |= m << i;
+        }
+        w[k / 4] |= t << (4 * (k % 4));
+    });
+    uint8_t *dst = base + p * (4 * NK) + q * NK;
+    if constexpr (NK == 8) {
+        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+        u32x2 o = {w[0], w[1]};
+        *reinterpret_cast<u32x2 *>(dst) = o;
+    } else {
+        *reinterpret_cast<unsigned *>(dst) = w[0];
+    }
+}
+
 // Fragment offsets of the split stream: every region of the s16 layout (mlp_bf16_s16.hip Layout16) twice as long.
 template <int LX, int LD, bool VD>
 struct LayoutSplit {
@@ -205,7 +209,7 @@ struct LayoutSplit {
     static constexpr int N_TILES = VD ? 128 + 16 + 1 + 8 + 1 : 128 + 1;
 };
 
-template <int LX, int LD, bool VD, class C>
+template <int LX, int LD, bool VD, class C, bool SAVE = false>
 __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_split_kernel(MlpArgs a) {
     constexpr int WG_THREADS = C::WAVES * 64, WG_POINTS = C::WAVES * 16;
     using Lay = LayoutSplit<LX, LD, VD>;
@@ -271,21 +275,53 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_split_kernel(MlpArgs a) 
         block_sync<-1, NB>(c);                                 // publishes block 0
         static_for<C::LA>([&](auto i_) { constexpr int i = i_; c.q[i] = ring_frag<i>(c); });
     }
+    // training forward: every layer's (hi, lo) output also goes to HBM for the backward pass (mlp_bwd_split.hip, backward.hip)
+    const int64_t HS = pad_points(a.P) * 256;                   // one saved hidden layer (one plane)
+    const int64_t BS = pad_points(a.P) * 32;                    // one layer of mask-bit rows
+    if constexpr (SAVE) {
+        // a three-k-step encoding (multires 15) is saved in rows of 128 slots, the fourth k-step zero: its weight-gradient
+        // product then has power-of-two rows (backward.hip enc_row_slots)
+        constexpr int ROW_E = KE == 3 ? 128 : 32 * KE;
+        save_frags_split<KE, ROW_E>(a.sv_e, a.sv_e_lo, E, p, q);
+        if constexpr (KE == 3) {
+            const bf16x8 zero2[2] = {};
+            save_frags_split<1, ROW_E>(a.sv_e + 96, a.sv_e_lo + 96, zero2, p, q);
+        }
+        if constexpr (VD) save_frags_split<KD, 32 * KD>(a.sv_d, a.sv_d_lo, Dv, p, q);
+    }
+    auto save_h = [&](auto l_, const bf16x8 *y) {
+        constexpr int l = l_;
+        if constexpr (SAVE) {
+            save_frags_split<8, 256>(a.sv_h + l * HS, a.sv_h_lo + l * HS, y, p, q);
+            save_bits_split<8>(a.sv_bits + l * BS, y, p, q);
+        }
+    };
+    using std::integral_constant;
     bf16x8 A[16], B[16];
     layer_split<Lay::F_L0, 0, 8, KE, 0, true, NB, NF>(c, E, E, A);
+    save_h(integral_constant<int, 0>{}, A);
     layer_split<Lay::F_L1 + 0 * 256, 16, 8, 8, 0, true, NB, NF>(c, A, A, B);
+    save_h(integral_constant<int, 1>{}, B);
     layer_split<Lay::F_L1 + 1 * 256, 32, 8, 8, 0, true, NB, NF>(c, B, B, A);
+    save_h(integral_constant<int, 2>{}, A);
     layer_split<Lay::F_L1 + 2 * 256, 48, 8, 8, 0, true, NB, NF>(c, A, A, B);
+    save_h(integral_constant<int, 3>{}, B);
     layer_split<Lay::F_L1 + 3 * 256, 64, 8, 8, 0, true, NB, NF>(c, B, B, A);
+    save_h(integral_constant<int, 4>{}, A);
     layer_split<Lay::F_L5, 80, 8, KE, 8, true, NB, NF>(c, E, A, B);            // skip: [input_pts | h]
+    save_h(integral_constant<int, 5>{}, B);
     layer_split<Lay::F_L6, 96, 8, 8, 0, true, NB, NF>(c, B, B, A);
+    save_h(integral_constant<int, 6>{}, A);
     layer_split<Lay::F_L6 + 256, 112, 8, 8, 0, true, NB, NF>(c, A, A, B);      // h7 in B
+    save_h(integral_constant<int, 7>{}, B);
 
     if constexpr (VD) {
         layer_split<Lay::F_FEAT, 128, 8, 8, 0, false, NB, NF>(c, B, B, A);     // feature (no activation)
+        if constexpr (SAVE) save_frags_split<8, 256>(a.sv_feat, a.sv_feat_lo, A, p, q);
         f32x4 alpha, rgb;
         tile_single_split<Lay::F_ALPHA, 144, 8, NB, NF>(c, B, alpha);          // row 0 = sigma
         layer_split<Lay::F_VIEWS, 145, 4, 8, KD, true, NB, NF>(c, A, Dv, B);   // views_linears.0 (128 rows)
+        if constexpr (SAVE) { save_frags_split<4, 128>(a.sv_hv, a.sv_hv_lo, B, p, q); save_bits_split<4>(a.sv_bits + 8 * BS, B, p, q); }
         tile_single_split<Lay::F_RGB, 153, 4, NB, NF>(c, B, rgb);              // rows 0..2
         if (valid && q == 0) {
             f32x4 o = {rgb[0], rgb[1], rgb[2], alpha[0]};
@@ -307,20 +343,20 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_split_kernel(MlpArgs a) 
     }
 }
 
-template <int LX, int LD, bool VD, class C>
+template <int LX, int LD, bool VD, class C, bool SAVE = false>
 static int launch_split(const MlpArgs &a, int n_frags_used, int n_tiles, hipStream_t s) {
     constexpr int WG_THREADS = C::WAVES * 64, WG_POINTS = C::WAVES * 16;
     using Lay = LayoutSplit<LX, LD, VD>;
     if (n_frags_used != Lay::F_END || n_tiles != Lay::N_TILES) return NERF_AMD_EINVAL;
     const size_t lds = C::RING_BYTES + (size_t)Lay::N_TILES * 16 * sizeof(float);
     static DynamicLdsOptIn opt_in;         // per kernel instantiation, tracks every device (launch_util.h)
-    if (opt_in.ensure(reinterpret_cast<const void *>(mlp_split_kernel<LX, LD, VD, C>), lds) != hipSuccess) return NERF_AMD_EHIP;
+    if (opt_in.ensure(reinterpret_cast<const void *>(mlp_split_kernel<LX, LD, VD, C, SAVE>), lds) != hipSuccess) return NERF_AMD_EHIP;
     int64_t groups = (a.P + WG_POINTS - 1) / WG_POINTS;
     if (groups <= 0) return NERF_AMD_OK;
     if (a.P >= (int64_t)1 << 31) return NERF_AMD_EINVAL;
     const int n_wg = device_cu_count();      // one workgroup per CU walks the tiles
     if (groups > n_wg) groups = n_wg;
-    hipLaunchKernelGGL((mlp_split_kernel<LX, LD, VD, C>), dim3((unsigned)groups), dim3(WG_THREADS), lds, s, a);
+    hipLaunchKernelGGL((mlp_split_kernel<LX, LD, VD, C, SAVE>), dim3((unsigned)groups), dim3(WG_THREADS), lds, s, a);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
 
@@ -341,6 +377,21 @@ int launch_mlp_split(const MlpArgs &a, int multires, int multires_views, int use
     } else if (a.out_ch <= 16) {
         if (multires == 10) return launch_split<10, 0, false, CfgSplit>(a, n_frags_used, n_tiles, s);
         if (multires == 15) return launch_split<15, 0, false, CfgSplit>(a, n_frags_used, n_tiles, s);
+    }
+    return NERF_AMD_EUNSUPPORTED;
+}
+
+// The training forward of the split-precision mode: the same kernel, every layer's (hi, lo) output saved (kernels.h).
+using CfgSplitSave = Ctx<8, 16, 4, 8, 2>;     // the plain pipeline shape, like the bf16 training forward
+
+int launch_mlp_split_save(const MlpArgs &a, int multires, int multires_views, int use_viewdirs, int n_frags_used, int n_tiles,
+                          hipStream_t s) {
+    if (use_viewdirs) {
+        if (multires == 10 && multires_views == 4) return launch_split<10, 4, true, CfgSplitSave, true>(a, n_frags_used, n_tiles, s);
+        if (multires == 15 && multires_views == 6) return launch_split<15, 6, true, CfgSplitSave, true>(a, n_frags_used, n_tiles, s);
+    } else if (a.out_ch <= 16) {
+        if (multires == 10) return launch_split<10, 0, false, CfgSplitSave, true>(a, n_frags_used, n_tiles, s);
+        if (multires == 15) return launch_split<15, 0, false, CfgSplitSave, true>(a, n_frags_used, n_tiles, s);
     }
     return NERF_AMD_EUNSUPPORTED;
 }

@@ -96,13 +96,13 @@ NA_HD inline int frag_source(const FragDesc &d, int lane, int j, int n_out, int 
 // Every packed copy of a model from ONE launch (a re-pack follows every optimizer step of a training loop, where six
 // small launches cost more on the host than on the GPU): block ranges select the job.
 struct PackJobs {
-    const FragDesc *frags_bwd, *frags16, *frags, *frags_split;
+    const FragDesc *frags_bwd, *frags16, *frags, *frags_split, *frags_bwd_split;
     const TileDesc *tiles16, *tiles;
     const LayerF32 *layers;
     const TensorDesc *tensors;
-    uint16_t *stream_bwd, *stream_s16, *stream_bf16, *stream_split;
+    uint16_t *stream_bwd, *stream_s16, *stream_bf16, *stream_split, *stream_bwd_split;
     float *bias_s16, *bias_bf16, *stream_f32, *bias_f32;
-    int n_bwd, n16, n32, n_split, n_tiles16, n_tiles, n_layers;
+    int n_bwd, n16, n32, n_split, n_bwd_split, n_tiles16, n_tiles, n_layers;
     int b_bias16, b_bias32;          // blocks of the two bias tables
 };
 constexpr int PACK_F32_BLOCKS = 32;  // per layer
@@ -130,6 +130,8 @@ __global__ __launch_bounds__(512) void pack_all_kernel(PackJobs J, PtrTable weig
     b -= J.n32;
     if (b < J.n_split) { pack_frag(J.frags_split, b, J.tensors, weights, J.stream_split); return; }
     b -= J.n_split;
+    if (b < J.n_bwd_split) { pack_frag(J.frags_bwd_split, b, J.tensors, weights, J.stream_bwd_split); return; }
+    b -= J.n_bwd_split;
     if (b < J.b_bias16) {            // [tile][16 rows], natural row order
         const int e = b * 512 + threadIdx.x;
         if (e < J.n_tiles16 * 16) {
@@ -172,8 +174,9 @@ int launch_pack(const Program &p, const FragDesc *d_frags, const TileDesc *d_til
                 uint16_t *stream_bf16, float *bias_bf16, float *stream_f32, float *bias_f32,
                 const FragDesc *d_frags16, const TileDesc *d_tiles16, uint16_t *stream_s16, float *bias_s16,
                 const FragDesc *d_frags_bwd, uint16_t *stream_bwd, const FragDesc *d_frags_split, uint16_t *stream_split,
-                hipStream_t s) {
+                const FragDesc *d_frags_bwd_split, uint16_t *stream_bwd_split, hipStream_t s) {
     PackJobs J;
+    J.frags_bwd_split = d_frags_bwd_split; J.stream_bwd_split = stream_bwd_split;
     J.frags_bwd = d_frags_bwd; J.frags16 = d_frags16; J.frags = d_frags; J.frags_split = d_frags_split;
     J.stream_split = stream_split;
     J.tiles16 = d_tiles16; J.tiles = d_tiles; J.layers = d_layers; J.tensors = d_tensors;
@@ -183,12 +186,13 @@ int launch_pack(const Program &p, const FragDesc *d_frags, const TileDesc *d_til
     J.n16 = p.bf16_ok ? (int)p.frags16.size() : 0;
     J.n32 = p.bf16_ok ? (int)p.frags.size() : 0;
     J.n_split = p.bf16_ok ? (int)p.frags_split.size() : 0;
+    J.n_bwd_split = p.bf16_ok ? (int)p.frags_bwd_split.size() : 0;
     J.n_tiles16 = p.bf16_ok ? (int)p.tiles16.size() : 0;
     J.n_tiles = p.bf16_ok ? (int)p.tiles.size() : 0;
     J.n_layers = (int)p.layers.size();
     J.b_bias16 = (J.n_tiles16 * 16 + 511) / 512;
     J.b_bias32 = (J.n_tiles * 32 + 511) / 512;
-    const unsigned grid = (unsigned)(J.n_bwd + J.n16 + J.n32 + J.n_split + J.b_bias16 + J.b_bias32 + J.n_layers * PACK_F32_BLOCKS);
+    const unsigned grid = (unsigned)(J.n_bwd + J.n16 + J.n32 + J.n_split + J.n_bwd_split + J.b_bias16 + J.b_bias32 + J.n_layers * PACK_F32_BLOCKS);
     hipLaunchKernelGGL(pack_all_kernel, dim3(grid), dim3(512), 0, s, J, d_w, d_b);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
@@ -208,13 +212,14 @@ void pack_bf16_host(const Program &p, int shape, const float *const *w, const fl
                     }
         return;
     }
-    if (shape == 18) {       // split-precision stream (fp16 hi / lo fragments); bias table = shape 16's
+    if (shape == 18 || shape == 19) {   // split-precision streams (fp16 hi / lo fragments): 18 forward (bias table = shape 16's), 19 transposed
+        const std::vector<FragDesc> &fr = shape == 18 ? p.frags_split : p.frags_bwd_split;
         if (stream)
-            for (size_t n = 0; n < p.frags_split.size(); ++n)
+            for (size_t n = 0; n < fr.size(); ++n)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 8; ++j) {
                         int row;
-                        const FragDesc &d = p.frags_split[n];
+                        const FragDesc &d = fr[n];
                         const TensorDesc &t = p.tensors[d.tensor];
                         const int col = frag_source(d, lane, j, t.n_out, &row);
                         stream[n * 512 + lane * 8 + j] = pack_value(col < 0 ? 0.0f : w[d.tensor][(int64_t)row * t.n_in + col], d.part);

@@ -153,17 +153,26 @@ int build_program(const nerf_amd_arch &a, Program &p, const char **err) {
             auto add_bwd = [&](int n_in, std::initializer_list<SegT> segs) {
                 for (int t = 0; t < n_in / 16; t += 2)
                     for (const SegT &sg : segs)
-                        for (int ks = 0; ks < sg.nk; ++ks)
+                        for (int ks = 0; ks < sg.nk; ++ks) {
                             for (int u = 0; u < 2; ++u)
                                 p.frags_bwd.push_back({sg.tensor, sg.kind, 16 * (t + u), sg.col_base, ks,
                                                        p.tensors[sg.tensor].n_out, n_in, 0});
+                            for (int part = 1; part <= 2; ++part)
+                                for (int u = 0; u < 2; ++u)
+                                    p.frags_bwd_split.push_back({sg.tensor, sg.kind, 16 * (t + u), sg.col_base, ks,
+                                                                 p.tensors[sg.tensor].n_out, n_in, part});
+                        }
             };
             // encoding-slot rows (ray gradients): n_in = 32 * k-steps of the encoding, L = its multires
             auto add_bwd_enc = [&](int tensor, int col_base, int n_slots, int L, int nk) {
                 for (int t = 0; t < n_slots / 16; t += 2)
-                    for (int ks = 0; ks < nk; ++ks)
+                    for (int ks = 0; ks < nk; ++ks) {
                         for (int u = 0; u < 2; ++u)
                             p.frags_bwd.push_back({tensor, FRAG_TE16, 16 * (t + u), col_base, ks, p.tensors[tensor].n_out, L, 0});
+                        for (int part = 1; part <= 2; ++part)
+                            for (int u = 0; u < 2; ++u)
+                                p.frags_bwd_split.push_back({tensor, FRAG_TE16, 16 * (t + u), col_base, ks, p.tensors[tensor].n_out, L, part});
+                    }
             };
             if (a.use_viewdirs) {
                 add_bwd(W / 2, {SegT{D + 3, FRAG_TG16, 0, 1}});                                // g_hv   <- rgb_linear
@@ -180,6 +189,8 @@ int build_program(const nerf_amd_arch &a, Program &p, const char **err) {
             add_bwd_enc(0, 0, 32 * p.KE16, Lx, W / 32);                                        // g_e    <- pts_linears.0
             p.n_frags_bwd_used = (int)p.frags_bwd.size();
             while (p.frags_bwd.size() % STREAM_PAD_FRAGS) p.frags_bwd.push_back({0, FRAG_ZERO, 0, 0, 0, 0, 0, 0});
+            p.n_frags_bwd_split_used = (int)p.frags_bwd_split.size();
+            while (p.frags_bwd_split.size() % STREAM_PAD_FRAGS) p.frags_bwd_split.push_back({0, FRAG_ZERO, 0, 0, 0, 0, 0, 0});
         }
     }
     return 0;

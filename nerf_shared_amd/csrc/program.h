@@ -159,6 +159,10 @@ struct Program {
     // backward (transposed-weight) stream for the s16 kernel; view-branch (10,4) model only
     std::vector<FragDesc> frags_bwd;
     int n_frags_bwd_used = 0;
+    // the same transposed stream as fp16 (hi, lo) pairs for the split-precision dX chain (mlp_bwd_split.hip): per pair of
+    // tiles and k-step four fragments hi(t0), hi(t1), lo(t0), lo(t1), like frags_split
+    std::vector<FragDesc> frags_bwd_split;
+    int n_frags_bwd_split_used = 0;
     // fp32 generic program
     std::vector<LayerF32> layers;
     int64_t f32_stream_floats = 0, f32_bias_floats = 0;

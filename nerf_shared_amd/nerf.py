@@ -7,10 +7,12 @@ Signatures, attribute names and state_dict keys follow the reference
 with ``load_state_dict`` unchanged.
 
 Inference (torch.no_grad(), or nothing requires grad) runs the forward-only kernels.  With
-gradients enabled, the standard model (D=8, W=256, skips=[4], viewdirs, multires 10/4 or 15/6,
-bf16) runs the training kernels and loss.backward() reaches its parameters, the points / view
-directions and the rays.  Any other model raises NerfAmdError when
-gradients are requested: outputs never silently come back without autograd history.
+gradients enabled, the standard model (D=8, W=256, skips=[4]; viewdirs with multires 10/4 or 15/6, or no
+view branch with multires 10 / 15) runs the training kernels -- in bf16, or in split precision (fp32-class
+gradients) when the model's precision is 'fp32_split' or 'fp32' -- and loss.backward() reaches its parameters,
+the points / view directions and the rays.  Any other architecture renders on the
+forward-only kernels and raises NerfAmdError from backward(): outputs never silently come back without
+autograd history.
 """
 import ctypes
 import weakref
@@ -29,7 +31,10 @@ _default_precision = "bf16"
 
 def set_default_precision(name):
     """'bf16' (fused kernel, bf16 operands / fp32 accumulate; falls back to fp32 for
-    architectures it does not cover) or 'fp32' (exact-fp32 MFMA parity mode)."""
+    architectures it does not cover), 'fp32_split' (fp32-class results from fp16 operand pairs on the 16-bit matrix pipe,
+    forward AND backward; needs every encoded input and hidden activation below 65504 in magnitude -- beyond that the fp16
+    hi part overflows to inf, which then spreads through the output: use 'fp32' for such models) or 'fp32' (exact-fp32
+    MFMA parity mode; trains on the split-precision kernels, NeRF._train_precision)."""
     global _default_precision
     if name not in _PRECISIONS:
         raise ValueError("precision must be one of %s" % sorted(_PRECISIONS))
@@ -104,7 +109,7 @@ class _DeferredGradFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, anchor, msg):
         ctx.msg = msg
-        return x.view_as(x)
+        return x.clone()          # not a view of the input: callers may write into the result in place (rgb.clamp_(), ...)
 
     @staticmethod
     def backward(ctx, g):
@@ -122,18 +127,19 @@ def attach_deferred_grad(out, deferred):
 
 
 class _FieldTrainFn(torch.autograd.Function):
-    """The fused bf16 field with HIP backward kernels: forward saves
+    """The fused field with HIP backward kernels, in bf16 or in split precision (`prec`:
+    _lib.PREC_BF16 / PREC_FP32_SPLIT): forward saves
     every layer's activations in a workspace tensor; backward runs the dX-chain kernel and the
     weight-gradient kernels (nerf_amd_field_backward) and returns gradients for the parameters and,
     when asked, for the points / view directions (explicit-points mode) or the ray batch (rays mode;
     z_vals are constants: the coarse depths depend on near/far only and the fine ones are detached)."""
 
     @staticmethod
-    def forward(ctx, model, pts, viewdirs, rays, z_vals, n_rays, n_samples, *params):
+    def forward(ctx, model, prec, pts, viewdirs, rays, z_vals, n_rays, n_samples, *params):
         dev = params[0].device
         handle = model._model_handle(dev)
         P = n_rays * n_samples
-        nbytes = lib.nerf_amd_train_workspace(handle, P)
+        nbytes = lib.nerf_amd_train_workspace(handle, P, prec)
         if nbytes < 0:
             raise _lib.NerfAmdError("this architecture has no training kernels")
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
@@ -141,9 +147,9 @@ class _FieldTrainFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             _lib.check(lib.nerf_amd_field_forward_train(handle, _lib.ptr(pts), _lib.ptr(viewdirs), _lib.ptr(rays),
                                                         rays.shape[1] if rays is not None else 0, _lib.ptr(z_vals),
-                                                        n_rays, n_samples, raw.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                        n_rays, n_samples, raw.data_ptr(), ws.data_ptr(), ws.numel(), prec,
                                                         _lib.stream_of(dev)), "nerf_amd_field_forward_train")
-        ctx.model, ctx.ws, ctx.R, ctx.S = model, ws, n_rays, n_samples
+        ctx.model, ctx.ws, ctx.R, ctx.S, ctx.prec = model, ws, n_rays, n_samples, prec
         ctx.inputs = (pts, viewdirs, rays, z_vals)
         ctx.pack_key = model._packed_key          # the weights this forward ran on (backward must see the same pack)
         return raw
@@ -168,7 +174,7 @@ class _FieldTrainFn(torch.autograd.Function):
         base = flat.data_ptr()
         wp = (ctypes.c_void_p * n)(*[base + 4 * o for o in sizes[0:n]])
         bp = (ctypes.c_void_p * n)(*[base + 4 * o for o in sizes[n:2 * n]])
-        need_pts, need_vd, need_rays = ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        need_pts, need_vd, need_rays = ctx.needs_input_grad[2], ctx.needs_input_grad[3], ctx.needs_input_grad[4]
         g_pts = torch.empty(R * S, 3, device=dev, dtype=torch.float32) if (pts is not None and need_pts) else None
         g_rays6 = torch.zeros(R, 6, device=dev, dtype=torch.float32) if (rays is not None and need_rays) else None
         g_vd = torch.zeros(R, 3, device=dev, dtype=torch.float32) if (model.use_viewdirs and ((pts is not None and need_vd) or g_rays6 is not None)) else None
@@ -176,7 +182,7 @@ class _FieldTrainFn(torch.autograd.Function):
             _lib.check(lib.nerf_amd_field_backward(model._handle, g.data_ptr(), _lib.ptr(pts), _lib.ptr(viewdirs), _lib.ptr(rays),
                                                    rays.shape[1] if rays is not None else 0, _lib.ptr(z_vals), R, S,
                                                    ws.data_ptr(), ws.numel(), wp, bp, n, _lib.ptr(g_pts), _lib.ptr(g_rays6),
-                                                   _lib.ptr(g_vd), _lib.stream_of(dev)), "nerf_amd_field_backward")
+                                                   _lib.ptr(g_vd), ctx.prec, _lib.stream_of(dev)), "nerf_amd_field_backward")
         ctx.ws = None
         g_rays = None
         if g_rays6 is not None:           # [R, 11] = d/d(o, d, near, far, viewdir); [R, 8] without view branch
@@ -186,7 +192,7 @@ class _FieldTrainFn(torch.autograd.Function):
         for i, shape in enumerate(shapes):
             grads.append(parts[i].view(shape))
             grads.append(parts[n + i])
-        return (None, g_pts, g_vd if (pts is not None and need_vd and g_vd is not None) else None, g_rays, None, None, None) + tuple(grads)
+        return (None, None, g_pts, g_vd if (pts is not None and need_vd and g_vd is not None) else None, g_rays, None, None, None) + tuple(grads)
 
 
 # The packed device copy of a model's weights is refreshed when a parameter's (data_ptr, _version)
@@ -303,7 +309,7 @@ class NeRF(nn.Module):
                            "nerf_amd_model_create")
             self._handle, self._handle_device, self._packed_key = h, device, None
             self._finalizer = weakref.finalize(self, _destroy_handle, h)
-            self.__dict__['_trainable_kernels'] = bool(lib.nerf_amd_model_supports_training(h))
+            self.__dict__['_trainable_kernels'] = bool(lib.nerf_amd_model_supports_training(h, _lib.PREC_BF16))
         return self._handle
 
     def _model_handle(self, device):
@@ -336,8 +342,8 @@ class NeRF(nn.Module):
 
     def _grad_request(self, device, *inputs):
         """("none", None): no gradient is requested (grad mode off, or nothing requires grad) -> forward-only kernels.
-        ("train", None): gradients are requested and the training kernels cover this model (bf16 mode) -> autograd Functions
-        with HIP backward kernels.
+        ("train", None): gradients are requested and the training kernels cover this model -> autograd Functions
+        with HIP backward kernels, in the arithmetic of _train_precision().
         ("defer", (anchor, message)): gradients are requested but the training kernels do not cover this model or precision:
         the call runs on the forward-only kernels and its results are tied to `anchor` by a backward that raises `message`
         (attach_deferred_grad) -- outputs never silently lose their autograd history (the reference's loss.backward(),
@@ -351,16 +357,26 @@ class NeRF(nn.Module):
             return "none", None
         prec = self.precision or _default_precision
         self._ensure_handle(device)
-        if prec == "bf16" and self.__dict__['_trainable_kernels']:
+        if self.__dict__['_trainable_kernels']:
             return "train", None
         msg = ("backward() reached a result of the forward-only kernels: the HIP training kernels cover NeRF(D=8, W=256, skips=[4]) "
                "with use_viewdirs=True and multires/multires_views 10/4 or 15/6, or use_viewdirs=False with multires 10 or 15 and "
-               "output_ch <= 16, in precision 'bf16'; this model is %s(D=%d, W=%d, skips=%s, use_viewdirs=%s, multires=%d, "
+               "output_ch <= 16 (in every precision); this model is %s(D=%d, W=%d, skips=%s, use_viewdirs=%s, multires=%d, "
                "multires_views=%d, output_ch=%d) in precision '%s'.  Gradients were requested when it was evaluated (grad mode on, a "
                "parameter or input requiring grad), so the result was given this backward instead of none; there is no PyTorch fallback"
                % (type(self).__name__, self.D, self.W, list(self.skips), self.use_viewdirs, self.multires,
                   self.multires_views, self.output_ch, prec))
         return "defer", (anchor, msg)
+
+    def _train_precision(self):
+        """Arithmetic of the training kernels for this model's precision: 'bf16' trains in bf16; 'fp32_split' AND 'fp32'
+        train on the split-precision kernels (fp16 operand pairs, three MFMAs per product -- forward, dX chain and weight
+        gradients; gradients agree with fp32 autograd to ~1e-6).  There is no exact-fp32 backward: an 'fp32' model's
+        training forward is the split-precision one (1e-5 from its exact inference forward on |raw| <= 20)."""
+        name = self.precision or _default_precision
+        if name not in _PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(_PRECISIONS))
+        return _lib.PREC_BF16 if name == "bf16" else _lib.PREC_FP32_SPLIT
 
     def _wants_grad(self, device, *inputs):
         """True when the training kernels will run for this call (see _grad_request)."""
@@ -370,7 +386,7 @@ class NeRF(nn.Module):
         """raw [R, S, 4] of rays [R, 11] at depths z_vals [R, S] (pts = o + d z formed in the kernel);
         differentiable with respect to the parameters and the ray batch."""
         R, S = z_vals.shape
-        raw = _FieldTrainFn.apply(self, None, None, rays, z_vals, R, S, *self._train_params())
+        raw = _FieldTrainFn.apply(self, self._train_precision(), None, None, rays, z_vals, R, S, *self._train_params())
         return raw.reshape(R, S, 4 if self.use_viewdirs else self.output_ch)
 
     def _precision_code(self):
@@ -412,7 +428,7 @@ class NeRF(nn.Module):
         out_ch = 4 if self.use_viewdirs else self.output_ch
         n_rays = pts.shape[0] // n_samples
         if want:
-            raw = _FieldTrainFn.apply(self, pts, vd, None, None, n_rays, n_samples, *self._train_params())
+            raw = _FieldTrainFn.apply(self, self._train_precision(), pts, vd, None, None, n_rays, n_samples, *self._train_params())
             return raw.reshape(list(inputs.shape[:-1]) + [out_ch])
         out = torch.empty(pts.shape[0], out_ch, device=dev, dtype=torch.float32)
         with torch.cuda.device(dev):

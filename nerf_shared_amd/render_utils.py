@@ -368,7 +368,17 @@ class Renderer(torch.nn.Module):
                                              R, Nc, int(bool(self.lindisp)), int(self.perturb > 0.), z.data_ptr(), stream),
                        "nerf_amd_coarse_z")
         rays_d = rays[:, 3:6]            # a view: composite gradients with respect to |d| flow back into `rays`
-        raw = coarse_model.forward_rays(rays, z)
+
+        def field(net, zz):
+            # a model that asks for no gradient (frozen, and the rays carry none) keeps its own forward-only kernel and
+            # precision; only models that train go through the training kernels
+            if net._grad_request(dev, rays)[0] == "train":
+                return net.forward_rays(rays, zz)
+            with torch.no_grad():
+                pts = rays[:, None, 0:3] + rays[:, None, 3:6] * zz[:, :, None]      # render_utils.py:131, two rounded ops
+                return net.forward(pts, rays[:, 8:11] if rays.shape[1] > 8 else None)
+
+        raw = field(coarse_model, z)
         rgb, disp, acc, weights, _ = _Raw2OutputsFn.apply(raw, z, rays_d, noise0, bool(self.white_bkgd))
         ret = {}
         if Ni > 0:
@@ -380,7 +390,7 @@ class Renderer(torch.nn.Module):
                                                  z_f.data_ptr(), z_std.data_ptr(), stream), "nerf_amd_resample")
             z = z_f
             net = coarse_model if fine_model is None else fine_model
-            raw = net.forward_rays(rays, z)
+            raw = field(net, z)
             rgb, disp, acc, weights, _ = _Raw2OutputsFn.apply(raw, z, rays_d, noise1, bool(self.white_bkgd))
         ret.update(rgb_map=rgb, disp_map=disp, acc_map=acc)
         if retraw:

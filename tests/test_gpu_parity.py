@@ -747,8 +747,8 @@ def test_sample_counts_beyond_the_lds_are_refused_with_the_real_reason(dev):
 
 def test_gradient_requests_outside_the_training_kernels_raise(dev):
     """main.py:103 calls loss.backward() on whatever render() returned: for a model the HIP training kernels do not cover
-    (precision fp32 / fp32_split, other depths and widths, an output_linear model with a multires the kernels are not
-    instantiated for) a call made with gradients requested renders on the forward-only kernels -- as the reference would
+    (other depths and widths, an output_linear model with a multires the kernels are not instantiated for -- in any
+    precision) a call made with gradients requested renders on the forward-only kernels -- as the reference would
     render it, so inference written without torch.no_grad() works -- and returns results that DO carry autograd history:
     a backward that raises NerfAmdError with the reason.  Nothing comes back silently without history, nothing trains
     silently wrong."""
@@ -756,7 +756,7 @@ def test_gradient_requests_outside_the_training_kernels_raise(dev):
     from nerf_shared_amd._lib import NerfAmdError
     K = synth.lego_intrinsics(40, 40)
     small = dict(D=4, W=128, output_ch=4, skips=[1], use_viewdirs=True, multires=6, multires_views=2)
-    cases = [("fp32 precision", VD, "fp32", True), ("split precision", VD, "fp32_split", True),
+    cases = [("D=4 W=128, fp32", small, "fp32", True), ("no view branch, multires 6, split precision", dict(NOVD, multires=6), "fp32_split", False),
              ("no view branch, multires 6", dict(NOVD, multires=6), "bf16", False), ("D=4 W=128", small, "bf16", True)]
     for label, arch, prec, vd in cases:
         rr = render_utils.Renderer(**dict(BASE, N_samples=16, N_importance=16, use_viewdirs=vd))
@@ -777,6 +777,7 @@ def test_gradient_requests_outside_the_training_kernels_raise(dev):
             assert out.requires_grad and out.grad_fn is not None, (label, i)          # history, not a bare tensor
             if i < 2:
                 assert torch.equal(out.detach(), want["rgb_map"]), (label, i)         # the same kernels, the same values
+            out.clamp_(0.0, 1.0)                                                      # results are no views: in-place ops work
             with pytest.raises(NerfAmdError, match="backward\\(\\) reached a result of the forward-only kernels"):
                 out.sum().backward()
             assert all(p.grad is None for p in m.parameters())
@@ -790,11 +791,13 @@ def test_gradient_requests_outside_the_training_kernels_raise(dev):
             out.sum().backward()
     r = render_utils.Renderer(**dict(BASE, N_samples=16, N_importance=16))
     assert r is not None
-    # the covered models in bf16 keep their history: with the view branch, and the output_linear model that
-    # NeRF() / config_parser.py:50 build by default (use_viewdirs=False)
-    for arch, vd in ((VD, True), (NOVD, False), (dict(D=8, W=256, skips=[4]), False)):
+    # the covered models keep their history in every precision (bf16 kernels, or the split-precision ones for 'fp32_split'
+    # and 'fp32'): with the view branch, and the output_linear model that NeRF() / config_parser.py:50 build by default
+    for arch, vd, prec in ((VD, True, "bf16"), (NOVD, False, "bf16"), (dict(D=8, W=256, skips=[4]), False, "bf16"),
+                           (VD, True, "fp32_split"), (NOVD, False, "fp32_split"), (VD, True, "fp32")):
         torch.manual_seed(5)                  # nn.Linear's own init: fix it, and lift the density bias so that the volume is
         m = nerf.NeRF(**arch).to(dev)         # not empty (sigma <= 0 everywhere means zero gradients, legitimately)
+        m.precision = prec
         with torch.no_grad():
             (m.alpha_linear.bias if vd else m.output_linear.bias[3:4]).add_(1.0)
         rr = render_utils.Renderer(**dict(BASE, N_samples=16, N_importance=16, use_viewdirs=vd))

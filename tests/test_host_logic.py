@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "library does not export %s" % name
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert lib.nerf_amd_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.nerf_amd_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_struct_layouts_match_header():
@@ -231,24 +231,42 @@ def test_gather_rows_gloo_world2(tmp_path):
     assert codes == [0, 0]
 
 
+SHIPPING_CXXFLAGS = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function"      # csrc/Makefile with EXTRA empty
+
+
 def device_isa(stem, tmp_path):
-    """Device assembly of csrc/<stem>.hip: the file the library build left beside the object (csrc/Makefile, -save-temps) when
-    it is newer than the source and every header, else a fresh `hipcc -S` (minutes for the field kernel)."""
+    """Device assembly of csrc/<stem>.hip as the shipping library contains it: the file the library build left beside the
+    object (csrc/Makefile, -save-temps) when (a) the default library is the one under test (no NERF_AMD_LIB override),
+    (b) the flag line recorded beside it is the shipping one (not an EXTRA=-D... scratch build) and (c) it is newer than
+    the source, every header, the Makefile and the experiment includes; else a fresh `hipcc -S` with the shipping flags
+    (minutes for the field kernel)."""
     import shutil
     csrc = os.path.join(REPO, "nerf_shared_amd", "csrc")
     src = os.path.join(csrc, stem + ".hip")
     kept = os.path.join(csrc, "build", stem + "-hip-amdgcn-amd-amdhsa-gfx950.s")
+    flags = os.path.join(csrc, "build", stem + ".flags")
+    exp = os.path.join(REPO, "tools", "experiments")
     deps = [src, os.path.join(csrc, "Makefile")] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")] + \
-           [os.path.join(REPO, "include", "nerf_amd.h")]
-    if os.path.exists(kept) and os.path.getmtime(kept) >= max(os.path.getmtime(d) for d in deps):
+           [os.path.join(REPO, "include", "nerf_amd.h")] + [os.path.join(exp, f) for f in os.listdir(exp) if f.endswith(".inc")]
+    if (not os.environ.get("NERF_AMD_LIB") and os.path.exists(kept) and os.path.exists(flags)
+            and open(flags).read().split() == SHIPPING_CXXFLAGS.split()
+            and os.path.getmtime(kept) >= max(os.path.getmtime(d) for d in deps)):
         return kept
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
     asm = str(tmp_path / (stem + ".s"))
-    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", src, "-o", asm],
+    subprocess.run([hipcc] + SHIPPING_CXXFLAGS.split() + ["--cuda-device-only", "-S", src, "-o", asm],
                    check=True, capture_output=True, timeout=900)
     return asm
+
+
+def test_shipping_flags_are_the_makefiles():
+    """device_isa's idea of the shipping flags is the Makefile's CXXFLAGS with EXTRA empty."""
+    mk = open(os.path.join(REPO, "nerf_shared_amd", "csrc", "Makefile")).read()
+    line = re.search(r"^CXXFLAGS\s*=\s*(.*)$", mk, re.M).group(1)
+    arch = re.search(r"^ARCH\s*\?=\s*(\S+)", mk, re.M).group(1)
+    assert line.replace("$(ARCH)", arch).replace("$(EXTRA)", "").split() == SHIPPING_CXXFLAGS.split()
 
 
 def test_backward_kernel_vmcnt_ledger_matches_its_isa(tmp_path):
@@ -264,6 +282,14 @@ def test_backward_kernel_vmcnt_ledger_matches_its_isa(tmp_path):
         assert stats["kernels"] == 1 and stats["ok"], tag
         assert stats["syncs"] == -(-frags // 16) and stats["dma_pieces"] == 2 * -(-frags // 16), (tag, stats)
         # the checker must be able to fail: claim more stores than the ISA has at every sync
+        assert not check_vmcnt.check(asm, tag, verbose=False, slack=-4)["ok"]
+    # the split-precision dX chain (mlp_bwd_split.hip): fragments = LayoutBS<KE, KD>::F_END, the same ring
+    asm = device_isa("mlp_bwd_split", tmp_path)
+    for tag, frags in (("mlp_bwd_split_kernelILi10ELi4ELb1E", 2368), ("mlp_bwd_split_kernelILi15ELi6ELb1E", 2448),
+                       ("mlp_bwd_split_kernelILi10ELi0ELb0E", 1952)):
+        stats = check_vmcnt.check(asm, tag, verbose=False)
+        assert stats["kernels"] == 1 and stats["ok"], (tag, stats)
+        assert stats["syncs"] == -(-frags // 16) and stats["dma_pieces"] == 2 * -(-frags // 16), (tag, stats)
         assert not check_vmcnt.check(asm, tag, verbose=False, slack=-4)["ok"]
 
 
