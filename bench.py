@@ -35,7 +35,8 @@ The JSON line also carries
                   all cores granted to the process and 1 thread, on bounded samples (N = 1 only).  Its `check`
                   entry is the metric's "PSNR vs ref": the rays of the 4096-ray batch the CPU leg timed, rendered by the
                   bf16 / fp32_split / fp32 modes and compared with the CPU image (PSNR, max |d rgb|, max |d acc|)
-                  on weights whose field has content.
+                  on weights whose field has content; for the fp32-class modes also the per-ray attribution of
+                  tools/precision_census.py (frac_gt_1e-3, unexplained, staged maxima).
 """
 import argparse
 import ctypes
@@ -238,8 +239,10 @@ def cpu_baseline(torch, synth, w, full_c1=True):
         batch = torch.from_numpy(synth.ray_batch_np(ro, rd, cfg.near, cfg.far, True))
         ref_models = [(O.state_dict_to_torch(synth.make_state_dict(sd, CHECK_SHARPEN, **{**ARCH, "skips": (4,)})), O.Arch(**ARCH))
                       for sd in CHECK_SEEDS]
-        res = O.render_rays(cfg, batch, ref_models[0], ref_models[1])
-        out["_check"] = (batch, {k: res[k] for k in ("rgb_map", "acc_map")})
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        import precision_census as PC                      # measurement infrastructure, like the oracle it drives
+        res = PC.oracle_stages(cfg, batch, ref_models[0], ref_models[1])
+        out["_check"] = (batch, res, ref_models, cfg)
     return out
 
 
@@ -499,7 +502,8 @@ def main():
                 # BASELINE.json's metric also says "PSNR vs ref": the 4096-ray batch the CPU leg just rendered (perturb 0, the
                 # bench's own weights), rendered by every GPU mode and compared with the CPU image -- the oracle as checker
                 import math
-                batch, ref = chk
+                batch, ref, ref_models, ocfg = chk
+                import precision_census as PC
                 rr = render_utils.Renderer(**renderer_cfg(w, 0.0))
                 cm = []
                 for seed in CHECK_SEEDS:
@@ -516,12 +520,20 @@ def main():
                     for m in cm:
                         m.precision = prec
                     with torch.no_grad():
-                        o = rr.render_rays(batch.to(dev), cm[0], cm[1])
-                    d = o["rgb_map"].cpu().double() - ref["rgb_map"].double()
+                        o = {k: v.cpu() for k, v in rr.render_rays(batch.to(dev), cm[0], cm[1], retraw=True, retweights=True).items()}
+                    d = o["rgb_map"].double() - ref["rgb_map"].double()
                     mse = float((d ** 2).mean())
                     check["modes"][prec] = {"psnr_db": (-10.0 * math.log10(mse)) if mse > 0 else None,
                                             "max_abs_rgb": float(d.abs().max()),
-                                            "max_abs_acc": float((o["acc_map"].cpu().double() - ref["acc_map"].double()).abs().max())}
+                                            "max_abs_acc": float((o["acc_map"].double() - ref["acc_map"].double()).abs().max())}
+                    if prec != "bf16":
+                        # the fp32-class modes, ray by ray (tools/precision_census.py attribute): what moved against the CPU
+                        # image is what the reference's own conditioning moves -- `unexplained` counts rays beyond 2e-4
+                        # with neither a displaced fine sample nor a flip-prone last sample; `staged_*` are the maxima over
+                        # ALL rays of the differences from the oracle evaluated on the mode's own depths / raw
+                        att = PC.attribute(ocfg, batch, ref_models[0], ref_models[1], o, ref=ref)
+                        check["modes"][prec].update({k: att[k] for k in ("frac_gt_tol", "frac_gt_1e-3", "frac_displaced", "unexplained",
+                                                                         "max_abs_undisplaced", "staged_raw_max", "staged_rgb_max", "staged_acc_max")})
                 cpu["check"] = check
             out["cpu_baseline"] = cpu
         print(json.dumps(out))

@@ -527,7 +527,7 @@ def split_np(x):
     return hi.astype(np.float32), lo.astype(np.float32)
 
 
-def host_pack_split(arch_kwargs, sd):
+def host_pack_split(arch_kwargs, sd, shape=18):
     names = ["pts_linears.%d" % i for i in range(arch_kwargs["D"])]
     names += ["feature_linear", "alpha_linear", "views_linears.0", "rgb_linear"] if arch_kwargs["use_viewdirs"] else ["output_linear"]
     ws = [np.ascontiguousarray(sd[n + ".weight"], np.float32) for n in names]
@@ -538,10 +538,10 @@ def host_pack_split(arch_kwargs, sd):
     wp = (ctypes.c_void_p * n)(*[w.ctypes.data for w in ws])
     bp = (ctypes.c_void_p * n)(*[b.ctypes.data for b in bs])
     nf, nb = ctypes.c_int64(), ctypes.c_int64()
-    _lib.check(lib.nerf_amd_pack_bf16_host(ctypes.byref(arch), 18, wp, bp, n, None, ctypes.byref(nf), None, ctypes.byref(nb)), "size query")
+    _lib.check(lib.nerf_amd_pack_bf16_host(ctypes.byref(arch), shape, wp, bp, n, None, ctypes.byref(nf), None, ctypes.byref(nb)), "size query")
     assert nb.value == 0
     stream = np.zeros(nf.value * 512, np.uint16)
-    _lib.check(lib.nerf_amd_pack_bf16_host(ctypes.byref(arch), 18, wp, bp, n,
+    _lib.check(lib.nerf_amd_pack_bf16_host(ctypes.byref(arch), shape, wp, bp, n,
                                            stream.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)), ctypes.byref(nf), None, None), "pack")
     return stream.view(np.float16).astype(np.float32).reshape(nf.value, 64, 8)
 
@@ -677,3 +677,34 @@ def test_split_stream_matches_kernel_dataflow_at_fp32_accuracy(arch):
     err = np.abs(got - want)
     assert np.abs(want).max() > 1.0
     assert (err <= 0.5 * (1e-4 + 1e-4 * np.abs(want))).all(), (err.max(), (err / (1e-4 + 1e-4 * np.abs(want))).max())
+
+
+@pytest.mark.parametrize("arch", CASES, ids=["vd_10_4", "vd_15_6", "novd_10"])
+def test_backward_split_stream_is_the_backward_stream_as_fp16_pairs(arch):
+    """The transposed stream of the split-precision dX chain (shape 19, mlp_bwd_split.hip) holds the same weights in the same
+    fragment order as the bf16 backward stream (shape 17, replayed by test_backward_stream_matches_kernel_dataflow): per
+    pair of tiles and k-step the two bf16 fragments t0, t1 become hi(t0), hi(t1), lo(t0), lo(t1), and hi + lo / 2^11 is the
+    fp32 weight the bf16 fragment rounds (to 22 bits; the same zero pattern)."""
+    sd = synth.make_state_dict(3, 2.0, **{**arch, "skips": tuple(arch["skips"])})
+    b16, _ = host_pack(arch, sd, 17)
+    sp = host_pack_split(arch, sd, 19)
+    n_used = {(10, 4, True): 1184, (15, 6, True): 1224, (10, 4, False): 976}[(arch["multires"], arch["multires_views"], arch["use_viewdirs"])]
+    assert b16.shape[0] % 192 == 0 and sp.shape[0] % 192 == 0 and sp.shape[0] >= 2 * n_used
+    assert not np.any(sp[2 * n_used:]) and not np.any(b16[n_used:])
+    for m in range(n_used // 2):
+        for u in range(2):
+            hi, lo, want = sp[4 * m + u].astype(np.float64), sp[4 * m + 2 + u].astype(np.float64), b16[2 * m + u].astype(np.float64)
+            val = hi + lo / 2048.0
+            assert np.array_equal(val == 0, want == 0) or np.all(np.abs(val[(val == 0) != (want == 0)]) < 1e-38), m
+            # bf16 keeps 8 bits: the pair's value rounds to the bf16 fragment (or its neighbour on a tie of the last pair bit)
+            assert np.all(np.abs(val - want) <= 2.0 ** -8 * np.abs(val) + 1e-30), (m, u, float(np.abs(val - want).max()))
+    # the pair itself is exact to 2^-21 against the fp32 weight: pts_linears.7's transposed fragment 0 of the g_h(6) layer
+    W = np.asarray(sd["pts_linears.7.weight"], np.float32)
+    KD = gen16_ksteps(arch["multires_views"]) if arch["use_viewdirs"] else 1
+    f_l7 = (144 + 16 * KD + 8 * 36) if arch["use_viewdirs"] else 8 * 4           # LayoutBS::F_L7
+    hi, lo = sp[f_l7].astype(np.float64), sp[f_l7 + 2].astype(np.float64)
+    for l in range(64):
+        for j in range(8):
+            o = 16 * (j >> 2) + 4 * (l >> 4) + (j & 3)                             # acc16_col(ks = 0, q, j): output feature
+            wv = np.float64(W[o, l & 15])                                          # element = W[o][input feature row0 + (l & 15)]
+            assert abs(hi[l, j] + lo[l, j] / 2048.0 - wv) <= 2.0 ** -21 * abs(wv) + 2.0 ** -25, (l, j)

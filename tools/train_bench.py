@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--adam", choices=["foreach", "fused", "amd"], default="amd",
                     help="amd: nerf_shared_amd.optim.Adam (what utils.get_optimizer returns); foreach / fused: torch.optim.Adam")
     ap.add_argument("--tuning", type=int, default=0, help="nerf_amd_set_tuning(0, value): 50 = round-1 weight-gradient kernel")
+    ap.add_argument("--precision", choices=["bf16", "fp32_split", "fp32"], default="bf16",
+                    help="arithmetic of the field and of its backward pass (fp32 trains on the split-precision kernels)")
     ap.add_argument("--cprofile", action="store_true", help="print the host-side profile of the timed steps (cProfile)")
     args = ap.parse_args()
     from nerf_shared_amd import _lib
@@ -37,6 +39,7 @@ def main():
     for seed in (0, 10):
         m = nerf.NeRF(**ARCH)
         m.load_state_dict(synth.torch_state_dict(seed, 1.0, **{**ARCH, "skips": (4,)}))
+        m.precision = args.precision
         models.append(m.to(dev))
     r = render_utils.Renderer(perturb=1.0, N_importance=128, N_samples=64, use_viewdirs=True, white_bkgd=True,
                               raw_noise_std=0.0, near=2.0, far=6.0)
@@ -84,7 +87,7 @@ def main():
     pts = args.rays * 256
     print(json.dumps({"rays_per_step": args.rays, "ms_per_step": dt * 1e3, "steps_per_s": 1 / dt,
                       "host_enqueue_ms_per_step": host * 1e3,
-                      "rays_per_s": args.rays / dt, "loss": float(loss), "adam": args.adam,
+                      "rays_per_s": args.rays / dt, "loss": float(loss), "adam": args.adam, "precision": args.precision,
                       "model_tflops": pts * 1186816 * 3 / dt / 1e12}))
 
 
