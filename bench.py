@@ -388,14 +388,25 @@ def main():
                 collect_profile()
                 _lib.lib.nerf_amd_profile_enable(1)
                 nd.gather_stats(reset=True)
+                nd.enable_diagnostics(dist.is_initialized() and mode == "pixel_ranges")
             t0 = time.perf_counter()
             frames(warmup, steps)
+            torch.cuda.synchronize()
+            own_dt = time.perf_counter() - t0          # this rank's own work is done (before the barrier makes them equal)
             fence()
             dt = time.perf_counter() - t0
             prof = None
             if profile:
                 _lib.lib.nerf_amd_profile_enable(0)
                 prof = collect_profile()
+                if dist.is_initialized() and mode == "pixel_ranges":
+                    # every rank's own account of the timed region (render, the part of the gathers its renders did not
+                    # hide, what rank 0 received): one run explains its own efficiency
+                    mine = dict(nd.diagnostics(), rank=rank, own_ms_per_frame=own_dt / max(1, steps) * 1e3)
+                    per_rank = [None] * world
+                    dist.all_gather_object(per_rank, mine)
+                    run.per_rank = per_rank
+                nd.enable_diagnostics(False)
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -403,6 +414,10 @@ def main():
 
     dt, rays_per_step, prof = run(w, args.perturb, args.steps, args.warmup, profile=True)
     dist_info.update(nd.gather_stats())          # per-frame gathers issued inside the timed region, and by which path
+    if getattr(run, "per_rank", None):
+        pr = run.per_rank
+        dist_info["per_rank"] = pr
+        dist_info["slowest_rank"] = max(pr, key=lambda d: d.get("own_ms_per_frame", 0.0))["rank"]
     cls = {"fp32": 0, "bf16": 1, "fp32_split": 2}[args.precision]
     launches, kern_ms, kern_pts = prof[cls]
 

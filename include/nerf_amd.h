@@ -331,6 +331,14 @@ int nerf_amd_adam_step(int32_t n, float *const *params, const float *const *grad
                        float *const *exp_avg_sq, const int64_t *numel, int64_t step, double lr, double beta1,
                        double beta2, double eps, double weight_decay, void *stream);
 
+/* The same update for a CAPTURED training step (a HIP graph replays the arguments it was captured with, so nothing that
+ * changes per step may be an argument): the step count *step_dev (int64, DEVICE; advanced by one on every execution) and
+ * the learning rate *lr_dev (double, DEVICE; the caller rewrites it between replays for main.py:108-112's decay) live in
+ * device memory; scalars_dev is 2 floats of DEVICE scratch.  n <= 64. */
+int nerf_amd_adam_step_device(int32_t n, float *const *params, const float *const *grads, float *const *exp_avg,
+                              float *const *exp_avg_sq, const int64_t *numel, int64_t *step_dev, const double *lr_dev,
+                              double beta1, double beta2, double eps, double weight_decay, float *scalars_dev, void *stream);
+
 /* ------------------------------------------------------------------------
  * Measurement hook (bench.py): while enabled, every field-MLP launch is
  * bracketed by hipEvents on its own stream.  nerf_amd_profile_collect waits for

@@ -26,7 +26,7 @@ EXPORTS = (
     "nerf_amd_render_batch_workspace", "nerf_amd_render_batch",
     "nerf_amd_profile_enable", "nerf_amd_profile_collect", "nerf_amd_set_tuning",
     "nerf_amd_model_supports_training", "nerf_amd_train_workspace", "nerf_amd_field_forward_train",
-    "nerf_amd_field_backward", "nerf_amd_coarse_z", "nerf_amd_resample", "nerf_amd_get_rays_backward", "nerf_amd_to8b", "nerf_amd_ndc_rays_backward", "nerf_amd_adam_step", "nerf_amd_img2mse", "nerf_amd_img2mse_backward", "nerf_amd_assemble_rays",
+    "nerf_amd_field_backward", "nerf_amd_coarse_z", "nerf_amd_resample", "nerf_amd_get_rays_backward", "nerf_amd_to8b", "nerf_amd_ndc_rays_backward", "nerf_amd_adam_step", "nerf_amd_adam_step_device", "nerf_amd_img2mse", "nerf_amd_img2mse_backward", "nerf_amd_assemble_rays",
 )
 
 
@@ -108,6 +108,8 @@ def _load():
         "nerf_amd_assemble_rays": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p, c_void_p]),
         "nerf_amd_adam_step": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double,
                                c_double, c_double, c_double, c_void_p]),
+        "nerf_amd_adam_step_device": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double,
+                                      c_double, c_double, c_double, c_void_p, c_void_p]),
         "nerf_amd_ndc_rays_backward": (c_int, [c_int32, c_int32, c_double, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_int64, c_void_p, c_void_p, c_void_p]),
         "nerf_amd_profile_enable": (c_int, [c_int]),

@@ -30,8 +30,20 @@ struct AdamTable {
     int n;
 };
 
+// The step-dependent scalars of a CAPTURED step (a HIP graph replays the kernel arguments it was captured with): the step
+// count and the learning rate live in device memory; one thread advances the count and leaves step_size = lr /
+// bias_correction1 and sqrt(bias_correction2) for the update kernel, in double like the host path.
+__global__ void adam_scalars_kernel(int64_t *step, const double *lr, double beta1, double beta2, float *scalars) {
+    const int64_t s = *step + 1;
+    *step = s;
+    const double bc1 = 1.0 - pow(beta1, (double)s), bc2 = 1.0 - pow(beta2, (double)s);
+    scalars[0] = (float)(*lr / bc1);
+    scalars[1] = (float)sqrt(bc2);
+}
+
 __global__ __launch_bounds__(256) void adam_step_kernel(AdamTable T, float step_size, float w1, float beta2, float w2, float eps,
-                                                        float weight_decay, float bc2_sqrt) {
+                                                        float weight_decay, float bc2_sqrt, const float *dev_scalars) {
+    if (dev_scalars) { step_size = dev_scalars[0]; bc2_sqrt = dev_scalars[1]; }
     int t = 0;                                  // uniform per block: scalar search
     while (t + 1 < T.n && (int)blockIdx.x >= T.first_block[t + 1]) ++t;
     const int base = ((int)blockIdx.x - T.first_block[t]) * ADAM_CHUNK;
@@ -56,7 +68,8 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamTable T, float step_
 
 int launch_adam(int n, float *const *params, const float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
                 const int64_t *numel, float step_size, double beta1, double beta2, float eps, float weight_decay,
-                float bc2_sqrt, hipStream_t s) {
+                float bc2_sqrt, hipStream_t s, int64_t *step_dev, const double *lr_dev, float *scalars_dev) {
+    if (scalars_dev) hipLaunchKernelGGL(adam_scalars_kernel, dim3(1), dim3(1), 0, s, step_dev, lr_dev, beta1, beta2, scalars_dev);
     // 1 - beta in double, as torch evaluates the Python scalar (1.0f - 0.999f is off by 5e-5 relative)
     const float w1 = (float)(1.0 - beta1), w2 = (float)(1.0 - beta2);
     for (int t0 = 0; t0 < n; t0 += ADAM_MAX_TENSORS) {
@@ -72,7 +85,7 @@ int launch_adam(int n, float *const *params, const float *const *grads, float *c
         T.first_block[T.n] = blocks;
         if (blocks > 0)
             hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)blocks), dim3(256), 0, s, T, step_size, w1, (float)beta2, w2, eps,
-                               weight_decay, bc2_sqrt);
+                               weight_decay, bc2_sqrt, (const float *)scalars_dev);
     }
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }

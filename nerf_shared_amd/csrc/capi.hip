@@ -868,6 +868,21 @@ int nerf_amd_adam_step(int32_t n, float *const *params, const float *const *grad
     return rc ? fail(rc, "adam launch failed") : NERF_AMD_OK;
 }
 
+int nerf_amd_adam_step_device(int32_t n, float *const *params, const float *const *grads, float *const *exp_avg,
+                              float *const *exp_avg_sq, const int64_t *numel, int64_t *step_dev, const double *lr_dev, double beta1,
+                              double beta2, double eps, double weight_decay, float *scalars_dev, void *stream) {
+    if (n < 0 || !step_dev || !lr_dev || !scalars_dev || (n > 0 && (!params || !grads || !exp_avg || !exp_avg_sq || !numel)))
+        return fail(NERF_AMD_EINVAL, "bad adam arguments");
+    if (n > 64) return fail(NERF_AMD_EINVAL, "adam (device scalars): at most 64 tensors per call (one count advance per call)");
+    for (int i = 0; i < n; ++i) {
+        if (numel[i] < 0 || numel[i] > 0x7fffffff) return fail(NERF_AMD_EINVAL, "adam: tensor size out of range");
+        if (numel[i] > 0 && (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i])) return fail(NERF_AMD_EINVAL, "adam: null tensor pointer");
+    }
+    int rc = na::launch_adam(n, params, grads, exp_avg, exp_avg_sq, numel, 0.0f, beta1, beta2, (float)eps, (float)weight_decay, 1.0f,
+                             static_cast<hipStream_t>(stream), step_dev, lr_dev, scalars_dev);
+    return rc ? fail(rc, "adam launch failed") : NERF_AMD_OK;
+}
+
 int nerf_amd_to8b(const float *x, int64_t n, uint8_t *out, void *stream) {
     if (n < 0 || (n > 0 && (!x || !out))) return fail(NERF_AMD_EINVAL, "bad to8b arguments");
     if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out) & 3))

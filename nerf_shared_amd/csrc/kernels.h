@@ -128,7 +128,7 @@ int launch_assemble_rays(const float *o, const float *d, const float *v, int64_t
 // adam.hip
 int launch_adam(int n, float *const *params, const float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
                 const int64_t *numel, float step_size, double beta1, double beta2, float eps, float weight_decay,
-                float bc2_sqrt, hipStream_t s);
+                float bc2_sqrt, hipStream_t s, int64_t *step_dev = nullptr, const double *lr_dev = nullptr, float *scalars_dev = nullptr);
 
 // render.hip
 struct RenderCfgK {

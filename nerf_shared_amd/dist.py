@@ -27,6 +27,29 @@ def gather_stats(reset=False):
     return out
 
 
+# Per-rank diagnostics of render_poses_gathered (bench.py --gpus N prints them for every rank, so that ONE multi-GPU run
+# explains its own efficiency): timing events around every frame's render on the caller's stream and around every wait of
+# the caller's stream for a gather (the part of the gather the next frames' renders did not hide).
+_DIAG = {"on": False, "frames": [], "waits": [], "recv_bytes": 0}
+
+
+def enable_diagnostics(on=True):
+    _DIAG.update(on=bool(on), frames=[], waits=[], recv_bytes=0)
+
+
+def diagnostics():
+    """After the device is idle (the caller synchronised): {frames, render_ms_per_frame, exposed_gather_ms_per_frame,
+    recv_bytes_per_frame} of this rank since enable_diagnostics().  The waits sit inside later frames' render intervals;
+    render_ms_per_frame has them taken out."""
+    n = len(_DIAG["frames"])
+    if n == 0:
+        return {"frames": 0}
+    wait = sum(a.elapsed_time(b) for a, b in _DIAG["waits"])
+    total = sum(a.elapsed_time(b) for a, b in _DIAG["frames"])
+    return {"frames": n, "render_ms_per_frame": (total - wait) / n, "exposed_gather_ms_per_frame": wait / n,
+            "recv_bytes_per_frame": _DIAG["recv_bytes"] // n}
+
+
 def shard_range(n, rank, world):
     """Contiguous [lo, hi) share of n items for `rank` of `world` (sizes differ by at most 1)."""
     lo = (n * rank) // world
@@ -112,7 +135,14 @@ class OverlappedGather:
     def _complete_oldest(self):
         finish, work, done, _keep = self._pending.pop(0)
         if done is not None:                       # GPU: the caller's stream waits for the side stream's gather
-            torch.cuda.current_stream().wait_event(done)
+            if _DIAG["on"]:
+                pre, post = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                pre.record()
+                torch.cuda.current_stream().wait_event(done)
+                post.record()
+                _DIAG["waits"].append((pre, post))
+            else:
+                torch.cuda.current_stream().wait_event(done)
         elif work is not None:
             work.wait()
         res = finish()
@@ -267,10 +297,19 @@ def render_poses_gathered(renderer, H, W, K, chunk, batch_c2w, coarse_model, fin
             n_done += 1
 
     for c2w in batch_c2w:
+        if _DIAG["on"]:
+            t_a = torch.cuda.Event(enable_timing=True)
+            t_a.record()
         batch = utils.make_ray_batch(H, W, K, c2w, renderer.near, renderer.far, renderer.use_viewdirs, renderer.ndc,
                                      device=dev, pix0=lo, n=hi - lo)
         ret = renderer.render_batch(coarse_model, fine_model, batch, chunk, False)
         gatherer.submit(pack_maps(ret))
+        if _DIAG["on"]:
+            t_b = torch.cuda.Event(enable_timing=True)
+            t_b.record()
+            _DIAG["frames"].append((t_a, t_b))
+            if rank == 0 and world > 1:
+                _DIAG["recv_bytes"] += (H * W - (hi - lo)) * 5 * 4
         if gatherer.ready_count() >= 4:            # hand finished frames on without waiting for the ones in flight
             drain(gatherer.poll_ready())
     drain(gatherer.collect())

@@ -34,6 +34,35 @@ class Adam(torch.optim.Adam):
         # (state[p]["exp_avg"] = ...) needs load_state_dict() or add_param_group() to drop the cached tables; a parameter
         # that moved is noticed by its data_ptr.
         self._together = {}
+        self._device_scalars = None        # enable_device_scalars(): {group index: (step int64[1], lr float64[1], scratch float32[2])}
+
+    # -- captured steps ------------------------------------------------------------
+    def enable_device_scalars(self):
+        """Keep the step count and the learning rate of every group in device memory and let the update read them there
+        (nerf_amd_adam_step_device), so that step() can be captured in a HIP graph and replayed: a replay re-runs the
+        kernels with the arguments they were captured with, and the bias corrections change every step.  Call it after at
+        least one ordinary step (the per-group fast path must be established); from then on step() advances the device
+        count, and whoever replays a captured step calls note_replayed_step() per replay and sync_lr() after changing
+        param_group['lr'] (utils.CapturedTrainStep does both)."""
+        if not self._together or len(self._together) != len(self.param_groups):
+            raise _lib.NerfAmdError("enable_device_scalars(): take one ordinary optimizer step first (every group's parameters "
+                                    "must have gradients and step together)")
+        self._device_scalars = {}
+        for gi, c in self._together.items():
+            dev = c["params"][0].device
+            self._device_scalars[gi] = (torch.full((1,), int(c["step"]), dtype=torch.int64, device=dev),
+                                        torch.full((1,), float(self.param_groups[gi]["lr"]), dtype=torch.float64, device=dev),
+                                        torch.zeros(2, dtype=torch.float32, device=dev))
+
+    def sync_lr(self):
+        """param_group['lr'] (a Python float, main.py:109-112) -> the device copy a captured step reads."""
+        for gi, (_, lr_dev, _) in (self._device_scalars or {}).items():
+            lr_dev.fill_(float(self.param_groups[gi]["lr"]))
+
+    def note_replayed_step(self, n=1):
+        """A captured step() was replayed n times: the host-side counts (state_dict(), checkpoints) follow the device's."""
+        for c in self._together.values():
+            c["step"] += n
 
     # -- torch.optim.Optimizer surface -------------------------------------------
     def __getstate__(self):
@@ -43,6 +72,7 @@ class Adam(torch.optim.Adam):
     def __setstate__(self, state):
         super().__setstate__(state)
         self._together = {}
+        self._device_scalars = None
 
     def state_dict(self):
         self._sync_steps()
@@ -54,10 +84,12 @@ class Adam(torch.optim.Adam):
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self._together = {}
+        self._device_scalars = None
 
     def add_param_group(self, param_group):
         super().add_param_group(param_group)
         self._together = {}
+        self._device_scalars = None
 
     def _sync_steps(self, gi=None):
         for k, c in list(self._together.items()):
@@ -93,9 +125,13 @@ class Adam(torch.optim.Adam):
                 # the same parameters as last time got gradients (a model's unused tensors never do -- the reference's
                 # NeRF(use_viewdirs=False) keeps an idle views_linears.0): one counter, cached tables, one launch
                 c["step"] += 1
-                self._launch(c["params"], [g for g in grads if g is not None], c["tables"], c["step"], group)
+                self._launch(c["params"], [g for g in grads if g is not None], c["tables"], c["step"], group,
+                             None if self._device_scalars is None else self._device_scalars[gi])
                 continue
             # general path: parameters step individually (first step, or the set with gradients changed)
+            if self._device_scalars is not None:
+                raise _lib.NerfAmdError("the set of parameters with gradients changed after enable_device_scalars(): a captured "
+                                        "step covers one fixed set; build a new optimizer / capture")
             if c is not None:
                 self._sync_steps(gi)
                 del self._together[gi]
@@ -140,7 +176,7 @@ class Adam(torch.optim.Adam):
                 (ctypes.c_int64 * n)(*[p.numel() for p in ps]),
                 [self.state[p]["exp_avg"] for p in ps] + [self.state[p]["exp_avg_sq"] for p in ps])   # keep-alive
 
-    def _launch(self, ps, grads, tables, step, group):
+    def _launch(self, ps, grads, tables, step, group, device_scalars=None):
         n = len(ps)
         arr = ctypes.c_void_p * n
         dev = ps[0].device
@@ -153,6 +189,14 @@ class Adam(torch.optim.Adam):
                 keep.append(g)          # alive until the launch is enqueued
             gp.append(g.data_ptr())
         beta1, beta2 = group["betas"]
+        if device_scalars is not None:
+            step_dev, lr_dev, scratch = device_scalars
+            with torch.cuda.device(dev):
+                _lib.check(lib.nerf_amd_adam_step_device(n, arr(*[p.data_ptr() for p in ps]), arr(*gp), tables[0], tables[1], tables[2],
+                                                         step_dev.data_ptr(), lr_dev.data_ptr(), float(beta1), float(beta2),
+                                                         float(group["eps"]), float(group["weight_decay"]), scratch.data_ptr(),
+                                                         _lib.stream_of(dev)), "nerf_amd_adam_step_device")
+            return
         with torch.cuda.device(dev):
             _lib.check(lib.nerf_amd_adam_step(n, arr(*[p.data_ptr() for p in ps]), arr(*gp), tables[0], tables[1], tables[2],
                                               step, float(group["lr"]), float(beta1), float(beta2), float(group["eps"]),

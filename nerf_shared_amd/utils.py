@@ -9,6 +9,7 @@ of the training ray batching (utils.py:360-442).  Dataset loaders are not reprod
 (no datasets offline).
 """
 import ctypes
+import math
 import os
 
 import numpy as np
@@ -278,6 +279,110 @@ def get_optimizer(coarse_model, fine_model, args):
         from . import optim
         return optim.Adam(params=params, lr=args.lrate, betas=(0.9, 0.999))
     return torch.optim.Adam(params=params, lr=args.lrate, betas=(0.9, 0.999))
+
+
+class CapturedTrainStep:
+    """One iteration of the reference's training loop (main.py:77-104: render_from_rays -> img2mse(rgb) [+ img2mse(rgb0)]
+    -> loss.backward() -> optimizer.step()) captured once in a HIP graph and replayed.
+
+    The eager step costs about a hundred kernel launches; at the reference's batch size (N_rand = 1024) Python and the
+    runtime spend as long enqueueing them as the GPU spends executing them.  A replay is one call.  What keeps the loop's
+    semantics between replays:
+      * rays / target are copied into the capture's input buffers on every call (any N_rand-ray batch of the same shape);
+      * the learning rate is read from device memory: change optimizer.param_groups[i]['lr'] as main.py:108-112 does and the
+        next call picks it up; the optimizer's step count advances on the device and is mirrored on the host;
+      * gradients are left in `.grad` after every call (the captured step starts from zeroed gradients, like
+        optimizer.zero_grad() at the top of the loop body);
+      * random draws (perturb, raw_noise_std) advance with every replay (torch's graph-safe generator offsets).
+    Everything the step touches must stay alive and in place (models, optimizer state).  Needs nerf_shared_amd.optim.Adam
+    (utils.get_optimizer) and models the training kernels cover.  Constructing it leaves parameters, moments and step
+    counts as they were (the warm-up steps the capture needs are undone).
+
+        step = utils.CapturedTrainStep(renderer, H, W, K, chunk, coarse, fine, optimizer, N_rand)
+        for i in range(n_iters):
+            rays, target = sample_random_ray_batch(...)          # [2, N_rand, 3], [N_rand, 3]
+            loss = step(rays, target)                            # device scalar; step.psnr likewise
+            for g in optimizer.param_groups: g['lr'] = new_lrate
+    """
+
+    def __init__(self, renderer, H, W, K, chunk, coarse_model, fine_model, optimizer, n_rays, warmup=3):
+        from . import optim
+        if not isinstance(optimizer, optim.Adam):
+            raise _lib.NerfAmdError("CapturedTrainStep needs nerf_shared_amd.optim.Adam (utils.get_optimizer): torch's optimizers "
+                                    "pass step-dependent scalars as kernel arguments, which a graph would freeze")
+        dev = next(coarse_model.parameters()).device
+        self.renderer, self.models, self.optimizer = renderer, (coarse_model, fine_model), optimizer
+        self.args = (H, W, K, chunk)
+        self.rays = torch.zeros(2, n_rays, 3, device=dev)
+        self.rays[1, :, 2] = -1.0                     # a valid placeholder batch for the warm-up (zero directions have no unit vector)
+        self.target = torch.full((n_rays, 3), 0.5, device=dev)
+        self.params = [p for g in optimizer.param_groups for p in g["params"]]
+        self.loss = self.psnr = None
+        self._lr = None
+        # Constructing the object must not train: the warm-up steps (which the capture needs -- lazy allocations, the
+        # optimizer's per-group fast path) run on the placeholder batch, and parameters, moments and step counts are put
+        # back afterwards.
+        with torch.no_grad():
+            snap_p = [p.detach().clone() for p in self.params]
+            snap_s = {p: {k: (v.detach().clone() if isinstance(v, torch.Tensor) else v) for k, v in optimizer.state[p].items()}
+                      for p in self.params if len(optimizer.state.get(p, {})) > 0}
+        optimizer._sync_steps()
+        steps_before = {gi: c["step"] for gi, c in optimizer._together.items()}
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for i in range(max(1, warmup)):          # (the first step also establishes the optimizer's per-group fast path)
+                self._body()
+                if i == 0:
+                    optimizer.enable_device_scalars()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        for m in self.models:
+            if m is not None:
+                m.weights_changed()                   # the re-pack of the parameters belongs inside the captured step
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._body()
+        with torch.no_grad():
+            for p, s0 in zip(self.params, snap_p):
+                p.copy_(s0)
+            for p in self.params:
+                st = optimizer.state[p]
+                if p in snap_s:
+                    st["exp_avg"].copy_(snap_s[p]["exp_avg"])
+                    st["exp_avg_sq"].copy_(snap_s[p]["exp_avg_sq"])
+                elif len(st) > 0:
+                    st["exp_avg"].zero_()
+                    st["exp_avg_sq"].zero_()
+                if p.grad is not None:
+                    p.grad.zero_()                    # (the capture's gradient tensors stay attached: replays fill them)
+        for gi, c in optimizer._together.items():
+            c["step"] = steps_before.get(gi, int(snap_s[c["params"][0]]["step"]) if c["params"][0] in snap_s else 0)
+            optimizer._device_scalars[gi][0].fill_(c["step"])
+
+    def _body(self):
+        H, W, K, chunk = self.args
+        coarse, fine = self.models
+        for p in self.params:
+            p.grad = None
+        rgb, disp, acc, extras = self.renderer.render_from_rays(H, W, K, chunk, self.rays, coarse, fine, retraw=True)
+        loss = img2mse(rgb, self.target)
+        self.psnr = -10. * torch.log(loss.detach()) / math.log(10.)       # mse2psnr without its host-side constant tensor
+        if 'rgb0' in extras:
+            loss = loss + img2mse(extras['rgb0'], self.target)
+        loss.backward()
+        self.optimizer.step()
+        self.loss = loss.detach()
+
+    def __call__(self, rays, target):
+        self.rays.copy_(rays if isinstance(rays, torch.Tensor) else torch.stack(list(rays), 0), non_blocking=True)
+        self.target.copy_(target, non_blocking=True)
+        lr = tuple(float(g["lr"]) for g in self.optimizer.param_groups)
+        if lr != self._lr:
+            self.optimizer.sync_lr()
+            self._lr = lr
+        self.graph.replay()
+        self.optimizer.note_replayed_step()
+        return self.loss
 
 
 def save_checkpoints(args, coarse_model, fine_model, optimizer, global_step, i):

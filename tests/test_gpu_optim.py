@@ -3,6 +3,7 @@ main.py:104) as one launch, against torch.optim.Adam on the same gradients."""
 import copy
 import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -205,3 +206,72 @@ def test_render_rays_argument_batch_assembly(dev, use_viewdirs, ndc):
     fused, ref = captured
     assert fused.shape == ref.shape == (H * W, 11 if use_viewdirs else 8)
     assert torch.equal(fused, ref)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32_split"])
+def test_captured_train_step_equals_the_eager_loop(dev, precision):
+    """utils.CapturedTrainStep: the body of main.py:77-104 captured in a HIP graph and replayed -- with a new batch and the
+    loop's learning-rate decay (main.py:108-112) between replays -- follows the same loop run eagerly: the same losses, the
+    same parameters afterwards, the same optimizer step count (deterministic renderer: perturb 0, so the two see the same
+    draws), and gradients are left in .grad after every call."""
+    from nerf_shared_amd import nerf, optim, render_utils, synth, utils
+    arch = dict(D=8, W=256, output_ch=5, skips=[4], use_viewdirs=True, multires=10, multires_views=4)
+    cfg = dict(perturb=0.0, N_importance=32, N_samples=32, use_viewdirs=True, white_bkgd=True, raw_noise_std=0.0, near=2.0, far=6.0)
+    K = synth.lego_intrinsics(400, 400)
+    rng = np.random.default_rng(5)
+    N, steps = 256, 9
+    batches = []
+    for _ in range(steps + 3):
+        idx = rng.choice(160000, size=N, replace=False)
+        ro, rd = synth.rays_np(400, 400, K, synth.LEGO_C2W, idx)
+        batches.append((torch.from_numpy(np.stack([ro, rd], 0)).to(dev), torch.from_numpy(rng.uniform(0, 1, size=(N, 3)).astype(np.float32)).to(dev)))
+
+    def fresh():
+        ms = []
+        for seed in (0, 10):
+            m = nerf.NeRF(**arch)
+            m.load_state_dict(synth.torch_state_dict(seed, 1.0, **{**arch, "skips": (4,)}))
+            m.precision = precision
+            ms.append(m.to(dev))
+        return ms, optim.Adam(list(ms[0].parameters()) + list(ms[1].parameters()), lr=5e-4, betas=(0.9, 0.999))
+
+    lr_at = lambda i: 5e-4 * (0.1 ** (i / 20.0))           # noqa: E731  (a fast decay, so that a frozen lr would show)
+    r = render_utils.Renderer(**cfg)
+    # eager loop: 3 warm-up steps on batches 0-2 (what the capture's constructor does on its zero buffers is replaced below)
+    (mc, mf), opt = fresh()
+    eager = []
+    for i in range(steps):
+        for g in opt.param_groups:
+            g["lr"] = lr_at(i)
+        opt.zero_grad()
+        rays, tgt = batches[i]
+        rgb, _, _, ex = r.render_from_rays(400, 400, K, 32768, rays, mc, mf, retraw=True)
+        loss = utils.img2mse(rgb, tgt) + utils.img2mse(ex["rgb0"], tgt)
+        loss.backward()
+        opt.step()
+        eager.append(float(loss))
+    # captured loop: constructing the step leaves the training state untouched
+    (gc, gf), gopt = fresh()
+    start = [p.detach().clone() for p in list(gc.parameters()) + list(gf.parameters())]
+    step = utils.CapturedTrainStep(r, 400, 400, K, 32768, gc, gf, gopt, N)
+    assert all(torch.equal(p, s0) for p, s0 in zip(list(gc.parameters()) + list(gf.parameters()), start))
+    assert gopt._together[0]["step"] == 0 and all(not st["exp_avg"].any() for st in gopt.state.values())
+    got = []
+    for i in range(steps):
+        for g in gopt.param_groups:
+            g["lr"] = lr_at(i)
+        loss = step(*batches[i])
+        got.append(float(loss))
+        assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in gc.parameters())
+    print("eager   ", ["%.6f" % v for v in eager])
+    print("captured", ["%.6f" % v for v in got])
+    np.testing.assert_allclose(got, eager, rtol=2e-5)
+    for a, b in zip(list(gc.parameters()) + list(gf.parameters()), list(mc.parameters()) + list(mf.parameters())):
+        assert float((a - b).norm() / b.norm().clamp_min(1e-30)) < (2e-3 if precision == "bf16" else 2e-5)
+    assert gopt._together[0]["step"] == steps == int(gopt.state_dict()["state"][0]["step"])
+    assert np.isfinite(float(step.psnr))
+    # inference after the captured steps sees the updated weights (the pack is marked stale by every replay)
+    with torch.no_grad():
+        a = r.render_from_rays(400, 400, K, 32768, batches[0][0], gc, gf, retraw=False)[0]
+        b = r.render_from_rays(400, 400, K, 32768, batches[0][0], mc, mf, retraw=False)[0]
+    assert float((a - b).abs().max()) < (5e-2 if precision == "bf16" else 1e-3)

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--tuning", type=int, default=0, help="nerf_amd_set_tuning(0, value): 50 = round-1 weight-gradient kernel")
     ap.add_argument("--precision", choices=["bf16", "fp32_split", "fp32"], default="bf16",
                     help="arithmetic of the field and of its backward pass (fp32 trains on the split-precision kernels)")
+    ap.add_argument("--graph", action="store_true", help="utils.CapturedTrainStep: the step captured in a HIP graph and replayed")
     ap.add_argument("--cprofile", action="store_true", help="print the host-side profile of the timed steps (cProfile)")
     args = ap.parse_args()
     from nerf_shared_amd import _lib
@@ -64,6 +65,18 @@ def main():
         opt.step()
         return loss
 
+    if args.graph:
+        if args.adam != "amd":
+            raise SystemExit("--graph needs --adam amd")
+        captured = utils.CapturedTrainStep(r, 400, 400, K, 32768, models[0], models[1], opt, args.rays)
+        rays_t = torch.stack(list(rays), 0)
+
+        def step():                                  # noqa: F811  (one replay + the loop's LR decay, main.py:108-112)
+            loss = captured(rays_t, target)
+            for g in opt.param_groups:
+                g["lr"] = 5e-4 * (0.1 ** (captured.optimizer._together[0]["step"] / 250000.0))
+            return loss
+
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -87,7 +100,7 @@ def main():
     pts = args.rays * 256
     print(json.dumps({"rays_per_step": args.rays, "ms_per_step": dt * 1e3, "steps_per_s": 1 / dt,
                       "host_enqueue_ms_per_step": host * 1e3,
-                      "rays_per_s": args.rays / dt, "loss": float(loss), "adam": args.adam, "precision": args.precision,
+                      "rays_per_s": args.rays / dt, "loss": float(loss), "adam": args.adam, "precision": args.precision, "graph": bool(args.graph),
                       "model_tflops": pts * 1186816 * 3 / dt / 1e12}))
 
 
