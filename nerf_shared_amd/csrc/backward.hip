@@ -46,6 +46,7 @@ struct DwArgs {
     const uint16_t *H;                   // head gradients transposed inside 32-point chunks (kernels.h g_rawt), or NULL
     // split-precision products (dw2s_body): the planes of fp16 lo rows of G, X and H (the pointers above are the hi planes)
     const uint16_t *G_lo, *X_lo, *H_lo;
+    int blocked;                         // A/B (nerf_amd_set_tuning(0, 59)): a workgroup takes a contiguous range of chunks instead of every nwg-th
 };
 
 struct DwReduceArgs {
@@ -347,11 +348,14 @@ __device__ __forceinline__ void dw2_body(const DwArgs &a, const int wg, const in
     const uint32_t ring = (uint32_t)(uintptr_t)smem;
 
     const int64_t n_chunks = (a.P + 31) / 32;
-    const int64_t n_local = wg < n_chunks ? (n_chunks - wg + nwg - 1) / nwg : 0;     // chunks wg, wg + nwg, ...
+    const int64_t per = (n_chunks + nwg - 1) / nwg;
+    const int64_t first = a.blocked ? wg * per : wg, stride = a.blocked ? 1 : nwg;
+    const int64_t n_local = a.blocked ? (first < n_chunks ? (n_chunks - first < per ? n_chunks - first : per) : 0)
+                                      : (wg < n_chunks ? (n_chunks - wg + nwg - 1) / nwg : 0);     // chunks wg, wg + nwg, ... (or a contiguous range)
     // this wave's DMA instructions of a chunk: j = wave, wave + 8, ... (indices past NI repeat the last one: every wave
     // issues exactly CNT, which keeps the counted waits compile-time constants)
     auto issue_chunk = [&](int64_t i) {
-        int64_t ch = wg + i * nwg;
+        int64_t ch = first + i * stride;
         if (ch >= n_chunks) ch = n_chunks - 1;                  // past the end: a harmless re-read that is never consumed
         const uint32_t slot = ring + (uint32_t)(i % NS) * IMG;
         const int64_t p0 = ch * 32;
@@ -398,7 +402,7 @@ __device__ __forceinline__ void dw2_body(const DwArgs &a, const int wg, const in
             else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * CNT) : "memory");
             issue_chunk(i + NS - 1);
             const uint32_t gimg = ring + (uint32_t)(i % NS) * IMG, ximg = gimg + 32 * RG;
-            const int64_t ch = wg + i * nwg;
+            const int64_t ch = first + i * stride;
             if (ch == n_chunks - 1 && (a.P & 31)) {             // the last chunk: rows past P hold the padding points' data
                 const int first = (int)(a.P & 31);
                 for (int e = tid; e < (32 - first) * (RG + RX) / 16; e += 512) {
@@ -1272,6 +1276,7 @@ static int weight_grad(DwSeq &s, int64_t P, float *slab, const uint16_t *X, int 
     DwReduceArgs r;
     r.slab = slab; r.n_slabs = 0; r.OT = 0; r.IT = 0;
     a.G_lo = a.X_lo = a.H_lo = nullptr; r.inv_scale = nullptr;
+    a.blocked = g_variant == 59 ? 1 : 0;
     r.HT = head ? 1 : 0; r.head_dW = head ? head->dW : nullptr; r.head_db = head ? head->db : nullptr;
     r.head_row0 = head ? head->row0 : 0; r.head_rows = head ? head->rows : 0; r.head_ld = head ? head->ld : 0;
     if (head && !(s.multi && n_out_slots == 256 && n_in_slots == 256)) return NERF_AMD_EINVAL;
@@ -1292,7 +1297,7 @@ static int head_grad(DwSeq &s, int64_t P, const uint16_t *X, int n_in_slots, int
     if (!s.multi || n_in_slots != 128 || s.mj.n >= DW_MAX_JOBS) return NERF_AMD_EINVAL;
     DwJob &J = s.mj.job[s.mj.n];
     J.a.G = nullptr; J.a.ldg = 0; J.a.X = X; J.a.ldx = n_in_slots; J.a.P = P; J.a.slab = nullptr; J.a.H = head.H;
-    J.a.G_lo = J.a.X_lo = J.a.H_lo = nullptr;
+    J.a.G_lo = J.a.X_lo = J.a.H_lo = nullptr; J.a.blocked = 0;
     J.shape = 5;
     DwReduceArgs &r = s.mr.r[s.mj.n];
     r.slab = nullptr; r.n_slabs = 0; r.OT = 0; r.IT = n_in_slots / 16;
@@ -1472,7 +1477,7 @@ static int train_param_grads_split(const Program &p, int64_t P, const TrainWs &w
         if (shape < 0 || (head && shape != 4 && shape != 5)) { rc = NERF_AMD_EUNSUPPORTED; return; }
         DwJob &J = mj.job[mj.n];
         J.a.G = G.hi; J.a.G_lo = G.lo; J.a.ldg = n_out_slots; J.a.X = X.hi; J.a.X_lo = X.lo; J.a.ldx = n_in_slots; J.a.P = P;
-        J.a.slab = nullptr; J.a.H = head ? w.g_rawt : nullptr; J.a.H_lo = head ? w.g_rawt_lo : nullptr;
+        J.a.slab = nullptr; J.a.H = head ? w.g_rawt : nullptr; J.a.H_lo = head ? w.g_rawt_lo : nullptr; J.a.blocked = 0;
         J.shape = shape;
         DwReduceArgs &r = mr.r[mj.n];
         r.slab = nullptr; r.n_slabs = 0; r.OT = OT; r.IT = IT;

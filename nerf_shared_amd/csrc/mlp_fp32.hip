@@ -81,7 +81,7 @@ __global__ __launch_bounds__(512) void mlp_f32_kernel(MlpArgs a) {
     const int64_t p0 = (int64_t)blockIdx.x * PTS;
     const int n_in_rows = a.input_ch + a.input_ch_views;
     for (int i = tid; i < n_in_rows * PTS; i += 512) {
-        const int row = i >> (HALVES == 2 ? 6 : 5), q = i & (PTS - 1);
+        const int row = i / PTS, q = i - row * PTS;
         int64_t p = p0 + q;
         if (p >= a.P) p = a.P - 1;
         const int64_t ray = (int64_t)((uint32_t)p / (uint32_t)a.S);
@@ -123,42 +123,46 @@ __global__ __launch_bounds__(512) void mlp_f32_kernel(MlpArgs a) {
             // only reads rows the previous layer's trailing barrier published and writes to global memory; the next
             // layer's first barrier (which wave 0 joins after its own tile) still precedes any overwrite of those rows.
             if (wave == 0) {
-                // accumulators start at the bias, like every other layer of the chain and like this head in the widest
-                // instantiation (D register i = output row i; the bias table is zero-padded past n_out)
-                f32x4 d0 = *reinterpret_cast<const f32x4 *>(a.bias_f32 + L.bias_off);
-                f32x4 d1 = *reinterpret_cast<const f32x4 *>(a.bias_f32 + L.bias_off + 4);
-                const float *xcol = act + L.in_row * PTS + (lane & (PTS - 1));   // HALVES = 1: lanes 32..63 repeat 0..31
                 const float *wrow = a.stream_f32 + L.frag_off + 4 * (lane & 3);        // rows 0..3 of tile 0; rows 4..7 are 16 floats on
                 const int groups8 = (L.n_in + 7) >> 3;
                 const bool two = L.n_out > 4;
-                for (int g = 0; g < groups8; ++g) {
-                    const f32x4 we = *reinterpret_cast<const f32x4 *>(wrow + g * 256);          // W[o][8g + 0, 2, 4, 6]
-                    const f32x4 wo = *reinterpret_cast<const f32x4 *>(wrow + g * 256 + 128);    // W[o][8g + 1, 3, 5, 7]
-                    f32x4 we2 = we, wo2 = wo;
-                    if (two) {
-                        we2 = *reinterpret_cast<const f32x4 *>(wrow + g * 256 + 16);
-                        wo2 = *reinterpret_cast<const f32x4 *>(wrow + g * 256 + 128 + 16);
-                    }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {              // k = 8g + 2i, 8g + 2i + 1 (columns past n_in are zero in the stream)
-                        const float x0 = xcol[(8 * g + 2 * i) * PTS], x1 = xcol[(8 * g + 2 * i + 1) * PTS];
-                        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(we[i], x0, d0, 0, 0, 0);
-                        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wo[i], x1, d0, 0, 0, 0);
+                for (int pg = 0; pg < (PTS + 63) / 64; ++pg) {                         // 64 points per pass (three halves: two passes)
+                    // accumulators start at the bias, like every other layer of the chain and like this head in the widest
+                    // instantiation (D register i = output row i; the bias table is zero-padded past n_out)
+                    f32x4 d0 = *reinterpret_cast<const f32x4 *>(a.bias_f32 + L.bias_off);
+                    f32x4 d1 = *reinterpret_cast<const f32x4 *>(a.bias_f32 + L.bias_off + 4);
+                    const int q = 64 * pg + lane;                                      // this lane's point of the workgroup
+                    const float *xcol = act + L.in_row * PTS + (q < PTS ? q : q - 32);  // lanes past the last point repeat real ones
+                    for (int g = 0; g < groups8; ++g) {
+                        const f32x4 we = *reinterpret_cast<const f32x4 *>(wrow + g * 256);          // W[o][8g + 0, 2, 4, 6]
+                        const f32x4 wo = *reinterpret_cast<const f32x4 *>(wrow + g * 256 + 128);    // W[o][8g + 1, 3, 5, 7]
+                        f32x4 we2 = we, wo2 = wo;
                         if (two) {
-                            d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(we2[i], x0, d1, 0, 0, 0);
-                            d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wo2[i], x1, d1, 0, 0, 0);
+                            we2 = *reinterpret_cast<const f32x4 *>(wrow + g * 256 + 16);
+                            wo2 = *reinterpret_cast<const f32x4 *>(wrow + g * 256 + 128 + 16);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {              // k = 8g + 2i, 8g + 2i + 1 (columns past n_in are zero in the stream)
+                            const float x0 = xcol[(8 * g + 2 * i) * PTS], x1 = xcol[(8 * g + 2 * i + 1) * PTS];
+                            d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(we[i], x0, d0, 0, 0, 0);
+                            d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wo[i], x1, d0, 0, 0, 0);
+                            if (two) {
+                                d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(we2[i], x0, d1, 0, 0, 0);
+                                d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wo2[i], x1, d1, 0, 0, 0);
+                            }
                         }
                     }
-                }
-                const int64_t p = p0 + lane;
-                if (lane < PTS && p < a.P) {
+                    const int64_t p = p0 + q;
+                    if (q < PTS && p < a.P) {
 #pragma unroll
-                    for (int o = 0; o < 8; ++o)
-                        if (o < L.n_out) {
-                            float v = o < 4 ? d0[o & 3] : d1[o & 3];
-                            if (L.relu) v = fmaxf(v, 0.0f);
-                            a.out[(int64_t)a.out_ch * p + L.out_col + o] = v;
-                        }
+                        for (int o = 0; o < 8; ++o)
+                            if (o < L.n_out) {
+                                float v = o < 4 ? d0[o & 3] : d1[o & 3];
+                                if (L.relu) v = fmaxf(v, 0.0f);
+                                a.out[(int64_t)a.out_ch * p + L.out_col + o] = v;
+                            }
+                    }
                 }
             }
             continue;
@@ -237,9 +241,14 @@ int launch_mlp_f32(const MlpArgs &a, hipStream_t s) {
     if (a.P <= 0) return NERF_AMD_OK;
     if (a.P >= (int64_t)1 << 31) return NERF_AMD_EINVAL;
     if (a.W > 8 * F32_MAX_TILES_PER_WAVE * 32) return NERF_AMD_EUNSUPPORTED;
-    // 64 points per workgroup while the activation rows fit the CU's LDS, 32 for the widest models (build_program bounds the rows)
+    // 64 points per workgroup while the activation rows fit the CU's LDS, 32 for the widest models (build_program bounds the
+    // rows).  nerf_amd_set_tuning(0, 61) = A/B: 96 points (three 32-point column halves, every weight fragment fetched from
+    // L2 feeds three MFMAs per k) where the rows fit -- measured in round 4 (tools/micro/f32_pts_ab.py, same process,
+    // bit-identical outputs): 106.0 TFLOP/s against 114.6 for 64 points, i.e. weight delivery per point is NOT what holds
+    // this kernel at 0.73 of its peak.
     const bool half = (size_t)a.lds_rows * 64 * sizeof(float) > 160 * 1024;
-    const int pts = half ? 32 : 64;
+    const bool three = !half && g_variant == 61 && (size_t)a.lds_rows * 96 * sizeof(float) <= 160 * 1024 && (a.W > a.out_ch ? a.W : a.out_ch) <= 256;
+    const int pts = half ? 32 : three ? 96 : 64;
     const size_t lds = (size_t)a.lds_rows * pts * sizeof(float);
     if (lds > 160 * 1024) return NERF_AMD_EUNSUPPORTED;
     const int64_t blocks = (a.P + pts - 1) / pts;
@@ -256,6 +265,7 @@ int launch_mlp_f32(const MlpArgs &a, hipStream_t s) {
         if (widest <= 512) return go(integral_constant<int, 2>{}, integral_constant<int, 1>{});
         return go(integral_constant<int, F32_MAX_TILES_PER_WAVE>{}, integral_constant<int, 1>{});
     }
+    if (three) return go(integral_constant<int, 1>{}, integral_constant<int, 3>{});
     if (widest <= 256) return go(integral_constant<int, 1>{}, integral_constant<int, 2>{});
     if (widest <= 512) return go(integral_constant<int, 2>{}, integral_constant<int, 2>{});
     return go(integral_constant<int, F32_MAX_TILES_PER_WAVE>{}, integral_constant<int, 2>{});

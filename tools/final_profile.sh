@@ -2,7 +2,7 @@
 # Round-end measurement pass on the GPU box: the bench line and the rocprofv3 summaries that go under profiles/.
 #   tools/final_profile.sh <tag>      -> gpurun_out/final_<tag>/...
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/final_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -17,8 +17,15 @@ for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUS
   N=$(echo $C | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$N -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_$N.json 2> $OUT/pmc_$N.err || echo "pmc pass $N failed"
 done
-# the training step: the timed line, then the kernel stats and the timeline of two steps under the profiler
+# the training step: the timed lines -- eager and captured (utils.CapturedTrainStep), bf16 and split precision --
+# then the kernel stats and the timeline of two steps under the profiler
 python tools/train_bench.py --steps 300 > $OUT/train_bench.json 2> $OUT/train_bench.err || echo "train bench failed"
+python tools/train_bench.py --steps 300 --graph > $OUT/train_bench_graph.json 2> $OUT/train_bench_graph.err || echo "train bench (graph) failed"
+python tools/train_bench.py --steps 200 --precision fp32_split > $OUT/train_bench_split.json 2> $OUT/train_bench_split.err || echo "train bench (split) failed"
+python tools/train_bench.py --steps 200 --precision fp32_split --graph > $OUT/train_bench_split_graph.json 2> $OUT/train_bench_split_graph.err || echo "train bench (split, graph) failed"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_split -- python3 tools/train_bench.py --steps 50 --precision fp32_split > $OUT/train_split_under_rocprof.json 2> $OUT/train_split.err || echo "split train profile failed"
+cp $OUT/train_split/*/*_kernel_stats.csv $OUT/train_split_kernel_stats.csv
+rm -rf $OUT/train_split
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train -- python3 tools/train_bench.py --steps 50 > $OUT/train_under_rocprof.json 2> $OUT/train.err || echo "train profile failed"
 cp $OUT/train/*/*_kernel_stats.csv $OUT/train_kernel_stats.csv
 python tools/step_timeline.py $(find $OUT/train -name "*kernel_trace.csv" | head -1) > $OUT/train_timeline.txt
