@@ -100,19 +100,23 @@ def test_field_backward_matches_fp32_autograd(dev, seed, sharpen, arch, precisio
     assert_table(table)
 
 
-def oracle_two_pass(cfg, batch, coarse, fine, z_fine):
+def oracle_two_pass(cfg, batch, coarse, fine, z_fine, pytest_draws=False):
     """The oracle's render_rays (render_utils.py:67-174) with the fine pass evaluated on given depths: rgb0 from the coarse
-    pass, rgb_map from `fine` at z_fine.  batch [N, 11] may carry autograd history."""
+    pass, rgb_map from `fine` at z_fine.  batch [N, 8|11] may carry autograd history.  pytest_draws: the reference's seeded
+    jitter / sigma-noise draws (render_utils.py:124-127, :267-270), as Renderer.render_rays(pytest=True) makes them."""
     rc = O.RenderCfg(**cfg)
+    n = batch.shape[0]
     rays_o, rays_d, viewdirs = batch[:, 0:3], batch[:, 3:6], (batch[:, 8:11] if batch.shape[1] > 8 else None)
     near, far = batch[:, 6:7], batch[:, 7:8]
-    z = O.coarse_z_vals(rc, near, far, batch.shape[0], None)
+    t_rand = O.pytest_uniform([n, rc.N_samples]) if (pytest_draws and rc.perturb > 0.0) else None
+    z = O.coarse_z_vals(rc, near, far, n, t_rand)
+    noise = (lambda shape: O.pytest_uniform(shape) * rc.raw_noise_std) if (pytest_draws and rc.raw_noise_std > 0.0) else (lambda shape: None)
     pts = rays_o[..., None, :] + rays_d[..., None, :] * z[..., :, None]
     raw = O.nerf_forward(coarse[0], coarse[1], pts, viewdirs)
-    rgb0 = O.raw2outputs(raw, z, rays_d, rc.white_bkgd, None)[0]
+    rgb0 = O.raw2outputs(raw, z, rays_d, rc.white_bkgd, noise(list(z.shape)))[0]
     pts = rays_o[..., None, :] + rays_d[..., None, :] * z_fine[..., :, None]
     raw = O.nerf_forward(fine[0], fine[1], pts, viewdirs)
-    return O.raw2outputs(raw, z_fine, rays_d, rc.white_bkgd, None)[0], rgb0
+    return O.raw2outputs(raw, z_fine, rays_d, rc.white_bkgd, noise(list(z_fine.shape)))[0], rgb0
 
 
 @pytest.mark.parametrize("arch", [VD, NOVD], ids=["viewdirs", "output_linear"])
@@ -292,3 +296,97 @@ def test_frozen_model_keeps_its_own_precision_in_a_training_call(dev):
     assert torch.equal(out["raw"], want)                                   # the exact-fp32 kernel's values, not bf16's
     (((out["rgb_map"] - target.to(dev)) ** 2).mean() + ((out["rgb0"] - target.to(dev)) ** 2).mean()).backward()
     assert all(p.grad is not None for p in mc.parameters()) and all(p.grad is None for p in mf.parameters())
+
+
+@pytest.mark.parametrize("variant", ["single_model_both_passes", "coarse_only", "noise_lindisp_perturb", "ndc_fern"])
+def test_training_gradients_of_the_other_render_configurations_match_fp32_autograd(dev, variant):
+    """render_rays' other branches under autograd in split precision: fine_model=None (the coarse network evaluates both
+    passes, render_utils.py:150-151: its gradient is the sum of two backward passes), N_importance=0, lindisp + stratified
+    jitter + sigma noise (seeded draws on both sides), and the LLFF configuration (configs/fern.txt: NDC rays, near/far 0/1,
+    64+64-style sampling, noise, black background) -- against fp32 autograd on the oracle."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from nerf_shared_amd import render_utils
+    from test_gpu_parity import oracle_batch
+    batch, target = _batch(64, 5)
+    cfg = dict(BASE, N_samples=32, N_importance=0 if variant == "coarse_only" else 40)
+    use_pytest = variant in ("noise_lindisp_perturb", "ndc_fern")
+    if variant == "noise_lindisp_perturb":
+        cfg.update(lindisp=True, raw_noise_std=1.0, perturb=1.0)
+    if variant == "ndc_fern":
+        H, W, focal = 378, 504, 408.0
+        K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+        c2w = np.array([[1, 0, 0, 0.05], [0, 1, 0, -0.02], [0, 0, 1, 0.1]], np.float32)
+        cfg.update(ndc=True, near=0.0, far=1.0, white_bkgd=False, raw_noise_std=1.0, perturb=1.0, N_importance=32)
+        batch = oracle_batch(cfg, H, W, K, c2w, np.sort(np.random.default_rng(12).choice(H * W, size=64, replace=False)))
+    r = render_utils.Renderer(**cfg)
+    mc, cc = models(dev, 1, 1.0, VD, "fp32_split")
+    mf, cf = models(dev, 11, 1.0, VD, "fp32_split")
+    with torch.no_grad():            # lift the density bias: a semi-transparent volume, non-degenerate gradients
+        for m, sd in ((mc, cc), (mf, cf)):
+            m.alpha_linear.bias += 0.3
+            sd["alpha_linear.bias"] += 0.3
+    use_fine = variant in ("noise_lindisp_perturb", "ndc_fern")
+    out = r.render_rays(batch.to(dev), mc, mf if use_fine else None, retweights=True, pytest=use_pytest)
+    t = target.to(dev)
+    loss = ((out["rgb_map"] - t) ** 2).mean()
+    if "rgb0" in out:
+        loss = loss + ((out["rgb0"] - t) ** 2).mean()
+    loss.backward()
+    assert use_fine or all(p.grad is None for p in mf.parameters())
+    oc, of = (cc, O.Arch(**VD)), ((cf, O.Arch(**VD)) if use_fine else (cc, O.Arch(**VD)))
+    if variant == "coarse_only":
+        o = O.render_rays(O.RenderCfg(**cfg), batch, oc, None)
+        l = ((o["rgb_map"] - target) ** 2).mean()
+    else:
+        rgb, rgb0 = oracle_two_pass(cfg, batch, oc, of, out["z_vals"].detach().cpu(), pytest_draws=use_pytest)
+        l = ((rgb - target) ** 2).mean() + ((rgb0 - target) ** 2).mean()
+    l.backward()
+    assert abs(float(loss) - float(l)) < 5e-6 * max(1.0, abs(float(l))), (float(loss), float(l))
+    table = []
+    check_params("coarse.", mc, cc, table)
+    if use_fine:
+        check_params("fine.", mf, cf, table)
+    assert all(float(cc[n].grad.norm()) > 0 for n in cc if cc[n].grad is not None), "degenerate test: zero gradient"
+    assert_table(table)
+
+
+def smallest_preactivation(cpu, arch, pts, vd):
+    """min |pre-activation| over the hidden ReLU units of NeRF.MLP (nerf.py:110-134) on the fp32 oracle: a unit within fp32
+    rounding of zero may sit on the other side in any other fp32-class evaluation (fp64 included), and then its whole
+    gradient column differs -- one flip among n points moves a tensor's gradient by ~sqrt(1 / (128 n))."""
+    with torch.no_grad():
+        sd = {k: v.detach() for k, v in cpu.items()}
+        e = O.embed(pts.reshape(-1, 3), arch["multires"])
+        h, small = e, float("inf")
+        for i in range(8):
+            a = torch.nn.functional.linear(h, sd["pts_linears.%d.weight" % i], sd["pts_linears.%d.bias" % i])
+            small = min(small, float(a.abs().min()))
+            h = torch.relu(a)
+            if i == 4:
+                h = torch.cat([e, h], -1)
+        feat = torch.nn.functional.linear(h, sd["feature_linear.weight"], sd["feature_linear.bias"])
+        d = O.embed(vd[:, None].expand(pts.shape).reshape(-1, 3), arch["multires_views"])
+        a = torch.nn.functional.linear(torch.cat([feat, d], -1), sd["views_linears.0.weight"], sd["views_linears.0.bias"])
+        return min(small, float(a.abs().min()))
+
+
+@pytest.mark.parametrize("n_points", [1, 15, 16, 17, 127, 128, 129, 255, 257, 2049])
+def test_field_backward_on_awkward_point_counts(dev, n_points):
+    """Point counts around the kernels' tiles (16 points per wave, 128 per workgroup, 32 per weight-gradient chunk, 256-row
+    padding of the training arrays): the padding points must contribute nothing.  With so few points ONE ReLU unit on the
+    other side of zero is visible (3e-3 at 257 points), so the draw is repeated until the oracle has no unit within 1e-5 of
+    zero -- what is tested here is the padding, not the conditioning of ReLU."""
+    m, cpu = models(dev, 1, 2.0, VD, "fp32_split")
+    for attempt in range(20):
+        rng = np.random.default_rng(100 + n_points + 1000 * attempt)
+        pts = torch.from_numpy(rng.uniform(-2, 2, size=(n_points, 1, 3)).astype(np.float32))
+        vd = torch.from_numpy(rng.normal(size=(n_points, 3)).astype(np.float32))
+        coef = torch.from_numpy(rng.normal(size=(n_points, 1, 4)).astype(np.float32))
+        if smallest_preactivation(cpu, VD, pts, vd) > 1e-5:
+            break
+    (O.nerf_forward(cpu, O.Arch(**VD), pts, vd) * coef).sum().backward()
+    (m(pts.to(dev), vd.to(dev)) * coef.to(dev)).sum().backward()
+    table = []
+    check_params("", m, cpu, table)
+    assert_table(table)
