@@ -94,6 +94,49 @@ def get_embedder(multires, i=0):
 
 
 # ------------------------------------------------------------------ the field
+def adopt(model):
+    """The NeRF of this package that evaluates `model`: `model` itself when it is one, else -- for a model built by the
+    reference's own class (nerf_shared.nerf.NeRF, nerf.py:61-94, or anything with its attributes and nn.Linear layout) -- a
+    twin that SHARES the model's Parameter objects (nothing is copied: optimizer steps, load_state_dict and .to() on the
+    reference model are seen by the twin), made once and kept on the model.  This is what lets a caller keep
+    `from nerf_shared import nerf` for its models and swap only the renderer."""
+    if model is None or isinstance(model, NeRF):
+        return model
+    twin = getattr(model, "__dict__", {}).get("_nerf_amd_twin")
+    if twin is not None:
+        return twin
+    try:
+        D, W, skips, vd = int(model.D), int(model.W), list(model.skips), bool(model.use_viewdirs)
+        ic, icv = int(model.input_ch), int(model.input_ch_views)
+        pts, views = model.pts_linears, model.views_linears
+    except AttributeError as e:
+        raise TypeError("expected a nerf_shared_amd.nerf.NeRF or a model with the reference NeRF's attributes (D, W, skips, "
+                        "use_viewdirs, input_ch, input_ch_views, pts_linears, views_linears, ...); got %s: %s"
+                        % (type(model).__name__, e))
+    i_embed = -1 if ic == 3 else 0
+    L, Lv = (ic - 3) // 6, ((icv - 3) // 6 if vd else 4)
+    if (i_embed == 0 and 3 + 6 * L != ic) or (vd and i_embed == 0 and 3 + 6 * Lv != icv) or (vd and i_embed == -1 and icv != 3):
+        raise TypeError("cannot tell the positional encodings of %s from input_ch=%d / input_ch_views=%d"
+                        % (type(model).__name__, ic, icv))
+    out_ch = 4 if vd else int(model.output_linear.out_features)
+    twin = NeRF(D=D, W=W, output_ch=out_ch, skips=skips, use_viewdirs=vd, multires=max(L, 0), multires_views=max(Lv, 0),
+                i_embed=i_embed)
+    pairs = list(zip(twin.pts_linears, pts)) + [(twin.views_linears[0], views[0])]
+    if vd:
+        pairs += [(twin.feature_linear, model.feature_linear), (twin.alpha_linear, model.alpha_linear),
+                  (twin.rgb_linear, model.rgb_linear)]
+    else:
+        pairs += [(twin.output_linear, model.output_linear)]
+    for mine, theirs in pairs:
+        if tuple(mine.weight.shape) != tuple(theirs.weight.shape) or tuple(mine.bias.shape) != tuple(theirs.bias.shape):
+            raise TypeError("layer shapes of %s do not follow the reference NeRF (%s vs %s)"
+                            % (type(model).__name__, tuple(theirs.weight.shape), tuple(mine.weight.shape)))
+        mine.weight, mine.bias = theirs.weight, theirs.bias          # the same Parameter objects
+    twin.precision = getattr(model, "precision", None)
+    model.__dict__["_nerf_amd_twin"] = twin                           # (not a registered submodule: state_dict keys stay the reference's)
+    return twin
+
+
 def _destroy_handle(handle):
     if handle:
         lib.nerf_amd_model_destroy(handle)

@@ -165,8 +165,7 @@ class Renderer(torch.nn.Module):
     @staticmethod
     def _check_model(m, name):
         if not isinstance(m, NeRF):
-            raise TypeError("%s must be a nerf_shared_amd.nerf.NeRF (got %s); load a reference model's "
-                            "state_dict into one" % (name, type(m).__name__))
+            raise TypeError("%s must be a nerf_shared_amd.nerf.NeRF or a reference-style NeRF module (got %s)" % (name, type(m).__name__))
 
     def _handles(self, dev, coarse_model, fine_model):
         """Library handles (re-packed if the weights changed), render cfg and output width."""
@@ -439,6 +438,7 @@ class Renderer(torch.nn.Module):
         [weights, z_vals], and with N_importance > 0: rgb0, disp0, acc0, z_std.
         """
         _lib.require_device(ray_batch, "ray_batch")
+        coarse_model, fine_model = nerf_mod.adopt(coarse_model), nerf_mod.adopt(fine_model)     # reference-class models: a twin sharing their parameters
         rays = ray_batch.detach().contiguous().float()
         if rays.dim() != 2 or rays.shape[1] not in (8, 11):
             raise _lib.NerfAmdError("ray_batch must be [N, 8] or [N, 11], got %s" % (tuple(ray_batch.shape),))
@@ -480,6 +480,7 @@ class Renderer(torch.nn.Module):
         generator in chunk order in every mode).  Off by default: the gain is ~3 % and
         concurrent kernels blur per-kernel timings."""
         _lib.require_device(rays_flat, "rays_flat")
+        coarse_model, fine_model = nerf_mod.adopt(coarse_model), nerf_mod.adopt(fine_model)
         rays = rays_flat.detach().contiguous().float()
         self._check_model(coarse_model, "coarse_model")
         N, dev = rays.shape[0], rays.device
@@ -538,6 +539,7 @@ class Renderer(torch.nn.Module):
                c2w=None, c2w_staticcam=None):
         """Render a full image from ``c2w`` or an explicit ray set (render_utils.py:176-238).
         Returns [rgb_map, disp_map, acc_map, extras]."""
+        coarse_model, fine_model = nerf_mod.adopt(coarse_model), nerf_mod.adopt(fine_model)
         if c2w is not None:
             dev = next(coarse_model.parameters()).device
             if not dev.type == 'cuda':

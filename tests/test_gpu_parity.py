@@ -1225,3 +1225,36 @@ def test_resample_stage_against_sample_pdf_and_torch_sort(dev):
         want = torch.sort(torch.cat([zt, samples], -1), -1)[0]
         assert torch.equal(z_fine, want), case
         close(z_std, torch.std(samples, -1, unbiased=False), atol=2e-6)
+
+
+def test_renderer_takes_reference_class_models(dev):
+    """A model built by the reference's own class (here: a stand-in with its attributes and layers, tests/test_host_logic.py)
+    renders bit-identically to this package's NeRF holding the same weights, and training through the renderer updates the
+    reference model's own parameters."""
+    nerf, render_utils, utils = amd()
+    from test_host_logic import _ReferenceStyleNeRF
+    K = synth.lego_intrinsics(40, 40)
+    r = render_utils.Renderer(**dict(BASE, N_samples=32, N_importance=32))
+    refs, ours = [], []
+    for seed in (1, 11):
+        sd = synth.torch_state_dict(seed, 3.0, **{**VD, "skips": (4,)})
+        ref = _ReferenceStyleNeRF(use_viewdirs=True, output_ch=5)
+        ref.load_state_dict(sd)
+        refs.append(ref.to(dev))
+        ours.append(gpu_model(dev, seed, 3.0, "bf16", **VD))
+    c2w = torch.from_numpy(synth.LEGO_C2W)
+    with torch.no_grad():
+        a = r.render(40, 40, K, refs[0], refs[1], chunk=500, c2w=c2w, retraw=False)
+        b = r.render(40, 40, K, ours[0], ours[1], chunk=500, c2w=c2w, retraw=False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+    batch = utils.make_ray_batch(40, 40, K, synth.LEGO_C2W, 2.0, 6.0, True, False, device=dev, n=64)
+    opt = torch.optim.SGD(list(refs[0].parameters()) + list(refs[1].parameters()), lr=1e-2)
+    before = refs[0].pts_linears[3].weight.detach().clone()
+    out = r.render_rays(batch, refs[0], refs[1])
+    (((out["rgb_map"] - 0.3) ** 2).mean() + ((out["rgb0"] - 0.3) ** 2).mean()).backward()
+    assert refs[1].rgb_linear.weight.grad is not None and refs[0].pts_linears[3].weight.grad is not None
+    opt.step()
+    assert not torch.equal(refs[0].pts_linears[3].weight, before)
+    with torch.no_grad():                                   # the packed copy followed the reference model's update
+        c = r.render(40, 40, K, refs[0], refs[1], chunk=500, c2w=c2w, retraw=False)
+    assert not torch.equal(c[0], a[0])

@@ -507,3 +507,42 @@ def test_load_weights_from_keras_maps_the_list_like_the_reference():
     assert m._packed_key is None
     with pytest.raises(AssertionError):
         nerf.NeRF(D=8, W=256, use_viewdirs=False).load_weights_from_keras(keras)
+
+
+class _ReferenceStyleNeRF(torch.nn.Module):
+    """What nerf_shared.nerf.NeRF.__init__ builds (nerf.py:62-94): the attributes and nn.Linear layout, nothing of its code."""
+
+    def __init__(self, D=8, W=256, output_ch=4, skips=(4,), use_viewdirs=False, multires=10, multires_views=4):
+        super().__init__()
+        self.D, self.W, self.skips, self.use_viewdirs = D, W, list(skips), use_viewdirs
+        self.embed_fn, self.input_ch = None, 3 + 6 * multires
+        self.input_ch_views, self.embeddirs_fn = (3 + 6 * multires_views if use_viewdirs else 0), None
+        lin = torch.nn.Linear
+        self.pts_linears = torch.nn.ModuleList([lin(self.input_ch, W)] + [lin(W, W) if i not in self.skips else lin(W + self.input_ch, W)
+                                                                         for i in range(D - 1)])
+        self.views_linears = torch.nn.ModuleList([lin(self.input_ch_views + W, W // 2)])
+        if use_viewdirs:
+            self.feature_linear, self.alpha_linear, self.rgb_linear = lin(W, W), lin(W, 1), lin(W // 2, 3)
+        else:
+            self.output_linear = lin(W, output_ch)
+
+
+def test_reference_class_models_are_adopted_by_sharing_their_parameters():
+    """Renderer takes models built by the reference's own NeRF class (main.py keeps `from nerf_shared import nerf`): nerf.adopt
+    makes a twin whose parameters ARE the model's Parameter objects; the model's state_dict keys stay the reference's."""
+    for kw in (dict(use_viewdirs=True, output_ch=5), dict(use_viewdirs=False, output_ch=5), dict(use_viewdirs=True, multires=15, multires_views=6)):
+        ref = _ReferenceStyleNeRF(**kw)
+        keys = list(ref.state_dict().keys())
+        twin = nerf.adopt(ref)
+        assert isinstance(twin, nerf.NeRF) and nerf.adopt(ref) is twin and nerf.adopt(twin) is twin
+        assert list(ref.state_dict().keys()) == keys and list(twin.state_dict().keys()) == keys
+        assert all(a is b for a, b in zip(twin.parameters(), ref.parameters()))
+        assert (twin.D, twin.W, twin.use_viewdirs, twin.input_ch, twin.input_ch_views) == (ref.D, ref.W, ref.use_viewdirs, ref.input_ch, ref.input_ch_views)
+        assert twin.output_ch == (4 if kw["use_viewdirs"] else 5) or kw["use_viewdirs"]
+    with pytest.raises(TypeError, match="reference NeRF's attributes"):
+        nerf.adopt(torch.nn.Linear(3, 3))
+    bad = _ReferenceStyleNeRF(use_viewdirs=True)
+    bad.rgb_linear = torch.nn.Linear(128, 4)
+    with pytest.raises(TypeError, match="layer shapes"):
+        nerf.adopt(bad)
+    assert nerf.adopt(None) is None
