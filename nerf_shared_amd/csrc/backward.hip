@@ -46,7 +46,6 @@ struct DwArgs {
     const uint16_t *H;                   // head gradients transposed inside 32-point chunks (kernels.h g_rawt), or NULL
     // split-precision products (dw2s_body): the planes of fp16 lo rows of G, X and H (the pointers above are the hi planes)
     const uint16_t *G_lo, *X_lo, *H_lo;
-    int blocked;                         // A/B (nerf_amd_set_tuning(0, 59)): a workgroup takes a contiguous range of chunks instead of every nwg-th
 };
 
 struct DwReduceArgs {
@@ -252,6 +251,14 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(DwReduceArgs a) {
 // bytes all start at bank 0, so the eight rows need eight different piece pairs: XOR with 0, 2, .., 14.  Rows of 128 bytes
 // (PIECES == 8) alternate between the two halves of the banks, so the four even rows {0, 2, 8, 10} (and the four odd ones)
 // need four different pairs: XOR with 0, 2, 4, 6.  Both forms satisfy swz(r + 4) == swz(r).
+#ifdef NERF_AMD_X_DW_STAMPS
+// tools/micro/dw_stamps.py: when each workgroup of the last dw_multi_kernel launch started and ended (100 MHz clock)
+__device__ unsigned long long g_dw_stamps[4 * 512];
+extern "C" int nerf_amd_x_dw_stamps(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dw_stamps), sizeof(g_dw_stamps)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 constexpr int DW2_NS(int OT, int IT) {
     const int n = (128 * 1024) / (32 * 32 * (OT + IT));
     return n < 4 ? 4 : (n > 12 ? 12 : n);
@@ -287,15 +294,8 @@ __device__ __forceinline__ bf16x8 tr_frag_swz(uint32_t img, int col0, int lane) 
 // One 1-KiB LDS-DMA piece: lane l fetches 16 bytes from g (per lane) into lds_base + 16 l.
 __device__ __forceinline__ void dma_piece(const char *g, uint32_t lds_base) {
     unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(g), "s"(lds_base)
-        : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\t" "s_mov_b32 m0, %2\n\t" "s_nop 0\n\t" "global_load_lds_dwordx4 %1, off\n\t" "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds_base) : "memory");
 }
 
 __device__ __forceinline__ void dw_reduce_block(const DwReduceArgs &a, int block, int tid, float *part /* [8][64] LDS */) {
@@ -336,7 +336,8 @@ __device__ __forceinline__ void dw2_body(const DwArgs &a, const int wg, const in
     constexpr int PG = OT * 2, PX = IT * 2;                     // 16-byte pieces per row
     constexpr int IMG_GX = 32 * (RG + RX);                      // G and X rows of one chunk
     constexpr int IMG = IMG_GX + (HEAD ? 1024 : 0);             // one chunk's image (+ the head operand)
-    constexpr int NI = OT + IT, CNT = (NI + 7) / 8;             // 1-KiB DMA instructions per chunk; per wave (the last ones may repeat)
+    constexpr int NI = OT + IT, CNT = (NI + 7) / 8;             // 1-KiB DMA instructions per chunk; per wave at most
+    constexpr int REM = NI - 8 * (CNT - 1);                     // waves below REM issue CNT per chunk, the others CNT - 1
     // ring slots: what fits in 128 KiB, at least 4 and at most 12 -- a narrow product keeps as many BYTES in flight as a
     // wide one (a workgroup's rate is bytes in flight / latency, and the one-launch path shares the CUs by bytes)
     constexpr int NS = DW2_NS(OT, IT);
@@ -348,12 +349,11 @@ __device__ __forceinline__ void dw2_body(const DwArgs &a, const int wg, const in
     const uint32_t ring = (uint32_t)(uintptr_t)smem;
 
     const int64_t n_chunks = (a.P + 31) / 32;
-    const int64_t per = (n_chunks + nwg - 1) / nwg;
-    const int64_t first = a.blocked ? wg * per : wg, stride = a.blocked ? 1 : nwg;
-    const int64_t n_local = a.blocked ? (first < n_chunks ? (n_chunks - first < per ? n_chunks - first : per) : 0)
-                                      : (wg < n_chunks ? (n_chunks - wg + nwg - 1) / nwg : 0);     // chunks wg, wg + nwg, ... (or a contiguous range)
-    // this wave's DMA instructions of a chunk: j = wave, wave + 8, ... (indices past NI repeat the last one: every wave
-    // issues exactly CNT, which keeps the counted waits compile-time constants)
+    const int64_t first = wg, stride = nwg;
+    const int64_t n_local = wg < n_chunks ? (n_chunks - wg + nwg - 1) / nwg : 0;     // chunks wg, wg + nwg, ...
+    // this wave's DMA instructions of a chunk: j = wave, wave + 8, ... below NI -- CNT of them, or CNT - 1 for the waves
+    // from REM on (a count per wave, uniform inside it, so the counted waits stay compile-time constants: wait_chunk below)
+    const bool full = REM == 8 || wave < REM;
     auto issue_chunk = [&](int64_t i) {
         int64_t ch = first + i * stride;
         if (ch >= n_chunks) ch = n_chunks - 1;                  // past the end: a harmless re-read that is never consumed
@@ -361,8 +361,8 @@ __device__ __forceinline__ void dw2_body(const DwArgs &a, const int wg, const in
         const int64_t p0 = ch * 32;
 #pragma unroll
         for (int k = 0; k < CNT; ++k) {
-            int j = wave + 8 * k;
-            if (j >= NI) j = NI - 1;
+            const int j = wave + 8 * k;
+            if (k == CNT - 1 && !full) break;
             const bool is_g = j < OT;
             const int jj = is_g ? j : j - OT;
             const int e = 64 * jj + lane;                       // 16-byte piece of the G (or X) image
@@ -399,7 +399,14 @@ __device__ __forceinline__ void dw2_body(const DwArgs &a, const int wg, const in
             // chunk i has landed (this wave's pieces; chunks i+1, i+2 stay in flight), everyone agrees, then the slot of
             // chunk i-1 -- which every wave finished reading before it came here -- is refilled with chunk i+3
             if (HEAD && wave == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * (CNT + 1)) : "memory");   // wave 0 issues one more piece per chunk
-            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * CNT) : "memory");
+            else if (full) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * CNT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * (CNT - 1)) : "memory");
+#ifdef NERF_AMD_X_DW_STAMPS
+            if (tid == 0 && (i == 0 || i == n_local / 2)) {         // first chunk landed | half way: packed into one word
+                const unsigned long long t = wall_clock64() - g_dw_stamps[4 * blockIdx.x];
+                if (i == 0) g_dw_stamps[4 * blockIdx.x + 3] = t; else g_dw_stamps[4 * blockIdx.x + 3] |= t << 32;
+            }
+#endif
             issue_chunk(i + NS - 1);
             const uint32_t gimg = ring + (uint32_t)(i % NS) * IMG, ximg = gimg + 32 * RG;
             const int64_t ch = first + i * stride;
@@ -541,7 +548,8 @@ __device__ __forceinline__ void dw2s_body(const DwArgs &a, const int wg, const i
     constexpr int IMG_G = 32 * RG, IMG_X = 32 * RX;             // one plane of one chunk
     constexpr int IMG_GX = 2 * (IMG_G + IMG_X);                 // G_hi, G_lo, X_hi, X_lo
     constexpr int IMG = IMG_GX + (HEAD ? 2048 : 0);             // + the head operand's two planes
-    constexpr int NI = 2 * (OT + IT), CNT = (NI + 7) / 8;       // 1-KiB DMA instructions per chunk; per wave (the last ones may repeat)
+    constexpr int NI = 2 * (OT + IT), CNT = (NI + 7) / 8;       // 1-KiB DMA instructions per chunk; per wave at most
+    constexpr int REM = NI - 8 * (CNT - 1);                     // waves below REM issue CNT per chunk, the others CNT - 1
     constexpr int NS = DW2S_NS(OT, IT);
     static_assert((NS - 2) * (CNT + (HEAD ? 2 : 0)) <= 63, "vmcnt field is 6 bits");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -555,8 +563,9 @@ __device__ __forceinline__ void dw2s_body(const DwArgs &a, const int wg, const i
     // The ring DMA as buffer_load ... lds: a buffer resource per plane (scalar), ONE per-lane 32-bit offset per piece that
     // does not depend on the chunk (row inside the chunk x row bytes + swizzled position), the chunk as the scalar offset --
     // no 64-bit per-lane address arithmetic inside the loop, and rows past the arrays' end read as zero instead of needing a
-    // clamp.  This wave's pieces of a chunk: j = wave, wave + 8, ... of the NI pieces G_hi | G_lo | X_hi | X_lo (indices past NI
-    // repeat the last one: every wave issues exactly CNT, which keeps the counted waits compile-time constants).
+    // clamp.  This wave's pieces of a chunk: j = wave, wave + 8, ... below NI of the pieces G_hi | G_lo | X_hi | X_lo: CNT of
+    // them, or CNT - 1 for the waves from REM on (uniform per wave, so the counted waits stay compile-time constants).
+    const bool full = REM == 8 || wave < REM;
     typedef __attribute__((ext_vector_type(4))) unsigned rsrc_t;
     const unsigned g_bytes = (unsigned)(pad_points(a.P) * a.ldg * 2), x_bytes = (unsigned)(pad_points(a.P) * a.ldx * 2);
     const rsrc_t rs_plane[4] = {make_rsrc(a.G, g_bytes), make_rsrc(a.G_lo, g_bytes), make_rsrc(a.X, x_bytes), make_rsrc(a.X_lo, x_bytes)};
@@ -599,6 +608,7 @@ __device__ __forceinline__ void dw2s_body(const DwArgs &a, const int wg, const i
         const unsigned so_x = __builtin_amdgcn_readfirstlane((unsigned)(ch * 32 * a.ldx * 2));
 #pragma unroll
         for (int k = 0; k < CNT; ++k) {
+            if (k == CNT - 1 && !full) break;
             const int pl = plane[k];
             const rsrc_t rs = pl == 0 ? rs_plane[0] : pl == 1 ? rs_plane[1] : pl == 2 ? rs_plane[2] : rs_plane[3];
             dma_buf(voff[k], rs, pl < 2 ? so_g : so_x, __builtin_amdgcn_readfirstlane(slot + lds_off[k]));
@@ -634,7 +644,8 @@ __device__ __forceinline__ void dw2s_body(const DwArgs &a, const int wg, const i
             // chunk i has landed (this wave's pieces; younger chunks stay in flight), everyone agrees, then the slot of
             // chunk i-1 -- which every wave finished reading before it came here -- is refilled with chunk i+NS-1
             if (HEAD && wave == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * (CNT + 2)) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * CNT) : "memory");
+            else if (full) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * CNT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * (CNT - 1)) : "memory");
             issue_chunk(i + NS - 1);
             const uint32_t g_hi = ring + (uint32_t)(i % NS) * IMG, g_lo = g_hi + IMG_G, x_hi = g_hi + 2 * IMG_G, x_lo = x_hi + IMG_X;
             const int64_t ch = wg + i * nwg;
@@ -936,6 +947,12 @@ __global__ __launch_bounds__(512, 2) void dw_multi_kernel(DwMulti m) {
     j = __builtin_amdgcn_readfirstlane(j);
     const DwJob &J = m.job[j];
     const int wg = (int)blockIdx.x - J.first_block;
+#ifdef NERF_AMD_X_DW_STAMPS
+    if (threadIdx.x == 0) {
+        g_dw_stamps[4 * blockIdx.x] = wall_clock64();
+        g_dw_stamps[4 * blockIdx.x + 2] = (unsigned long long)j << 8 | (unsigned)J.shape;
+    }
+#endif
     switch (J.shape) {
     case 0: dw2_body<16, 16, 4, 2>(J.a, wg, J.n_blocks); break;
     case 1: dw2_body<8, 16, 4, 2>(J.a, wg, J.n_blocks); break;
@@ -944,6 +961,10 @@ __global__ __launch_bounds__(512, 2) void dw_multi_kernel(DwMulti m) {
     case 4: dw2_body<16, 16, 4, 2, true>(J.a, wg, J.n_blocks); break;
     default: dw_head_body<8>(J.a, wg, J.n_blocks); break;
     }
+#ifdef NERF_AMD_X_DW_STAMPS
+    __syncthreads();
+    if (threadIdx.x == 0) g_dw_stamps[4 * blockIdx.x + 1] = wall_clock64();
+#endif
 }
 
 // The same one launch for the split-precision products (dw2s_body): job shapes 0..5 as above, 6: <16,8,4,2> (the xyz
@@ -954,6 +975,12 @@ __global__ __launch_bounds__(512, 2) void dw_multi_split_kernel(DwMulti m) {
     j = __builtin_amdgcn_readfirstlane(j);
     const DwJob &J = m.job[j];
     const int wg = (int)blockIdx.x - J.first_block;
+#ifdef NERF_AMD_X_DW_STAMPS
+    if (threadIdx.x == 0) {
+        g_dw_stamps[4 * blockIdx.x] = wall_clock64();
+        g_dw_stamps[4 * blockIdx.x + 2] = (unsigned long long)j << 8 | (unsigned)J.shape;
+    }
+#endif
     switch (J.shape) {
     case 0: dw2s_body<16, 16, 4, 2>(J.a, wg, J.n_blocks); break;
     case 1: dw2s_body<8, 16, 4, 2>(J.a, wg, J.n_blocks); break;
@@ -964,6 +991,10 @@ __global__ __launch_bounds__(512, 2) void dw_multi_split_kernel(DwMulti m) {
     case 7: dw2s_body<8, 4, 8, 1>(J.a, wg, J.n_blocks); break;
     default: dw_head_split_body<8>(J.a, wg, J.n_blocks); break;
     }
+#ifdef NERF_AMD_X_DW_STAMPS
+    __syncthreads();
+    if (threadIdx.x == 0) g_dw_stamps[4 * blockIdx.x + 1] = wall_clock64();
+#endif
 }
 constexpr size_t dw_split_lds(int OT, int IT, bool head) { return (size_t)DW2S_NS(OT, IT) * (2 * 32 * 32 * (OT + IT) + (head ? 2048 : 0)); }
 
@@ -1223,28 +1254,45 @@ static int launch_dw(const DwArgs &a, const DwReduceArgs &ra, DwSeq &q) {
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
 
+// Workgroups per product of the one-launch paths.  Every product streams the same number of chunks, but what a workgroup
+// needs per chunk depends on the product's shape -- bytes, MFMAs, and a cost per ring step that does not shrink with the
+// chunk -- so sharing the workgroups by bytes let the narrow products finish last: at 196608 points the <8,2> product ended
+// at 495 us and the head-alone one at 440 us when the 256 x 256 products were done at 385 us, and the launch takes as long as
+// its last workgroup.  The table is that measurement (tools/micro/dw_stamps.py: us per chunk and workgroup by job shape,
+// every CU busy, bf16 and split-precision kernels); the next workgroup always goes to the product that would end last.
+static void dw_share_workgroups(const DwMulti &mj, bool split, int cap, int *nb) {
+    static const float cost_bf16[8] = {1.49f, 1.06f, 0.90f, 0.56f, 1.64f, 0.43f, 1.06f, 0.62f};
+    static const float cost_split[8] = {2.88f, 1.91f, 1.43f, 0.80f, 3.11f, 0.544f, 1.91f, 0.95f};
+    const float *cost = split ? cost_split : cost_bf16;
+    int used = 0;
+    for (int j = 0; j < mj.n; ++j) { nb[j] = 1; ++used; }
+    for (; used < DW_GRID; ++used) {
+        int best = -1;
+        float worst = 0.f;
+        for (int j = 0; j < mj.n; ++j) {
+            const float t = cost[mj.job[j].shape & 7] / (float)nb[j];
+            if (nb[j] < cap && t > worst) { worst = t; best = j; }
+        }
+        if (best < 0) break;                                    // every product has as many workgroups as 8-chunk pieces
+        ++nb[best];
+    }
+}
+
 int DwSeq::flush() {
     if (!multi || mj.n == 0) return NERF_AMD_OK;
     const size_t lds = 4 * (32 * (16 * 32 + 16 * 32) + 1024);     // the largest job shape: 256 x 256 with a head operand per ring slot
     static DynamicLdsOptIn opt_in;
     if (opt_in.ensure(reinterpret_cast<const void *>(dw_multi_kernel), lds) != hipSuccess) return NERF_AMD_EHIP;
-    // workgroups in proportion to the bytes per point of a product, DW_GRID in all (never more than a product has
-    // 8-chunk pieces); every product's slabs follow the previous product's
-    // per shape: 16-column tiles of G and X (bytes per point / 32, the share of the workgroups) and floats per slab
+    // DW_GRID workgroups in all, shared by dw_share_workgroups (never more than a product has 8-chunk pieces); every
+    // product's slabs follow the previous product's
     const int64_t n_chunks = (mj.job[0].a.P + 31) / 32;
-    int w[DW_MAX_JOBS], total_w = 0, nb[DW_MAX_JOBS], per[DW_MAX_JOBS], used = 0;
-    for (int j = 0; j < mj.n; ++j) {
-        const DwReduceArgs &r = mr.r[j];
-        w[j] = r.OT + r.IT; per[j] = dw_slab_floats(r.OT, r.IT, r.HT);
-        total_w += w[j];
-    }
-    for (int j = 0; j < mj.n; ++j) { nb[j] = DW_GRID * w[j] / total_w; if (nb[j] < 1) nb[j] = 1; used += nb[j]; }
-    for (int j = 0; used < DW_GRID; j = (j + 1) % mj.n) { ++nb[j]; ++used; }
+    int nb[DW_MAX_JOBS], per[DW_MAX_JOBS];
+    for (int j = 0; j < mj.n; ++j) per[j] = dw_slab_floats(mr.r[j].OT, mr.r[j].IT, mr.r[j].HT);
     const int cap = n_chunks / 8 < 1 ? 1 : (int)(n_chunks / 8 > DW_GRID ? DW_GRID : n_chunks / 8);
+    dw_share_workgroups(mj, false, cap, nb);
     float *sl = slab;
     int first = 0, rfirst = 0;
     for (int j = 0; j < mj.n; ++j) {
-        if (nb[j] > cap) nb[j] = cap;
         mj.job[j].a.slab = sl;
         mj.job[j].first_block = first; mj.job[j].n_blocks = nb[j];
         mr.r[j].slab = sl; mr.r[j].n_slabs = nb[j];
@@ -1276,7 +1324,6 @@ static int weight_grad(DwSeq &s, int64_t P, float *slab, const uint16_t *X, int 
     DwReduceArgs r;
     r.slab = slab; r.n_slabs = 0; r.OT = 0; r.IT = 0;
     a.G_lo = a.X_lo = a.H_lo = nullptr; r.inv_scale = nullptr;
-    a.blocked = g_variant == 59 ? 1 : 0;
     r.HT = head ? 1 : 0; r.head_dW = head ? head->dW : nullptr; r.head_db = head ? head->db : nullptr;
     r.head_row0 = head ? head->row0 : 0; r.head_rows = head ? head->rows : 0; r.head_ld = head ? head->ld : 0;
     if (head && !(s.multi && n_out_slots == 256 && n_in_slots == 256)) return NERF_AMD_EINVAL;
@@ -1297,7 +1344,7 @@ static int head_grad(DwSeq &s, int64_t P, const uint16_t *X, int n_in_slots, int
     if (!s.multi || n_in_slots != 128 || s.mj.n >= DW_MAX_JOBS) return NERF_AMD_EINVAL;
     DwJob &J = s.mj.job[s.mj.n];
     J.a.G = nullptr; J.a.ldg = 0; J.a.X = X; J.a.ldx = n_in_slots; J.a.P = P; J.a.slab = nullptr; J.a.H = head.H;
-    J.a.G_lo = J.a.X_lo = J.a.H_lo = nullptr; J.a.blocked = 0;
+    J.a.G_lo = J.a.X_lo = J.a.H_lo = nullptr;
     J.shape = 5;
     DwReduceArgs &r = s.mr.r[s.mj.n];
     r.slab = nullptr; r.n_slabs = 0; r.OT = 0; r.IT = n_in_slots / 16;
@@ -1477,7 +1524,7 @@ static int train_param_grads_split(const Program &p, int64_t P, const TrainWs &w
         if (shape < 0 || (head && shape != 4 && shape != 5)) { rc = NERF_AMD_EUNSUPPORTED; return; }
         DwJob &J = mj.job[mj.n];
         J.a.G = G.hi; J.a.G_lo = G.lo; J.a.ldg = n_out_slots; J.a.X = X.hi; J.a.X_lo = X.lo; J.a.ldx = n_in_slots; J.a.P = P;
-        J.a.slab = nullptr; J.a.H = head ? w.g_rawt : nullptr; J.a.H_lo = head ? w.g_rawt_lo : nullptr; J.a.blocked = 0;
+        J.a.slab = nullptr; J.a.H = head ? w.g_rawt : nullptr; J.a.H_lo = head ? w.g_rawt_lo : nullptr;
         J.shape = shape;
         DwReduceArgs &r = mr.r[mj.n];
         r.slab = nullptr; r.n_slabs = 0; r.OT = OT; r.IT = IT;
@@ -1515,23 +1562,17 @@ static int train_param_grads_split(const Program &p, int64_t P, const TrainWs &w
                 gw[D + 3], gb[D + 3]);
     }
     if (rc) return rc;
-    // ---- the one launch: workgroups in proportion to the bytes per point of a product, DW_GRID in all
+    // ---- the one launch: DW_GRID workgroups in all, shared by dw_share_workgroups
     static DynamicLdsOptIn opt_in;
     if (opt_in.ensure(reinterpret_cast<const void *>(dw_multi_split_kernel), 135168) != hipSuccess) return NERF_AMD_EHIP;
     const int64_t n_chunks = (P + 31) / 32;
-    int wgt[DW_MAX_JOBS], total_w = 0, nb[DW_MAX_JOBS], per[DW_MAX_JOBS], used = 0;
-    for (int j = 0; j < mj.n; ++j) {
-        const DwReduceArgs &r = mr.r[j];
-        wgt[j] = r.OT + r.IT; per[j] = dw_slab_floats(r.OT, r.IT, r.HT);
-        total_w += wgt[j];
-    }
-    for (int j = 0; j < mj.n; ++j) { nb[j] = DW_GRID * wgt[j] / total_w; if (nb[j] < 1) nb[j] = 1; used += nb[j]; }
-    for (int j = 0; used < DW_GRID; j = (j + 1) % mj.n) { ++nb[j]; ++used; }
+    int nb[DW_MAX_JOBS], per[DW_MAX_JOBS];
+    for (int j = 0; j < mj.n; ++j) per[j] = dw_slab_floats(mr.r[j].OT, mr.r[j].IT, mr.r[j].HT);
     const int cap = n_chunks / 8 < 1 ? 1 : (int)(n_chunks / 8 > DW_GRID ? DW_GRID : n_chunks / 8);
+    dw_share_workgroups(mj, true, cap, nb);
     float *sl = w.slab;
     int first = 0, rfirst = 0;
     for (int j = 0; j < mj.n; ++j) {
-        if (nb[j] > cap) nb[j] = cap;
         mj.job[j].a.slab = sl;
         mj.job[j].first_block = first; mj.job[j].n_blocks = nb[j];
         mr.r[j].slab = sl; mr.r[j].n_slabs = nb[j];
