@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 
 from nerf_shared_amd import synth  # noqa: E402
 from oracle import nerf_oracle as O  # noqa: E402
-from test_gpu_backward import BASE, NOVD, NOVD4, NOVD15, VD, VD15, _batch, rel_err  # noqa: E402
+from test_gpu_backward import BASE, NOVD, NOVD4, NOVD15, VD, VD15, _batch, rel_err, sphere_run  # noqa: E402,F401
 
 GATE_REL, GATE_COS = 1e-3, 0.9999
 
@@ -256,6 +256,164 @@ def test_adam_trajectory_follows_the_fp32_oracle(dev):
     worst = max(rel_err(p, cc[n]) for n, p in mc.named_parameters())
     print("coarse parameters after 12 steps: worst rel-L2 vs oracle %.2e" % worst)
     assert worst < 1e-3
+
+
+def _pose(w, dt, c2w0):
+    """exp(w^) R0 | t0 + dt, torch ops only (the same function serves the GPU run and the CPU oracle).  torch.matrix_exp, not
+    Rodrigues' formula through w / |w|: the derivative of that with respect to a small w cancels catastrophically in fp32
+    (1e-3 between two fp32 evaluations that differ in the last bit of a sine), which would measure the test, not the library."""
+    z = torch.zeros((), dtype=w.dtype, device=w.device)
+    Wx = torch.stack([torch.stack([z, -w[2], w[1]]), torch.stack([w[2], z, -w[0]]), torch.stack([-w[1], w[0], z])])
+    return torch.cat([torch.matrix_exp(Wx) @ c2w0[:3, :3], (c2w0[:3, 3] + dt)[:, None]], 1)
+
+
+@pytest.mark.parametrize("precision", ["fp32_split", "bf16"])
+def test_pose_optimisation_follows_the_fp32_oracle(dev, precision, sphere_run):
+    """The loop of the pose-estimation demo (demo_est_rel_pose.py:74-98) on six numbers: frozen networks (the pair trained on
+    the analytic sphere scene: a loss surface with a basin), a camera pose exp(w^) R0 | t0 + dt with learnable (w, dt),
+    get_rays -> render_rays -> mse against the image of the true pose -> Adam, 15 steps.
+
+    (a) At every iterate of the fp32 CPU oracle's loop, on the SAME ray values (the oracle's get_rays of that pose) and the
+        run's own fine depths (module docstring): dL/d(rays) carried down to the six numbers equals fp32 autograd on the
+        oracle: median <= 1e-4 (measured ~1e-6), cosine >= 0.9999, worst case within 3x the fp64 oracle's worst case.
+    (b), (c) need a yardstick: the fp64 oracle run beside the fp32 one.  The trained field is sharp: through the 2^9 of the
+        positional encoding a one-ulp difference in a ray (the GPU's get_rays against the CPU's) moves the gradient of the six
+        numbers by ~1e-3, and end to end it moves a third of the fine depths, some by a whole bin (sample_pdf) -- fp64
+        autograd of the oracle sits 1e-3 ... 2e-1 from its own fp32 autograd here.  "Equal to fp32 autograd" can then only mean
+        "as close to it as exact arithmetic is": within 3x the fp64 oracle's own distance (floor 1e-3), for
+        (b) the end-to-end gradient through the whole GPU path (utils.get_rays on the device included): median and worst
+            case over the iterates;
+        (c) the free-running loop's distance from the fp32 oracle's, against the free-running fp64 oracle's.
+    The bf16 leg prints the same table ("a gradient 23 degrees off fp32" -- here cosine 0.2 and below at some
+    iterates even on identical rays and depths) and only has to reduce the loss."""
+    from nerf_shared_amd import nerf, render_utils, utils
+    H = W = 14
+    K = synth.lego_intrinsics(H, W)
+    cfg = dict(BASE, N_samples=32, N_importance=48)
+    r = render_utils.Renderer(**cfg)
+    pairs = []
+    for trained in sphere_run[1][:2]:
+        sd = {k: v.detach().cpu().clone() for k, v in trained.state_dict().items()}
+        m = nerf.NeRF(**VD)
+        m.load_state_dict(sd)
+        m = m.to(dev)
+        m.precision = precision
+        m.requires_grad_(False)
+        pairs.append((m, {k: v.detach() for k, v in O.state_dict_to_torch(sd).items()}))
+    (mc, co), (mf, fo) = pairs
+    arch = O.Arch(**VD)
+    c2w0 = torch.from_numpy(synth.LEGO_C2W.astype(np.float32))
+    ocfg = O.RenderCfg(**cfg)
+    w0, dt0 = [0.02, -0.03, 0.015], [0.06, -0.05, 0.04]
+    steps, lr = 15, 2e-3
+
+    def assemble(ro, rd):                          # Renderer.render's batch assembly (render_utils.py:205-226)
+        ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+        vdir = rd / torch.norm(rd, dim=-1, keepdim=True)
+        return torch.cat([ro, rd, 2.0 * torch.ones_like(rd[:, :1]), 6.0 * torch.ones_like(rd[:, :1]), vdir], -1)
+
+    with torch.no_grad():
+        target = O.render_rays(ocfg, assemble(*O.get_rays(H, W, K, c2w0)), (co, arch), (fo, arch))["rgb_map"]
+
+    last = {}
+
+    def gpu_loss(pose):
+        out = r.render_rays(assemble(*utils.get_rays(H, W, K, pose)), mc, mf, retweights=True)
+        last["z"] = out["z_vals"].detach().cpu()
+        return utils.img2mse(out["rgb_map"], target.to(dev))
+
+    def cpu_loss(dtype, staged):
+        cast = lambda sd: {k: v.to(dtype) for k, v in sd.items()}     # noqa: E731
+        c, f = (cast(co), arch), (cast(fo), arch)
+
+        def loss(pose):
+            b = assemble(*O.get_rays(H, W, K, pose.to(dtype))).to(dtype)
+            rgb = oracle_two_pass(cfg, b, c, f, last["z"].to(dtype))[0] if staged else O.render_rays(ocfg, b, c, f)["rgb_map"]
+            return ((rgb - target.to(dtype)) ** 2).mean()
+        return loss
+
+    def run(device, loss_fn, forced=None, dtype=torch.float32, also=()):
+        """The Adam loop; with forced = a recorded trajectory the gradient is evaluated at ITS iterates (no steps taken), and
+        every function of `also` is differentiated at the same iterate right after loss_fn."""
+        w = torch.tensor(w0, device=device, dtype=dtype, requires_grad=True)
+        dt = torch.tensor(dt0, device=device, dtype=dtype, requires_grad=True)
+        opt = torch.optim.Adam([w, dt], lr=lr)
+        traj, losses, grads = [], [], [[] for _ in range(1 + len(also))]
+        for k in range(steps):
+            if forced is not None:
+                with torch.no_grad():
+                    w.copy_(torch.from_numpy(forced[k][:3]))
+                    dt.copy_(torch.from_numpy(forced[k][3:]))
+            traj.append(torch.cat([w.detach(), dt.detach()]).cpu().double().numpy().copy())
+            for i, fn in enumerate((loss_fn,) + tuple(also)):
+                opt.zero_grad()
+                if i == 0:
+                    loss = fn(_pose(w, dt, c2w0.to(device=device, dtype=dtype)))
+                    loss.backward()
+                    losses.append(float(loss.detach()))
+                else:                                            # a CPU function beside a GPU loop
+                    wc, dc = w.detach().cpu().clone().requires_grad_(True), dt.detach().cpu().clone().requires_grad_(True)
+                    fn(_pose(wc, dc, c2w0)).backward()
+                grads[i].append((torch.cat([w.grad, dt.grad]) if i == 0 else torch.cat([wc.grad, dc.grad])).cpu().double().numpy().copy())
+            if forced is None:
+                opt.step()
+        return np.array(traj), losses, [np.array(g) for g in grads]
+
+    def rel_rows(a, b):
+        return np.linalg.norm(a - b, axis=1) / np.linalg.norm(b, axis=1)
+
+    def cos_rows(a, b):
+        return (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+
+    cpu = torch.device("cpu")
+    ref, ref_losses, (g32,) = run(cpu, cpu_loss(torch.float32, False))
+    _, _, (g64,) = run(cpu, cpu_loss(torch.float64, False), forced=ref, dtype=torch.float64)
+    _, forced_losses, (g_gpu,) = run(dev, gpu_loss, forced=ref)
+    # (a) the same ray values on both sides, the oracle's fine pass on the run's depths
+    g_same, g32_staged, g64_staged = [], [], []
+    co64, fo64 = ({k: v.double() for k, v in co.items()}, arch), ({k: v.double() for k, v in fo.items()}, arch)
+    for k in range(steps):
+        w = torch.from_numpy(ref[k][:3]).float().requires_grad_(True)
+        dt = torch.from_numpy(ref[k][3:]).float().requires_grad_(True)
+        ro, rd = O.get_rays(H, W, K, _pose(w, dt, c2w0))
+        ro_g, rd_g = ro.detach().to(dev).requires_grad_(True), rd.detach().to(dev).requires_grad_(True)
+        out = r.render_rays(assemble(ro_g, rd_g), mc, mf, retweights=True)
+        utils.img2mse(out["rgb_map"], target.to(dev)).backward()
+        g_same.append(torch.cat(torch.autograd.grad([ro, rd], [w, dt], [ro_g.grad.cpu(), rd_g.grad.cpu()], retain_graph=True)).double().numpy())
+        rgb = oracle_two_pass(cfg, assemble(ro, rd), (co, arch), (fo, arch), out["z_vals"].detach().cpu())[0]
+        g32_staged.append(torch.cat(torch.autograd.grad(((rgb - target) ** 2).mean(), [w, dt], retain_graph=True)).double().numpy())
+        rgb = oracle_two_pass(cfg, assemble(ro, rd).double(), co64, fo64, out["z_vals"].detach().cpu().double())[0]
+        g64_staged.append(torch.cat(torch.autograd.grad(((rgb - target.double()) ** 2).mean(), [w, dt])).double().numpy())
+    g_same, g32_staged, g64_staged = np.array(g_same), np.array(g32_staged), np.array(g64_staged)
+    staged, yard_staged = rel_rows(g_same, g32_staged), rel_rows(g64_staged, g32_staged)
+    e2e, yard = rel_rows(g_gpu, g32), rel_rows(g64, g32)
+    print(precision, "gradient at the fp32 oracle's iterates, relative L2 from ITS gradient")
+    print("  (a) same rays, the run's depths:", ["%.1e" % v for v in staged], "cos min %.8f" % cos_rows(g_same, g32_staged).min())
+    print("      the fp64 oracle there:      ", ["%.1e" % v for v in yard_staged], "cos min %.8f" % cos_rows(g64_staged, g32_staged).min())
+    print("  (b) end to end:                 ", ["%.1e" % v for v in e2e], "cos min %.6f" % cos_rows(g_gpu, g32).min())
+    print("      the fp64 oracle:            ", ["%.1e" % v for v in yard], "cos min %.6f" % cos_rows(g64, g32).min())
+    print("  loss there", ["%.6f" % v for v in forced_losses[::2]], "fp32 oracle", ["%.6f" % v for v in ref_losses[::2]])
+    got, losses, _ = run(dev, gpu_loss)
+    ref64, losses64, _ = run(cpu, cpu_loss(torch.float64, False), dtype=torch.float64)
+    travelled = np.abs(ref[-1] - np.array(w0 + dt0)).max()
+    drift, drift64 = np.abs(got - ref).max(axis=1), np.abs(ref64 - ref).max(axis=1)
+    print("free-running loop: loss", ["%.5f" % v for v in losses[::2]])
+    print("      fp32 oracle: loss", ["%.5f" % v for v in ref_losses[::2]])
+    print("      fp64 oracle: loss", ["%.5f" % v for v in losses64[::2]])
+    print("  max |parameter - fp32 oracle's| per step", ["%.1e" % v for v in drift])
+    print("  the fp64 oracle's                       ", ["%.1e" % v for v in drift64], "; the fp32 oracle travelled %.3e" % travelled)
+    assert losses[-1] < 0.6 * losses[0] and ref_losses[-1] < 0.6 * ref_losses[0]
+    if precision == "fp32_split":
+        np.testing.assert_allclose(forced_losses, ref_losses, rtol=1e-2)
+        # (a): ~1e-6 except where a ReLU sits within rounding of zero at a point that carries the image's gradient (the fp64
+        # oracle shows the same sporadic 1e-3 ... 1e-2 against the fp32 one): typical value and direction gated tightly, the
+        # worst case against the fp64 oracle's worst case
+        assert np.median(staged) < 1e-4 and cos_rows(g_same, g32_staged).min() > GATE_COS, staged
+        assert staged.max() < 3.0 * max(yard_staged.max(), 1e-3), (staged, yard_staged)
+        # (b), (c): against the fp64 oracle's own distance from the fp32 oracle (the kinks are hit at different iterates by
+        # different arithmetics, so typical and worst values are compared, not iterate by iterate)
+        assert np.median(e2e) < 3.0 * max(np.median(yard), 1e-3) and e2e.max() < 3.0 * max(yard.max(), 1e-3), (e2e, yard)
+        assert drift.max() < 3.0 * max(drift64.max(), 1e-3 * travelled), (drift, drift64)
 
 
 def test_loss_scale_is_invisible(dev):
