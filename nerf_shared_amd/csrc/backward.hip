@@ -929,6 +929,7 @@ constexpr int DW_MAX_JOBS = 16;
 struct DwJob {
     DwArgs a;
     int shape;                           // 0: <16,16,4,2>  1: <8,16,4,2>  2: <16,4,8,1>  3: <8,2,8,1>  4: <16,16,4,2> + head  5: head alone on 8 X tiles
+                                         // 6: <16,8,4,2>  7: <8,4,8,1>   (the encodings of a multires 15 / 6 model)
     int first_block, n_blocks;
 };
 struct DwMulti {
@@ -959,6 +960,8 @@ __global__ __launch_bounds__(512, 2) void dw_multi_kernel(DwMulti m) {
     case 2: dw2_body<16, 4, 8, 1>(J.a, wg, J.n_blocks); break;
     case 3: dw2_body<8, 2, 8, 1>(J.a, wg, J.n_blocks); break;
     case 4: dw2_body<16, 16, 4, 2, true>(J.a, wg, J.n_blocks); break;
+    case 6: dw2_body<16, 8, 4, 2>(J.a, wg, J.n_blocks); break;
+    case 7: dw2_body<8, 4, 8, 1>(J.a, wg, J.n_blocks); break;
     default: dw_head_body<8>(J.a, wg, J.n_blocks); break;
     }
 #ifdef NERF_AMD_X_DW_STAMPS
@@ -1080,9 +1083,11 @@ constexpr size_t SLAB_FLOATS = (size_t)256 * (256 * 256 + 256);
 constexpr int DW_GRID = 256;
 size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 
-// Rows of a saved xyz-encoding row: 32 per k-step; the split-precision arrays pad a three-k-step encoding (multires 15) to
-// 128 so that its weight-gradient product keeps power-of-two rows (dw2s_body; the extra slots map to no weight column).
-int enc_row_slots(int k16, bool split) { return split && k16 == 3 ? 128 : 32 * k16; }
+// Rows of a saved xyz-encoding row: 32 per k-step; a three-k-step encoding (multires 15) is padded to 128 so that its
+// weight-gradient product keeps power-of-two rows and streams with the others in the one launch (dw2_body / dw2s_body; the
+// extra slots are zero and map to no weight column).  (Round 4: the bf16 arrays too -- their 96-slot rows had left the two
+// xyz-encoding products of a multires-15 model on the round-1 kernel, 174 us each beside a 284-us launch of everything else.)
+int enc_row_slots(int k16, bool split) { (void)split; return k16 == 3 ? 128 : 32 * k16; }
 
 int64_t carve(const Program &p, int64_t P_points, char *base, TrainWs *w, bool split) {
     const size_t P = (size_t)pad_points(P_points);     // rows for the last workgroup's padding points too
@@ -1190,12 +1195,12 @@ struct DwSeq {
 template <int OT, int IT, int WO, int WI>
 static int launch_dw2(const DwArgs &a, const DwReduceArgs &ra, DwSeq &q) {
     if (q.multi) {
-        static_assert((OT == 16 && IT == 16) || (OT == 8 && IT == 16) || (OT == 16 && IT == 4), "shape not in dw_multi_kernel");
+        static_assert((OT == 16 && (IT == 16 || IT == 8 || IT == 4)) || (OT == 8 && (IT == 16 || IT == 4)), "shape not in dw_multi_kernel");
         if (q.mj.n >= DW_MAX_JOBS) return NERF_AMD_EINVAL;
         if (ra.HT && !(OT == 16 && IT == 16)) return NERF_AMD_EINVAL;      // a head rides on the 256 x 256 shape only
         DwJob &J = q.mj.job[q.mj.n];
         J.a = a;
-        J.shape = OT == 16 ? (IT == 16 ? (ra.HT ? 4 : 0) : 2) : 1;
+        J.shape = OT == 16 ? (IT == 16 ? (ra.HT ? 4 : 0) : IT == 8 ? 6 : 2) : (IT == 16 ? 1 : 7);
         DwReduceArgs &r = q.mr.r[q.mj.n];
         r = ra; r.OT = OT; r.IT = IT;
         ++q.mj.n;
@@ -1332,8 +1337,8 @@ static int weight_grad(DwSeq &s, int64_t P, float *slab, const uint16_t *X, int 
     if (n_out_slots == 256 && n_in_slots == 256) return g_variant == 50 ? launch_dw<16, 16, 4, 2>(a, r, s) : launch_dw2<16, 16, 4, 2>(a, r, s);
     if (n_out_slots == 128 && n_in_slots == 256 && g_variant != 50) return launch_dw2<8, 16, 4, 2>(a, r, s);
     if (n_out_slots == 256 && n_in_slots == 64) return g_variant == 50 ? launch_dw<16, 4, 8, 1>(a, r, s) : launch_dw2<16, 4, 8, 1>(a, r, s);
-    if (n_out_slots == 256 && n_in_slots == 96) return launch_dw<16, 6, 4, 2>(a, r, s);
-    if (n_out_slots == 128 && n_in_slots == 64) return launch_dw<8, 4, 8, 1>(a, r, s);
+    if (n_out_slots == 256 && n_in_slots == 128) return g_variant == 50 ? launch_dw<16, 8, 4, 2>(a, r, s) : launch_dw2<16, 8, 4, 2>(a, r, s);
+    if (n_out_slots == 128 && n_in_slots == 64) return g_variant == 50 ? launch_dw<8, 4, 8, 1>(a, r, s) : launch_dw2<8, 4, 8, 1>(a, r, s);
     if (n_out_slots == 128 && n_in_slots == 256) return launch_dw<8, 16, 4, 2>(a, r, s);
     if (n_out_slots == 128 && n_in_slots == 32) return launch_dw<8, 2, 8, 1>(a, r, s);
     return NERF_AMD_EUNSUPPORTED;
@@ -1366,9 +1371,9 @@ int train_param_grads(const Program &p, int64_t P, void *workspace, float *const
     TrainWs w;
     carve(p, P, static_cast<char *>(workspace), &w, split);
     if (split) return train_param_grads_split(p, P, w, gw, gb, stream, g_raw);
-    const int D = p.arch.D, W = p.arch.W, E = 32 * p.KE16, Dd = 32 * p.KD16, ic = p.input_ch, icv = p.input_ch_views;
+    const int D = p.arch.D, W = p.arch.W, E = enc_row_slots(p.KE16, false), Dd = 32 * p.KD16, ic = p.input_ch, icv = p.input_ch_views;
     const bool vd = p.arch.use_viewdirs != 0;
-    if (W != 256 || (E != 64 && E != 96) || (vd && Dd != 32 && Dd != 64)) return NERF_AMD_EUNSUPPORTED;
+    if (W != 256 || (E != 64 && E != 128) || (vd && Dd != 32 && Dd != 64)) return NERF_AMD_EUNSUPPORTED;
     DwSeq s;
     s.main_s = stream; s.slab = w.slab;
     constexpr int MAX_PRODUCTS = 24;

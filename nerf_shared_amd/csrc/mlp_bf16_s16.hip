@@ -400,7 +400,14 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16_kernel(MlpArgs 
     const int64_t HS = pad_points(a.P) * 256;                   // one saved hidden layer
     const int64_t BS = pad_points(a.P) * 32;                    // one layer of mask-bit rows
     if constexpr (SAVE) {
-        save_frags<KE, 32 * KE>(a.sv_e, E, pidx, q);
+        // a three-k-step encoding (multires 15) is saved in rows of 128 slots, the fourth k-step zero: its weight-gradient
+        // product then has power-of-two rows (backward.hip enc_row_slots)
+        constexpr int ROW_E = KE == 3 ? 128 : 32 * KE;
+        save_frags<KE, ROW_E>(a.sv_e, E, pidx, q);
+        if constexpr (KE == 3) {
+            const bf16x8 zero2[2] = {};
+            save_frags<1, ROW_E>(a.sv_e + 96, zero2, pidx, q);
+        }
         if constexpr (VD) save_frags<KD, 32 * KD>(a.sv_d, Dv, pidx, q);
     }
     bf16x8 A[16], B[16];

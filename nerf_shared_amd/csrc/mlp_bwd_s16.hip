@@ -223,7 +223,11 @@ struct BwdLedger {
     }
 };
 
-template <int LX, int LD, bool VD, class C>
+// RAYG: someone wants dL/dpts / dL/drays / dL/dviewdirs.  A training step does not (render_utils.py:145 cuts the only path
+// from the loss to the rays' depths, and the rays are data): then the three encoding products and the encodings' derivatives
+// -- 6-9 % of the chain's MFMAs, all of its trigonometry, and the registers that made the multires-15 instantiation spill
+// 120 VGPRs -- are skipped; their fragments pass through the ring unread (pipeline.h skip_frags).
+template <int LX, int LD, bool VD, class C, bool RAYG>
 __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bwd_s16_kernel(MlpArgs a) {
     constexpr int WG_POINTS = C::WAVES * 32;
     constexpr int KE = gen16_ksteps(LX), KD = VD ? gen16_ksteps(LD) : 1;
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bwd_s16_kernel(MlpArgs a
         const int64_t p = (int64_t)blockIdx.x * WG_POINTS + c.wave * 32 + cc * 16 + (lane & 15);
         pidx[cc] = p;
         valid[cc] = p < a.P;
-        {
+        if constexpr (RAYG) {
             const int64_t pc = valid[cc] ? p : a.P - 1;
             const int64_t ray = (int64_t)((uint32_t)pc / (uint32_t)a.S);
             rayi[cc] = ray;
@@ -322,10 +326,12 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bwd_s16_kernel(MlpArgs a
         tlayer<LayoutB::F_HV, 4, 1, 0, true, 128, NB, NF>(c, Grgb, Grgb, B, m_hv, a.g_hv, pidx, q);
         // g_feat = W_views[:, :256]^T g_hv          (feature_linear has no activation)
         tlayer<LayoutB::F_FEAT, 8, 4, 0, false, 256, NB, NF>(c, B, B, A, none, a.g_feat, pidx, q);
-        {   // view-direction encoding: g_dirs = W_views[:, 256:]^T g_hv, then through the encoding
+        if constexpr (RAYG) {   // view-direction encoding: g_dirs = W_views[:, 256:]^T g_hv, then through the encoding
             float g[2][8 * KD];
             tenc<LayoutB::F_DIRS, KD, 4, NB, NF>(c, B, g);
             static_for<2>([&](auto cc_) { constexpr int cc = cc_; encode16_bwd<LD, KD>(dv[cc][0], dv[cc][1], dv[cc][2], hh, bb, g[cc], gd[cc]); });
+        } else {
+            skip_frags<LayoutB::F_DIRS, 8 * KD, NB, NF>(c);
         }
         // g_h8 = relu'(h8) * (W_feature^T g_feat + W_alpha^T g_sigma)
         m_next = load_bits<8>(a.sv_bits + 6 * BS, pidx, q);
@@ -342,10 +348,12 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bwd_s16_kernel(MlpArgs a
     tlayer<LayoutB::F_L7 + 1 * 128, 8, 8, 0, true, 256, NB, NF>(c, A, A, B, m_cur, a.g_h + 5 * HS, pidx, q);
     m_cur = m_next; m_next = load_bits<8>(a.sv_bits + 3 * BS, pidx, q);
     tlayer<LayoutB::F_L7 + 2 * 128, 8, 8, 0, true, 256, NB, NF>(c, B, B, A, m_cur, a.g_h + 4 * HS, pidx, q);
-    {   // xyz encoding through the skip layer's [input_pts] columns (its pre-activation gradient is still in B)
+    if constexpr (RAYG) {   // xyz encoding through the skip layer's [input_pts] columns (its pre-activation gradient is still in B)
         float g[2][8 * KE];
         tenc<LayoutB::F_E5, KE, 8, NB, NF>(c, B, g);
         static_for<2>([&](auto cc_) { constexpr int cc = cc_; encode16_bwd<LX, KE>(xp[cc][0], xp[cc][1], xp[cc][2], hh, bb, g[cc], gx[cc]); });
+    } else {
+        skip_frags<LayoutB::F_E5, 16 * KE, NB, NF>(c);
     }
     m_cur = m_next; m_next = load_bits<8>(a.sv_bits + 2 * BS, pidx, q);
     tlayer<LayoutB::F_L4 + 0 * 128, 8, 8, 0, true, 256, NB, NF>(c, A, A, B, m_cur, a.g_h + 3 * HS, pidx, q);
@@ -355,13 +363,15 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bwd_s16_kernel(MlpArgs a
     tlayer<LayoutB::F_L4 + 2 * 128, 8, 8, 0, true, 256, NB, NF>(c, A, A, B, m_cur, a.g_h + 1 * HS, pidx, q);
     m_cur = m_next;
     tlayer<LayoutB::F_L4 + 3 * 128, 8, 8, 0, true, 256, NB, NF>(c, B, B, A, m_cur, a.g_h + 0 * HS, pidx, q);
-    {   // xyz encoding through pts_linears.0
+    if constexpr (RAYG) {   // xyz encoding through pts_linears.0
         float g[2][8 * KE];
         tenc<LayoutB::F_E0, KE, 8, NB, NF>(c, A, g);
         static_for<2>([&](auto cc_) { constexpr int cc = cc_; encode16_bwd<LX, KE>(xp[cc][0], xp[cc][1], xp[cc][2], hh, bb, g[cc], gx[cc]); });
+    } else {
+        skip_frags<LayoutB::F_E0, 16 * KE, NB, NF>(c);
     }
     // ---- point / ray gradients: sum the four lane quarters of each point, then one lane per point writes
-    static_for<2>([&](auto cc_) {
+    if constexpr (RAYG) static_for<2>([&](auto cc_) {
         constexpr int cc = cc_;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -387,8 +397,8 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bwd_s16_kernel(MlpArgs a
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // no LDS-DMA may outlive the workgroup
 }
 
-template <int LX, int LD, bool VD>
-static int launch_bwd(const MlpArgs &a, int n_frags_used, hipStream_t s) {
+template <int LX, int LD, bool VD, bool RAYG>
+static int launch_bwd_as(const MlpArgs &a, int n_frags_used, hipStream_t s) {
     constexpr int KE = gen16_ksteps(LX), KD = VD ? gen16_ksteps(LD) : 1;
     using C = Ctx<8, 16, NA_EXPERIMENT_BWD_NS, 8, 2, 0, 1, 0, BwdLedger<KE, KD, VD>>;
     if (n_frags_used != LayoutB<KE, KD, VD>::F_END) return NERF_AMD_EINVAL;
@@ -397,10 +407,17 @@ static int launch_bwd(const MlpArgs &a, int n_frags_used, hipStream_t s) {
     if (!VD && a.out_ch > 16) return NERF_AMD_EUNSUPPORTED;
     const size_t lds = C::RING_BYTES;
     static DynamicLdsOptIn opt_in;
-    if (opt_in.ensure(reinterpret_cast<const void *>(mlp_bwd_s16_kernel<LX, LD, VD, C>), lds) != hipSuccess) return NERF_AMD_EHIP;
+    if (opt_in.ensure(reinterpret_cast<const void *>(mlp_bwd_s16_kernel<LX, LD, VD, C, RAYG>), lds) != hipSuccess) return NERF_AMD_EHIP;
     const int64_t groups = (a.P + 255) / 256;
-    hipLaunchKernelGGL((mlp_bwd_s16_kernel<LX, LD, VD, C>), dim3((unsigned)groups), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((mlp_bwd_s16_kernel<LX, LD, VD, C, RAYG>), dim3((unsigned)groups), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
+}
+
+template <int LX, int LD, bool VD>
+static int launch_bwd(const MlpArgs &a, int n_frags_used, hipStream_t s) {
+    // the encoding products only when a gradient with respect to points, rays or view directions has a place to go
+    if (a.g_pts || a.g_rays || a.g_vd) return launch_bwd_as<LX, LD, VD, true>(a, n_frags_used, s);
+    return launch_bwd_as<LX, LD, VD, false>(a, n_frags_used, s);
 }
 
 int launch_mlp_bwd_s16(const MlpArgs &a, int multires, int multires_views, int use_viewdirs, int n_frags_used, hipStream_t s) {

@@ -206,7 +206,8 @@ struct BwdSplitLedger {
     }
 };
 
-template <int LX, int LD, bool VD, class C>
+// RAYG as in mlp_bwd_s16.hip: without a taker for dL/dpts, dL/drays or dL/dviewdirs the encoding products are skipped.
+template <int LX, int LD, bool VD, class C, bool RAYG>
 __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bwd_split_kernel(MlpArgs a) {
     constexpr int WG_POINTS = C::WAVES * 16;
     constexpr int KE = gen16_ksteps(LX), KD = VD ? gen16_ksteps(LD) : 1;
@@ -300,10 +301,12 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bwd_split_kernel(MlpArgs
         tlayer_split<Lay::F_HV, 4, 1, 0, true, 128, NB, NF>(c, Grgb, Grgb, B, m_hv, a.g_hv, a.g_hv_lo, p, q);
         // g_feat = W_views[:, :256]^T g_hv          (feature_linear has no activation)
         tlayer_split<Lay::F_FEAT, 8, 4, 0, false, 256, NB, NF>(c, B, B, A, none, a.g_feat, a.g_feat_lo, p, q);
-        {   // view-direction encoding: g_dirs = W_views[:, 256:]^T g_hv, then through the encoding
+        if constexpr (RAYG) {   // view-direction encoding: g_dirs = W_views[:, 256:]^T g_hv, then through the encoding
             float g[8 * KD];
             tenc_split<Lay::F_DIRS, KD, 4, NB, NF>(c, B, g);
             encode_split_bwd<LD, KD, 32 * KD>(a.sv_d, a.sv_d_lo, p, hh, bb, g, gd);
+        } else {
+            skip_frags<Lay::F_DIRS, 16 * KD, NB, NF>(c);
         }
         // g_h8 = relu'(h8) * (W_feature^T g_feat + W_alpha^T g_sigma)
         m_next = load_bits_split<8>(a.sv_bits + 6 * BS, p, q);
@@ -320,10 +323,12 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bwd_split_kernel(MlpArgs
     tlayer_split<Lay::F_L7 + 1 * 256, 8, 8, 0, true, 256, NB, NF>(c, A, A, B, m_cur, a.g_h + 5 * HS, a.g_h_lo + 5 * HS, p, q);
     m_cur = m_next; m_next = load_bits_split<8>(a.sv_bits + 3 * BS, p, q);
     tlayer_split<Lay::F_L7 + 2 * 256, 8, 8, 0, true, 256, NB, NF>(c, B, B, A, m_cur, a.g_h + 4 * HS, a.g_h_lo + 4 * HS, p, q);
-    {   // xyz encoding through the skip layer's [input_pts] columns (its pre-activation gradient is still in B)
+    if constexpr (RAYG) {   // xyz encoding through the skip layer's [input_pts] columns (its pre-activation gradient is still in B)
         float g[8 * KE];
         tenc_split<Lay::F_E5, KE, 8, NB, NF>(c, B, g);
         encode_split_bwd<LX, KE, (KE == 3 ? 128 : 32 * KE)>(a.sv_e, a.sv_e_lo, p, hh, bb, g, gx);
+    } else {
+        skip_frags<Lay::F_E5, 32 * KE, NB, NF>(c);
     }
     m_cur = m_next; m_next = load_bits_split<8>(a.sv_bits + 2 * BS, p, q);
     tlayer_split<Lay::F_L4 + 0 * 256, 8, 8, 0, true, 256, NB, NF>(c, A, A, B, m_cur, a.g_h + 3 * HS, a.g_h_lo + 3 * HS, p, q);
@@ -333,10 +338,12 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bwd_split_kernel(MlpArgs
     tlayer_split<Lay::F_L4 + 2 * 256, 8, 8, 0, true, 256, NB, NF>(c, A, A, B, m_cur, a.g_h + 1 * HS, a.g_h_lo + 1 * HS, p, q);
     m_cur = m_next;
     tlayer_split<Lay::F_L4 + 3 * 256, 8, 8, 0, true, 256, NB, NF>(c, B, B, A, m_cur, a.g_h + 0 * HS, a.g_h_lo + 0 * HS, p, q);
-    {   // xyz encoding through pts_linears.0
+    if constexpr (RAYG) {   // xyz encoding through pts_linears.0
         float g[8 * KE];
         tenc_split<Lay::F_E0, KE, 8, NB, NF>(c, A, g);
         encode_split_bwd<LX, KE, (KE == 3 ? 128 : 32 * KE)>(a.sv_e, a.sv_e_lo, p, hh, bb, g, gx);
+    } else {
+        skip_frags<Lay::F_E0, 32 * KE, NB, NF>(c);
     }
     // ---- point / ray gradients: sum the four lane quarters of the point, take the loss scale off, one lane writes
 #pragma unroll
@@ -345,7 +352,7 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bwd_split_kernel(MlpArgs
         gd[k] += __shfl_xor(gd[k], 16); gd[k] += __shfl_xor(gd[k], 32);
         gx[k] *= S_inv; gd[k] *= S_inv;
     }
-    if (valid && q == 0) {
+    if (RAYG && valid && q == 0) {
         if (a.g_pts) { a.g_pts[3 * p] = gx[0]; a.g_pts[3 * p + 1] = gx[1]; a.g_pts[3 * p + 2] = gx[2]; }
         if (a.g_rays) {
 #pragma unroll
@@ -363,8 +370,8 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bwd_split_kernel(MlpArgs
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // no LDS-DMA may outlive the workgroup
 }
 
-template <int LX, int LD, bool VD>
-static int launch_bwd_split(const MlpArgs &a, int n_frags_used, hipStream_t s) {
+template <int LX, int LD, bool VD, bool RAYG>
+static int launch_bwd_split_as(const MlpArgs &a, int n_frags_used, hipStream_t s) {
     constexpr int KE = gen16_ksteps(LX), KD = VD ? gen16_ksteps(LD) : 1;
     using C = Ctx<8, 16, 4, 8, 2, 0, 1, 0, BwdSplitLedger<KE, KD, VD>>;
     if (n_frags_used != LayoutBS<KE, KD, VD>::F_END) return NERF_AMD_EINVAL;
@@ -374,10 +381,16 @@ static int launch_bwd_split(const MlpArgs &a, int n_frags_used, hipStream_t s) {
     hipLaunchKernelGGL(gmax_kernel, dim3(GRAD_SCALE_PARTS), dim3(256), 0, s, a.g_raw, a.P * (int64_t)a.out_ch, a.g_scale);
     const size_t lds = C::RING_BYTES;
     static DynamicLdsOptIn opt_in;
-    if (opt_in.ensure(reinterpret_cast<const void *>(mlp_bwd_split_kernel<LX, LD, VD, C>), lds) != hipSuccess) return NERF_AMD_EHIP;
+    if (opt_in.ensure(reinterpret_cast<const void *>(mlp_bwd_split_kernel<LX, LD, VD, C, RAYG>), lds) != hipSuccess) return NERF_AMD_EHIP;
     const int64_t groups = (a.P + 127) / 128;
-    hipLaunchKernelGGL((mlp_bwd_split_kernel<LX, LD, VD, C>), dim3((unsigned)groups), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((mlp_bwd_split_kernel<LX, LD, VD, C, RAYG>), dim3((unsigned)groups), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
+}
+
+template <int LX, int LD, bool VD>
+static int launch_bwd_split(const MlpArgs &a, int n_frags_used, hipStream_t s) {
+    if (a.g_pts || a.g_rays || a.g_vd) return launch_bwd_split_as<LX, LD, VD, true>(a, n_frags_used, s);
+    return launch_bwd_split_as<LX, LD, VD, false>(a, n_frags_used, s);
 }
 
 int launch_mlp_bwd_split(const MlpArgs &a, int multires, int multires_views, int use_viewdirs, int n_frags_used, hipStream_t s) {

@@ -312,6 +312,21 @@ __device__ __forceinline__ bf16x8 take(C &c) {
     }
 }
 
+// Fragments [F0, F0 + N) of the stream pass unread (a product the caller does not need -- the dX chains' encoding products
+// when no ray gradient is asked for): their syncs and DMA issue sites stay where take<n> has them, and the read-ahead queue
+// is refilled so that fragment F0 + N is the next one out.
+template <int F0, int N, int NB, int NFRAGS, class C>
+__device__ __forceinline__ void skip_frags(C &c) {
+    static_for<N>([&](auto i_) {
+        constexpr int n = F0 + i_;
+        maybe_sync<n, NB>(c);
+        late_issue<n, NB, NFRAGS>(c);
+        if constexpr (C::LA > 0 && (C::ABL & 2) == 0) {
+            if constexpr (n + C::LA >= F0 + N && n + C::LA < NFRAGS) c.q[n % C::LA] = ring_frag<n + C::LA>(c);
+        }
+    });
+}
+
 // o + d * z with the product rounded before the sum, as the reference's two ATen ops do (render_utils.py:131).  HIP's
 // __fmul_rn / __fadd_rn are plain operators to the compiler, which contracts them into one v_fma (single rounding) under
 // the default -ffp-contract=fast -- the round-1 kernels did, in the rays + depths mode.  The empty asm makes the product

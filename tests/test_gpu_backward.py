@@ -803,9 +803,10 @@ def test_fused_kernel_encodings_match_the_reference_embedder(dev, arch):
     P = R * S
     P_pad = (P + 255) // 256 * 256
 
-    def rows(offset, K):
-        n = P_pad * 32 * K
-        bits = ws[offset:offset + 2 * n].view(np.uint16).reshape(P_pad, 32 * K)[:P]
+    def rows(offset, K, row):
+        n = P_pad * row
+        bits = ws[offset:offset + 2 * n].view(np.uint16).reshape(P_pad, row)[:P]
+        assert not bits[:, 32 * K:].any()                   # the padding slots of a 128-slot row (multires 15) are zero
         return (bits.astype(np.uint32) << 16).view(np.float32)
 
     def check(got, x, L, K, what):
@@ -829,9 +830,10 @@ def test_fused_kernel_encodings_match_the_reference_embedder(dev, arch):
         print("%s: %d of %d encoded values differ from bf16(reference) (%.3f %%)" % (what, bad, total, 100.0 * bad / total))
         assert bad <= 0.001 * total, (what, bad, total)
 
-    off_d = (P_pad * 32 * KE * 2 + 255) // 256 * 256
-    check(rows(0, KE), pts.reshape(-1, 3), Lx, KE, "xyz L=%d" % Lx)
-    check(rows(off_d, KD), np.repeat(vd, S, axis=0), Ld, KD, "dirs L=%d" % Ld)
+    row_e = 128 if KE == 3 else 32 * KE                     # backward.hip enc_row_slots
+    off_d = (P_pad * row_e * 2 + 255) // 256 * 256
+    check(rows(0, KE, row_e), pts.reshape(-1, 3), Lx, KE, "xyz L=%d" % Lx)
+    check(rows(off_d, KD, 32 * KD), np.repeat(vd, S, axis=0), Ld, KD, "dirs L=%d" % Ld)
 
 
 @pytest.mark.parametrize("arch", [VD, VD15], ids=["multires10_4", "multires15_6"])
@@ -856,7 +858,7 @@ def test_saved_hidden_activations_match_the_rounding_model(dev, arch):
     P = R * S
     Pp = (P + 255) // 256 * 256
     al = lambda v: (v + 255) // 256 * 256                                      # noqa: E731
-    off = al(Pp * 32 * KE * 2) + al(Pp * 32 * KD * 2)                           # past the saved encodings
+    off = al(Pp * (128 if KE == 3 else 32 * KE) * 2) + al(Pp * 32 * KD * 2)     # past the saved encodings (enc_row_slots)
     slot_to_feature = np.array([32 * ks + 16 * (j >> 2) + 4 * q + (j & 3) for ks in range(8) for q in range(4) for j in range(8)])
     rb = lambda x: x.to(torch.bfloat16).to(torch.float32)                       # noqa: E731
     sd = {k: v.detach() for k, v in cpu.items()}

@@ -277,7 +277,10 @@ def test_backward_kernel_vmcnt_ledger_matches_its_isa(tmp_path):
     import check_vmcnt
     asm = device_isa("mlp_bwd_s16", tmp_path)
     # one instantiation per supported encoding pair; fragments = LayoutB<KE, KD>::F_END, 16 per ring block
-    for tag, frags in (("mlp_bwd_s16_kernelILi10ELi4E", 1184), ("mlp_bwd_s16_kernelILi15ELi6E", 1224)):
+    # (the trailing template argument: with / without the encoding products, i.e. ray gradients asked for or not -- the
+    # skipped fragments keep their syncs and DMA sites, pipeline.h skip_frags)
+    for tag, frags in ((("mlp_bwd_s16_kernelILi10ELi4E", "EEELb1EEEv"), 1184), (("mlp_bwd_s16_kernelILi15ELi6E", "EEELb1EEEv"), 1224),
+                       (("mlp_bwd_s16_kernelILi10ELi4E", "EEELb0EEEv"), 1184), (("mlp_bwd_s16_kernelILi15ELi6E", "EEELb0EEEv"), 1224)):
         stats = check_vmcnt.check(asm, tag, verbose=False)
         assert stats["kernels"] == 1 and stats["ok"], tag
         assert stats["syncs"] == -(-frags // 16) and stats["dma_pieces"] == 2 * -(-frags // 16), (tag, stats)
@@ -285,8 +288,9 @@ def test_backward_kernel_vmcnt_ledger_matches_its_isa(tmp_path):
         assert not check_vmcnt.check(asm, tag, verbose=False, slack=-4)["ok"]
     # the split-precision dX chain (mlp_bwd_split.hip): fragments = LayoutBS<KE, KD>::F_END, the same ring
     asm = device_isa("mlp_bwd_split", tmp_path)
-    for tag, frags in (("mlp_bwd_split_kernelILi10ELi4ELb1E", 2368), ("mlp_bwd_split_kernelILi15ELi6ELb1E", 2448),
-                       ("mlp_bwd_split_kernelILi10ELi0ELb0E", 1952)):
+    for tag, frags in ((("mlp_bwd_split_kernelILi10ELi4ELb1E", "EEELb1EEEv"), 2368), (("mlp_bwd_split_kernelILi15ELi6ELb1E", "EEELb1EEEv"), 2448),
+                       (("mlp_bwd_split_kernelILi10ELi0ELb0E", "EEELb1EEEv"), 1952), (("mlp_bwd_split_kernelILi10ELi4ELb1E", "EEELb0EEEv"), 2368),
+                       (("mlp_bwd_split_kernelILi15ELi6ELb1E", "EEELb0EEEv"), 2448)):
         stats = check_vmcnt.check(asm, tag, verbose=False)
         assert stats["kernels"] == 1 and stats["ok"], (tag, stats)
         assert stats["syncs"] == -(-frags // 16) and stats["dma_pieces"] == 2 * -(-frags // 16), (tag, stats)

@@ -25,7 +25,8 @@ def check(path, want="", verbose=True, slack=0, lag=0):
     stats = {"ok": True, "kernels": 0, "syncs": 0, "dma_pieces": 0, "min_inflight": None}
     for f in funcs:
         name = f.split(":", 1)[0].strip()
-        if "s_barrier" not in f or not ("global_load_lds" in f or re.search(r"buffer_load_dwordx4 .* lds", f)) or want not in name:
+        wants = (want,) if isinstance(want, str) else tuple(want)      # every substring must occur in the symbol
+        if "s_barrier" not in f or not ("global_load_lds" in f or re.search(r"buffer_load_dwordx4 .* lds", f)) or not all(w in name for w in wants):
             continue
         stats["kernels"] += 1
         queue = []          # in issue order: ('dma', block) / ('st',) / ('ld',)

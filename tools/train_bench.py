@@ -30,12 +30,15 @@ def main():
     ap.add_argument("--tuning", type=int, default=0, help="nerf_amd_set_tuning(0, value): 50 = round-1 weight-gradient kernel")
     ap.add_argument("--precision", choices=["bf16", "fp32_split", "fp32"], default="bf16",
                     help="arithmetic of the field and of its backward pass (fp32 trains on the split-precision kernels)")
+    ap.add_argument("--multires", type=int, default=10)
+    ap.add_argument("--multires-views", type=int, default=4, help="15 / 6: configs/stonehenge.txt:18-19")
     ap.add_argument("--graph", action="store_true", help="utils.CapturedTrainStep: the step captured in a HIP graph and replayed")
     ap.add_argument("--cprofile", action="store_true", help="print the host-side profile of the timed steps (cProfile)")
     args = ap.parse_args()
     from nerf_shared_amd import _lib
     _lib.check(_lib.lib.nerf_amd_set_tuning(0, args.tuning), "set_tuning")
     dev = torch.device("cuda:0")
+    ARCH.update(multires=args.multires, multires_views=args.multires_views)
     models = []
     for seed in (0, 10):
         m = nerf.NeRF(**ARCH)
