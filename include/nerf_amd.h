@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NERF_AMD_ABI_VERSION 6
+#define NERF_AMD_ABI_VERSION 7
 
 #define NERF_AMD_OK            0
 #define NERF_AMD_EINVAL       -1   /* bad argument / unsupported shape        */
@@ -88,6 +88,22 @@ typedef struct nerf_amd_model nerf_amd_model;   /* opaque, library-owned */
 int  nerf_amd_model_create(const nerf_amd_arch *arch, int device, nerf_amd_model **out);
 int  nerf_amd_model_update(nerf_amd_model *m, const float *const *weights, const float *const *biases,
                            int n_tensors, void *stream);
+/*
+ * The same for some of the packed copies only (a training step in one precision needs two of the five; re-packing all
+ * of them after every optimizer step is 22 us per model of a 1.6-ms step).  `copies`: bit-or of NERF_AMD_COPY_*.
+ * `others_current` != 0: the parameters are the ones the OTHER copies were packed from (a copy is being added for the
+ * same weights) -- they stay valid; 0: the parameters changed, the other copies become stale.  Every entry point
+ * fails with NERF_AMD_EINVAL when the copy it needs is stale or was never packed.  nerf_amd_model_update =
+ * NERF_AMD_COPY_ALL.
+ */
+#define NERF_AMD_COPY_BF16      1   /* bf16 fragment streams + bias tables: NERF_AMD_PREC_BF16 inference and training forward */
+#define NERF_AMD_COPY_BWD       2   /* transposed bf16 stream: nerf_amd_field_backward in NERF_AMD_PREC_BF16 */
+#define NERF_AMD_COPY_SPLIT     4   /* fp16 (hi, lo) pair stream + bias table: NERF_AMD_PREC_FP32_SPLIT */
+#define NERF_AMD_COPY_BWD_SPLIT 8   /* transposed pair stream: nerf_amd_field_backward in split precision */
+#define NERF_AMD_COPY_FP32      16  /* fp32 fragment stream + biases: NERF_AMD_PREC_FP32, nerf_amd_mlp_embedded */
+#define NERF_AMD_COPY_ALL       31
+int  nerf_amd_model_update_copies(nerf_amd_model *m, const float *const *weights, const float *const *biases,
+                                  int n_tensors, int copies, int others_current, void *stream);
 void nerf_amd_model_destroy(nerf_amd_model *m);
 /* 1 when the fused bf16 kernel supports this architecture (D=8, W=256, skips=[4]). */
 int  nerf_amd_model_supports_bf16(const nerf_amd_model *m);

@@ -13,13 +13,17 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NERF_AMD_LIB selects another build of the same library (diagnostic builds such as -DNERF_AMD_STAMPS)
 LIB_PATH = os.environ.get("NERF_AMD_LIB") or os.path.join(_HERE, "libnerf_amd.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 PREC_FP32, PREC_BF16, PREC_FP32_SPLIT = 0, 1, 2
+# packed copies of a model's parameters (include/nerf_amd.h NERF_AMD_COPY_*) and which of them a call needs
+COPY_BF16, COPY_BWD, COPY_SPLIT, COPY_BWD_SPLIT, COPY_FP32, COPY_ALL = 1, 2, 4, 8, 16, 31
+COPY_OF = {PREC_BF16: COPY_BF16, PREC_FP32_SPLIT: COPY_SPLIT, PREC_FP32: COPY_FP32}                    # inference
+TRAIN_COPIES = {PREC_BF16: COPY_BF16 | COPY_BWD, PREC_FP32_SPLIT: COPY_SPLIT | COPY_BWD_SPLIT}        # forward_train + backward
 MAX_SKIPS = 8
 
 EXPORTS = (
     "nerf_amd_abi_version", "nerf_amd_last_error",
-    "nerf_amd_model_create", "nerf_amd_model_update", "nerf_amd_model_destroy",
+    "nerf_amd_model_create", "nerf_amd_model_update", "nerf_amd_model_update_copies", "nerf_amd_model_destroy",
     "nerf_amd_model_supports_bf16", "nerf_amd_model_supports_split", "nerf_amd_model_out_ch", "nerf_amd_pack_bf16_host",
     "nerf_amd_embed", "nerf_amd_nerf_forward", "nerf_amd_mlp_embedded", "nerf_amd_ndc_rays", "nerf_amd_raw2outputs", "nerf_amd_raw2outputs_backward", "nerf_amd_sample_pdf",
     "nerf_amd_render_rays_workspace", "nerf_amd_render_rays", "nerf_amd_render_chunks", "nerf_amd_make_rays",
@@ -64,6 +68,7 @@ def _load():
         "nerf_amd_last_error": (c_char_p, []),
         "nerf_amd_model_create": (c_int, [POINTER(Arch), c_int, POINTER(c_void_p)]),
         "nerf_amd_model_update": (c_int, [c_void_p, pp_f, pp_f, c_int, c_void_p]),
+        "nerf_amd_model_update_copies": (c_int, [c_void_p, pp_f, pp_f, c_int, c_int, c_int, c_void_p]),
         "nerf_amd_model_destroy": (None, [c_void_p]),
         "nerf_amd_model_supports_bf16": (c_int, [c_void_p]),
         "nerf_amd_model_supports_split": (c_int, [c_void_p]),

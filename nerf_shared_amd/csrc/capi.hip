@@ -68,7 +68,7 @@ struct nerf_amd_model {
     float *bias_bf16 = nullptr, *stream_f32 = nullptr, *bias_f32 = nullptr, *bias_s16 = nullptr;
     FragDesc *d_frags16 = nullptr;
     TileDesc *d_tiles16 = nullptr;
-    bool packed = false;
+    int fresh = 0;                       // NERF_AMD_COPY_* of the packed copies that hold the current parameters
 };
 
 extern "C" {
@@ -123,9 +123,10 @@ int nerf_amd_model_create(const nerf_amd_arch *arch, int device, nerf_amd_model 
     return NERF_AMD_OK;
 }
 
-int nerf_amd_model_update(nerf_amd_model *m, const float *const *weights, const float *const *biases,
-                          int n_tensors, void *stream) {
+int nerf_amd_model_update_copies(nerf_amd_model *m, const float *const *weights, const float *const *biases,
+                                 int n_tensors, int copies, int others_current, void *stream) {
     if (!m || !weights || !biases) return fail(NERF_AMD_EINVAL, "null argument");
+    if (copies & ~NERF_AMD_COPY_ALL) return fail(NERF_AMD_EINVAL, "unknown copy bits");
     const Program &p = m->prog;
     if (n_tensors != (int)p.tensors.size())
         return fail(NERF_AMD_EINVAL, "expected " + std::to_string(p.tensors.size()) + " parameter tensors, got " + std::to_string(n_tensors));
@@ -140,10 +141,15 @@ int nerf_amd_model_update(nerf_amd_model *m, const float *const *weights, const 
     int rc = launch_pack(p, m->d_frags, m->d_tiles, m->d_layers, m->d_tensors, wt, bt,
                          m->stream_bf16, m->bias_bf16, m->stream_f32, m->bias_f32,
                          m->d_frags16, m->d_tiles16, m->stream_s16, m->bias_s16, m->d_frags_bwd, m->stream_bwd,
-                         m->d_frags_split, m->stream_split, m->d_frags_bwd_split, m->stream_bwd_split, s);
+                         m->d_frags_split, m->stream_split, m->d_frags_bwd_split, m->stream_bwd_split, copies, s);
     if (rc) return fail(rc, "pack launch failed");
-    m->packed = true;
+    m->fresh = (others_current ? m->fresh : 0) | copies;
     return NERF_AMD_OK;
+}
+
+int nerf_amd_model_update(nerf_amd_model *m, const float *const *weights, const float *const *biases,
+                          int n_tensors, void *stream) {
+    return nerf_amd_model_update_copies(m, weights, biases, n_tensors, NERF_AMD_COPY_ALL, 0, stream);
 }
 
 void nerf_amd_model_destroy(nerf_amd_model *m) {
@@ -196,9 +202,17 @@ int nerf_amd_embed(const float *x, int64_t n, int multires, float *out, void *st
 
 namespace {
 
+// The packed copy an entry point is about to read must hold the current parameters.
+int need_copy(const nerf_amd_model *m, int copy) {
+    if (m->fresh & copy) return NERF_AMD_OK;
+    return fail(NERF_AMD_EINVAL, m->fresh ? "the packed copy of the parameters this call needs is stale or was never made (nerf_amd_model_update_copies)"
+                                          : "model has no parameters yet (call nerf_amd_model_update)");
+}
+
 int run_field(const nerf_amd_model *m, MlpArgs a, int precision, hipStream_t s) {
     const Program &p = m->prog;
-    if (!m->packed) return fail(NERF_AMD_EINVAL, "model has no parameters yet (call nerf_amd_model_update)");
+    if (int rc0 = need_copy(m, precision == NERF_AMD_PREC_BF16 ? NERF_AMD_COPY_BF16 : precision == NERF_AMD_PREC_FP32_SPLIT ? NERF_AMD_COPY_SPLIT : NERF_AMD_COPY_FP32))
+        return rc0;
     a.stream_bf16 = m->stream_bf16; a.bias_bf16 = m->bias_bf16;
     a.stream_s16 = m->stream_s16; a.bias_s16 = m->bias_s16;
     a.stream_split = m->stream_split;
@@ -325,7 +339,7 @@ int nerf_amd_field_forward_train(const nerf_amd_model *m, const float *pts, cons
     if (!pts && ray_ch != (vd ? 11 : 8)) return fail(NERF_AMD_EINVAL, vd ? "rays must be [R,11]" : "rays must be [R,8] for a model without view branch");
     if (pts && vd && !viewdirs) return fail(NERF_AMD_EINVAL, "pts mode needs viewdirs [R,3]");
     if (!train_precision_ok(precision) || !train_supported(m->prog)) return fail(NERF_AMD_EUNSUPPORTED, TRAIN_COVER);
-    if (!m->packed) return fail(NERF_AMD_EINVAL, "model has no parameters yet");
+    if (int rc0 = need_copy(m, precision == NERF_AMD_PREC_FP32_SPLIT ? NERF_AMD_COPY_SPLIT : NERF_AMD_COPY_BF16)) return rc0;
     if (R == 0) return NERF_AMD_OK;
     const bool split = precision == NERF_AMD_PREC_FP32_SPLIT;
     const int64_t P = R * S;
@@ -358,6 +372,7 @@ int nerf_amd_field_backward(const nerf_amd_model *m, const float *g_raw, const f
     if (n_tensors != (int)m->prog.tensors.size()) return fail(NERF_AMD_EINVAL, "wrong number of gradient tensors");
     if (n_points == 0) return NERF_AMD_OK;
     const bool split = precision == NERF_AMD_PREC_FP32_SPLIT;
+    if (int rc0 = need_copy(m, split ? NERF_AMD_COPY_BWD_SPLIT : NERF_AMD_COPY_BWD)) return rc0;
     if (!g_raw || !workspace || workspace_bytes < train_workspace_bytes(m->prog, n_points, split))
         return fail(NERF_AMD_EINVAL, "null pointer or workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -174,7 +174,7 @@ int launch_pack(const Program &p, const FragDesc *d_frags, const TileDesc *d_til
                 uint16_t *stream_bf16, float *bias_bf16, float *stream_f32, float *bias_f32,
                 const FragDesc *d_frags16, const TileDesc *d_tiles16, uint16_t *stream_s16, float *bias_s16,
                 const FragDesc *d_frags_bwd, uint16_t *stream_bwd, const FragDesc *d_frags_split, uint16_t *stream_split,
-                const FragDesc *d_frags_bwd_split, uint16_t *stream_bwd_split, hipStream_t s) {
+                const FragDesc *d_frags_bwd_split, uint16_t *stream_bwd_split, int copies, hipStream_t s) {
     PackJobs J;
     J.frags_bwd_split = d_frags_bwd_split; J.stream_bwd_split = stream_bwd_split;
     J.frags_bwd = d_frags_bwd; J.frags16 = d_frags16; J.frags = d_frags; J.frags_split = d_frags_split;
@@ -182,17 +182,20 @@ int launch_pack(const Program &p, const FragDesc *d_frags, const TileDesc *d_til
     J.tiles16 = d_tiles16; J.tiles = d_tiles; J.layers = d_layers; J.tensors = d_tensors;
     J.stream_bwd = stream_bwd; J.stream_s16 = stream_s16; J.stream_bf16 = stream_bf16;
     J.bias_s16 = bias_s16; J.bias_bf16 = bias_bf16; J.stream_f32 = stream_f32; J.bias_f32 = bias_f32;
-    J.n_bwd = p.bf16_ok ? (int)p.frags_bwd.size() : 0;
-    J.n16 = p.bf16_ok ? (int)p.frags16.size() : 0;
-    J.n32 = p.bf16_ok ? (int)p.frags.size() : 0;
-    J.n_split = p.bf16_ok ? (int)p.frags_split.size() : 0;
-    J.n_bwd_split = p.bf16_ok ? (int)p.frags_bwd_split.size() : 0;
-    J.n_tiles16 = p.bf16_ok ? (int)p.tiles16.size() : 0;
-    J.n_tiles = p.bf16_ok ? (int)p.tiles.size() : 0;
-    J.n_layers = (int)p.layers.size();
+    // copies: NERF_AMD_COPY_* (include/nerf_amd.h); a job that is not asked for gets no blocks
+    const bool c_bf16 = copies & NERF_AMD_COPY_BF16, c_split = copies & NERF_AMD_COPY_SPLIT;
+    J.n_bwd = p.bf16_ok && (copies & NERF_AMD_COPY_BWD) ? (int)p.frags_bwd.size() : 0;
+    J.n16 = p.bf16_ok && c_bf16 ? (int)p.frags16.size() : 0;
+    J.n32 = p.bf16_ok && c_bf16 ? (int)p.frags.size() : 0;
+    J.n_split = p.bf16_ok && c_split ? (int)p.frags_split.size() : 0;
+    J.n_bwd_split = p.bf16_ok && (copies & NERF_AMD_COPY_BWD_SPLIT) ? (int)p.frags_bwd_split.size() : 0;
+    J.n_tiles16 = p.bf16_ok && (c_bf16 || c_split) ? (int)p.tiles16.size() : 0;       // the 16-row bias table serves both
+    J.n_tiles = p.bf16_ok && c_bf16 ? (int)p.tiles.size() : 0;
+    J.n_layers = (copies & NERF_AMD_COPY_FP32) ? (int)p.layers.size() : 0;
     J.b_bias16 = (J.n_tiles16 * 16 + 511) / 512;
     J.b_bias32 = (J.n_tiles * 32 + 511) / 512;
     const unsigned grid = (unsigned)(J.n_bwd + J.n16 + J.n32 + J.n_split + J.n_bwd_split + J.b_bias16 + J.b_bias32 + J.n_layers * PACK_F32_BLOCKS);
+    if (grid == 0) return NERF_AMD_OK;
     hipLaunchKernelGGL(pack_all_kernel, dim3(grid), dim3(512), 0, s, J, d_w, d_b);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }

@@ -180,7 +180,7 @@ class _FieldTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, prec, pts, viewdirs, rays, z_vals, n_rays, n_samples, *params):
         dev = params[0].device
-        handle = model._model_handle(dev)
+        handle = model._model_handle(dev, _lib.TRAIN_COPIES[prec])      # the forward's copy and the backward's, one launch
         P = n_rays * n_samples
         nbytes = lib.nerf_amd_train_workspace(handle, P, prec)
         if nbytes < 0:
@@ -355,13 +355,20 @@ class NeRF(nn.Module):
             self.__dict__['_trainable_kernels'] = bool(lib.nerf_amd_model_supports_training(h, _lib.PREC_BF16))
         return self._handle
 
-    def _model_handle(self, device):
-        """Create the library handle on first use and re-pack when any parameter changed."""
+    def _model_handle(self, device, copies=None):
+        """Create the library handle on first use and re-pack when any parameter changed -- the packed copies the caller is
+        about to use (_lib.COPY_*; None: the one this model's own precision renders with).  A copy that was not asked for
+        since the parameters last changed is packed when someone first asks for it."""
         self._ensure_handle(device)
+        if copies is None:
+            copies = _lib.COPY_OF[self._precision_code()]
         # (data_ptr, _version) of every parameter: unchanged = same storage, same contents, hence same device and dtype
         params = [m._parameters[k] for k in ('weight', 'bias') for m in self._linears()]
         key = tuple([t.data_ptr() for t in params] + [t._version for t in params])
-        if key != self._packed_key:
+        same = key == self._packed_key
+        have = self.__dict__.get('_packed_copies', 0) if same else 0
+        missing = copies & ~have
+        if missing:
             for t in params:
                 if t.device != device or t.dtype != torch.float32:
                     raise _lib.NerfAmdError("NeRF parameters must be fp32 on %s (found %s on %s); call model.to(device)"
@@ -371,9 +378,10 @@ class NeRF(nn.Module):
             wp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in live[:n]])
             bp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in live[n:]])
             with torch.cuda.device(device):
-                _lib.check(lib.nerf_amd_model_update(self._handle, wp, bp, n, _lib.stream_of(device)),
-                           "nerf_amd_model_update")
+                _lib.check(lib.nerf_amd_model_update_copies(self._handle, wp, bp, n, missing, 1 if same else 0, _lib.stream_of(device)),
+                           "nerf_amd_model_update_copies")
             self._packed_key = key
+            self.__dict__['_packed_copies'] = have | missing
         return self._handle
 
     def _train_params(self):
@@ -445,7 +453,7 @@ class NeRF(nn.Module):
 
     def supports_bf16(self, device=None):
         dev = device or next(self.parameters()).device
-        return bool(lib.nerf_amd_model_supports_bf16(self._model_handle(torch.device(dev))))
+        return bool(lib.nerf_amd_model_supports_bf16(self._ensure_handle(torch.device(dev))))
 
     # -- reference API ------------------------------------------------------------
     def forward(self, inputs, viewdirs, netchunk=1024 * 64):
@@ -467,12 +475,12 @@ class NeRF(nn.Module):
             vd = (viewdirs if want else viewdirs.detach()).reshape(-1, 3).contiguous().float()
         elif self.use_viewdirs:
             raise _lib.NerfAmdError("this NeRF was built with use_viewdirs=True: viewdirs is required")
-        handle = self._model_handle(dev)
         out_ch = 4 if self.use_viewdirs else self.output_ch
         n_rays = pts.shape[0] // n_samples
         if want:
             raw = _FieldTrainFn.apply(self, self._train_precision(), pts, vd, None, None, n_rays, n_samples, *self._train_params())
             return raw.reshape(list(inputs.shape[:-1]) + [out_ch])
+        handle = self._model_handle(dev)
         out = torch.empty(pts.shape[0], out_ch, device=dev, dtype=torch.float32)
         with torch.cuda.device(dev):
             _lib.check(lib.nerf_amd_nerf_forward(handle, pts.data_ptr(), _lib.ptr(vd), n_rays, n_samples,
@@ -490,7 +498,7 @@ class NeRF(nn.Module):
         xe = x.detach().reshape(-1, x.shape[-1]).contiguous().float()
         if xe.shape[-1] != width:
             raise _lib.NerfAmdError("MLP expects %d embedded columns, got %d" % (width, xe.shape[-1]))
-        handle = self._model_handle(dev)
+        handle = self._model_handle(dev, _lib.COPY_FP32)
         out_ch = 4 if self.use_viewdirs else self.output_ch
         out = torch.empty(xe.shape[0], out_ch, device=dev, dtype=torch.float32)
         with torch.cuda.device(dev):

@@ -172,11 +172,15 @@ class Renderer(torch.nn.Module):
         self._check_model(coarse_model, "coarse_model")
         if fine_model is not None:
             self._check_model(fine_model, "fine_model")
-        hc = coarse_model._model_handle(dev)
-        hf = fine_model._model_handle(dev) if (fine_model is not None and int(self.N_importance) > 0) else None
+        use_fine = fine_model is not None and int(self.N_importance) > 0
+        coarse_model._ensure_handle(dev)
+        if use_fine:
+            fine_model._ensure_handle(dev)
         prec = coarse_model._precision_code()
-        if hf is not None and fine_model._precision_code() != prec:
+        if use_fine and fine_model._precision_code() != prec:
             prec = _lib.PREC_FP32
+        hc = coarse_model._model_handle(dev, _lib.COPY_OF[prec])      # only the packed copy this precision reads
+        hf = fine_model._model_handle(dev, _lib.COPY_OF[prec]) if use_fine else None
         return hc, hf, self._cfg(prec), lib.nerf_amd_model_out_ch(hc)
 
     def _chunk_io(self, rays, cfg, out_ch, outs, pytest, ws=None, z_pre=None, t_rand_out=None):
@@ -516,9 +520,7 @@ class Renderer(torch.nn.Module):
         _linspace01(int(self.N_samples), dev)
         if self.N_importance > 0:
             _linspace01(int(self.N_importance), dev)
-        coarse_model._model_handle(dev)
-        if fine_model is not None:
-            fine_model._model_handle(dev)
+        self._handles(dev, coarse_model, fine_model)
         cur = torch.cuda.current_stream(dev)
         ready = torch.cuda.Event()
         ready.record(cur)

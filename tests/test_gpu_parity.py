@@ -337,6 +337,57 @@ def test_weight_update_repacks(dev, golden):
     close(m(pts, vd), g["vd_s1"], atol=1e-4, rtol=1e-4)
 
 
+def test_packed_copies_follow_the_weights_and_the_precision(dev, golden):
+    """Only the packed copies a call needs are refreshed (nerf_amd_model_update_copies): switching the precision of a model
+    adds the missing copy for the SAME weights; changing the weights makes every copy stale, whichever precision asks next;
+    a training step in one precision followed by a render in another sees the stepped weights; and the C ABI refuses a
+    copy that is stale or was never made."""
+    import ctypes
+    nerf, render_utils, utils = amd()
+    from nerf_shared_amd import _lib
+    g = golden("g2_nerf")
+    pts, vd = torch.from_numpy(g["pts"]).to(dev), torch.from_numpy(g["viewdirs"]).to(dev)
+    m = gpu_model(dev, 0, 1.0, "bf16", **VD)
+    fresh = {p: gpu_model(dev, 0, 1.0, p, **VD)(pts, vd) for p in ("bf16", "fp32_split", "fp32")}
+    for p in ("bf16", "fp32_split", "fp32", "bf16"):       # one model, a copy added per precision, no weight change
+        m.precision = p
+        assert torch.equal(m(pts, vd), fresh[p]), p
+    assert m._packed_copies == _lib.COPY_BF16 | _lib.COPY_SPLIT | _lib.COPY_FP32
+    m.load_state_dict({k: v.to(dev) for k, v in synth.torch_state_dict(1, 3.0, **{**VD, "skips": (4,)}).items()})
+    m.precision = "fp32"                                    # the weights changed: the next call packs ITS copy only ...
+    close(m(pts, vd), g["vd_s1"], atol=1e-4, rtol=1e-4)
+    assert m._packed_copies == _lib.COPY_FP32
+    m.precision = "fp32_split"                              # ... and another precision gets the new weights too
+    close(m(pts, vd), g["vd_s1"], atol=1e-4, rtol=1e-4)
+    # a bf16 training step, then the same model rendered in split precision: the stepped weights, not the packed-before ones
+    t = gpu_model(dev, 0, 1.0, "bf16", **VD).requires_grad_(True)
+    opt = torch.optim.SGD(t.parameters(), lr=1e-2)
+    t(pts, vd).square().mean().backward()
+    assert t._packed_copies == _lib.COPY_BF16 | _lib.COPY_BWD
+    opt.step()
+    t.precision = "fp32_split"
+    with torch.no_grad():
+        after = t(pts, vd)
+    ref = gpu_model(dev, 0, 1.0, "fp32_split", **VD)
+    ref.load_state_dict(t.state_dict())
+    assert torch.equal(after, ref(pts, vd))
+    # the C ABI: a copy that was not packed is refused, loudly
+    h = m._handle
+    params = [mod._parameters[k] for k in ("weight", "bias") for mod in m._linears()]
+    n = len(params) // 2
+    wp = (ctypes.c_void_p * n)(*[x.data_ptr() for x in params[:n]])
+    bp = (ctypes.c_void_p * n)(*[x.data_ptr() for x in params[n:]])
+    lib = _lib.lib
+    assert lib.nerf_amd_model_update_copies(h, wp, bp, n, _lib.COPY_BF16, 0, _lib.stream_of(dev)) == 0
+    out = torch.empty(pts.shape[0] * pts.shape[1], 4, device=dev)
+    args = (h, pts.data_ptr(), vd.data_ptr(), pts.shape[0], pts.shape[1], out.data_ptr())
+    assert lib.nerf_amd_nerf_forward(*args, _lib.PREC_BF16, _lib.stream_of(dev)) == 0
+    rc = lib.nerf_amd_nerf_forward(*args, _lib.PREC_FP32, _lib.stream_of(dev))
+    assert rc != 0 and b"stale or was never made" in lib.nerf_amd_last_error()
+    assert lib.nerf_amd_model_update_copies(h, wp, bp, n, 64, 0, _lib.stream_of(dev)) != 0      # unknown bit
+    m.weights_changed()                                     # hand the handle back to the shim in a known state
+
+
 # ------------------------------------------------------------------ G3
 def test_raw2outputs_golden(dev, golden):
     _, render_utils, _ = amd()

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "library does not export %s" % name
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert lib.nerf_amd_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.nerf_amd_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_struct_layouts_match_header():
