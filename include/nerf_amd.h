@@ -100,8 +100,9 @@ int  nerf_amd_model_update(nerf_amd_model *m, const float *const *weights, const
 #define NERF_AMD_COPY_BWD       2   /* transposed bf16 stream: nerf_amd_field_backward in NERF_AMD_PREC_BF16 */
 #define NERF_AMD_COPY_SPLIT     4   /* fp16 (hi, lo) pair stream + bias table: NERF_AMD_PREC_FP32_SPLIT */
 #define NERF_AMD_COPY_BWD_SPLIT 8   /* transposed pair stream: nerf_amd_field_backward in split precision */
-#define NERF_AMD_COPY_FP32      16  /* fp32 fragment stream + biases: NERF_AMD_PREC_FP32, nerf_amd_mlp_embedded */
-#define NERF_AMD_COPY_ALL       31
+#define NERF_AMD_COPY_FP32      16  /* fp32 fragment stream + biases: NERF_AMD_PREC_FP32 (inference and training forward), nerf_amd_mlp_embedded */
+#define NERF_AMD_COPY_FP32_BWD  32  /* transposed fp32 stream: nerf_amd_field_backward in NERF_AMD_PREC_FP32 */
+#define NERF_AMD_COPY_ALL       63
 int  nerf_amd_model_update_copies(nerf_amd_model *m, const float *const *weights, const float *const *biases,
                                   int n_tensors, int copies, int others_current, void *stream);
 void nerf_amd_model_destroy(nerf_amd_model *m);

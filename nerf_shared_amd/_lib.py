@@ -16,9 +16,10 @@ LIB_PATH = os.environ.get("NERF_AMD_LIB") or os.path.join(_HERE, "libnerf_amd.so
 ABI_VERSION = 7
 PREC_FP32, PREC_BF16, PREC_FP32_SPLIT = 0, 1, 2
 # packed copies of a model's parameters (include/nerf_amd.h NERF_AMD_COPY_*) and which of them a call needs
-COPY_BF16, COPY_BWD, COPY_SPLIT, COPY_BWD_SPLIT, COPY_FP32, COPY_ALL = 1, 2, 4, 8, 16, 31
+COPY_BF16, COPY_BWD, COPY_SPLIT, COPY_BWD_SPLIT, COPY_FP32, COPY_FP32_BWD, COPY_ALL = 1, 2, 4, 8, 16, 32, 63
 COPY_OF = {PREC_BF16: COPY_BF16, PREC_FP32_SPLIT: COPY_SPLIT, PREC_FP32: COPY_FP32}                    # inference
-TRAIN_COPIES = {PREC_BF16: COPY_BF16 | COPY_BWD, PREC_FP32_SPLIT: COPY_SPLIT | COPY_BWD_SPLIT}        # forward_train + backward
+TRAIN_COPIES = {PREC_BF16: COPY_BF16 | COPY_BWD, PREC_FP32_SPLIT: COPY_SPLIT | COPY_BWD_SPLIT,       # forward_train + backward
+                PREC_FP32: COPY_FP32 | COPY_FP32_BWD}
 MAX_SKIPS = 8
 
 EXPORTS = (

@@ -68,6 +68,8 @@ struct nerf_amd_model {
     float *bias_bf16 = nullptr, *stream_f32 = nullptr, *bias_f32 = nullptr, *bias_s16 = nullptr;
     FragDesc *d_frags16 = nullptr;
     TileDesc *d_tiles16 = nullptr;
+    TrainLayerF32 *d_tlayers = nullptr;  // train_f32.hip: per-layer descriptors and the transposed fp32 stream
+    float *stream_f32_t = nullptr;
     int fresh = 0;                       // NERF_AMD_COPY_* of the packed copies that hold the current parameters
 };
 
@@ -97,7 +99,7 @@ int nerf_amd_model_create(const nerf_amd_arch *arch, int device, nerf_amd_model 
         (rc = upload(&m->d_frags16, p.frags16)) || (rc = upload(&m->d_tiles16, p.tiles16)) ||
         (rc = upload(&m->d_frags_bwd, p.frags_bwd)) || (rc = upload(&m->d_frags_split, p.frags_split)) ||
         (rc = upload(&m->d_frags_bwd_split, p.frags_bwd_split)) ||
-        (rc = upload(&m->d_layers, p.layers)) || (rc = upload(&m->d_tensors, p.tensors))) {
+        (rc = upload(&m->d_layers, p.layers)) || (rc = upload(&m->d_tensors, p.tensors)) || (rc = upload(&m->d_tlayers, p.tlayers))) {
         nerf_amd_model_destroy(m);
         return rc;
     }
@@ -115,6 +117,8 @@ int nerf_amd_model_create(const nerf_amd_arch *arch, int device, nerf_amd_model 
     }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->stream_f32), (size_t)p.f32_stream_floats * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->bias_f32), (size_t)p.f32_bias_floats * sizeof(float));
+    if (e == hipSuccess && p.f32_stream_t_floats > 0)
+        e = hipMalloc(reinterpret_cast<void **>(&m->stream_f32_t), (size_t)p.f32_stream_t_floats * sizeof(float));
     if (e != hipSuccess) {
         nerf_amd_model_destroy(m);
         return hip_fail(e, "hipMalloc(model buffers)");
@@ -141,7 +145,8 @@ int nerf_amd_model_update_copies(nerf_amd_model *m, const float *const *weights,
     int rc = launch_pack(p, m->d_frags, m->d_tiles, m->d_layers, m->d_tensors, wt, bt,
                          m->stream_bf16, m->bias_bf16, m->stream_f32, m->bias_f32,
                          m->d_frags16, m->d_tiles16, m->stream_s16, m->bias_s16, m->d_frags_bwd, m->stream_bwd,
-                         m->d_frags_split, m->stream_split, m->d_frags_bwd_split, m->stream_bwd_split, copies, s);
+                         m->d_frags_split, m->stream_split, m->d_frags_bwd_split, m->stream_bwd_split, m->d_tlayers, m->stream_f32_t,
+                         copies, s);
     if (rc) return fail(rc, "pack launch failed");
     m->fresh = (others_current ? m->fresh : 0) | copies;
     return NERF_AMD_OK;
@@ -159,6 +164,7 @@ void nerf_amd_model_destroy(nerf_amd_model *m) {
     (void)hipFree(m->d_frags_bwd); (void)hipFree(m->stream_bwd); (void)hipFree(m->d_frags_split); (void)hipFree(m->stream_split);
     (void)hipFree(m->d_frags16); (void)hipFree(m->d_tiles16); (void)hipFree(m->stream_s16); (void)hipFree(m->bias_s16);
     (void)hipFree(m->stream_bf16); (void)hipFree(m->bias_bf16); (void)hipFree(m->stream_f32); (void)hipFree(m->bias_f32);
+    (void)hipFree(m->d_tlayers); (void)hipFree(m->stream_f32_t);
     delete m;
 }
 
@@ -318,16 +324,24 @@ int nerf_amd_ndc_rays_backward(int32_t H, int32_t W, double focal, float near, c
 }
 
 namespace {
-const char *TRAIN_COVER = "training kernels cover D=8, W=256, skips=[4] with view branch (multires 10/4 or 15/6) or without (multires 10 or 15, output_ch <= 16), in NERF_AMD_PREC_BF16 or NERF_AMD_PREC_FP32_SPLIT";
-bool train_precision_ok(int precision) { return precision == NERF_AMD_PREC_BF16 || precision == NERF_AMD_PREC_FP32_SPLIT; }
+const char *TRAIN_COVER = "fused training kernels cover D=8, W=256, skips=[4] with view branch (multires 10/4 or 15/6) or without (multires 10 or 15, output_ch <= 16), in NERF_AMD_PREC_BF16 or NERF_AMD_PREC_FP32_SPLIT; NERF_AMD_PREC_FP32 trains any architecture (no point / ray gradients)";
+// which training path a (model, precision) pair takes: 1 fused bf16 / split kernels, 2 the exact-fp32 path, 0 none
+int train_path(const nerf_amd_model *m, int precision) {
+    if ((precision == NERF_AMD_PREC_BF16 || precision == NERF_AMD_PREC_FP32_SPLIT) && train_supported(m->prog)) return 1;
+    if (precision == NERF_AMD_PREC_FP32 && train_f32_supported(m->prog)) return 2;
+    return 0;
+}
 }  // namespace
 
 int nerf_amd_model_supports_training(const nerf_amd_model *m, int precision) {
-    return m && train_precision_ok(precision) && train_supported(m->prog) ? 1 : 0;
+    return m && train_path(m, precision) ? 1 : 0;
 }
 
 int64_t nerf_amd_train_workspace(const nerf_amd_model *m, int64_t n_points, int precision) {
-    if (!m || n_points < 0 || !train_precision_ok(precision) || !train_supported(m->prog)) return -1;
+    if (!m || n_points < 0) return -1;
+    const int path = train_path(m, precision);
+    if (path == 2) return train_f32_workspace_bytes(m->prog, n_points);
+    if (path != 1) return -1;
     return train_workspace_bytes(m->prog, n_points, precision == NERF_AMD_PREC_FP32_SPLIT);
 }
 
@@ -338,7 +352,26 @@ int nerf_amd_field_forward_train(const nerf_amd_model *m, const float *pts, cons
     const bool vd = m->prog.arch.use_viewdirs != 0;
     if (!pts && ray_ch != (vd ? 11 : 8)) return fail(NERF_AMD_EINVAL, vd ? "rays must be [R,11]" : "rays must be [R,8] for a model without view branch");
     if (pts && vd && !viewdirs) return fail(NERF_AMD_EINVAL, "pts mode needs viewdirs [R,3]");
-    if (!train_precision_ok(precision) || !train_supported(m->prog)) return fail(NERF_AMD_EUNSUPPORTED, TRAIN_COVER);
+    const int path = train_path(m, precision);
+    if (!path) return fail(NERF_AMD_EUNSUPPORTED, TRAIN_COVER);
+    if (path == 2) {                                   // exact fp32, any architecture (train_f32.hip)
+        if (int rc0 = need_copy(m, NERF_AMD_COPY_FP32)) return rc0;
+        if (R == 0) return NERF_AMD_OK;
+        const int64_t P = R * S;
+        if ((!pts && (!rays || !z_vals)) || !raw || !workspace || workspace_bytes < train_f32_workspace_bytes(m->prog, P))
+            return fail(NERF_AMD_EINVAL, "null pointer or workspace too small");
+        const Program &p = m->prog;
+        MlpArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.stream_f32 = m->stream_f32; a.bias_f32 = m->bias_f32; a.layers = m->d_layers; a.n_layers = (int)p.layers.size();
+        a.input_ch = p.input_ch; a.input_ch_views = p.input_ch_views; a.W = p.arch.W; a.lds_rows = p.lds_rows;
+        a.multires = p.arch.multires; a.multires_views = p.arch.multires_views; a.i_embed = p.arch.i_embed;
+        if (pts) { a.pts = pts; a.viewdirs = vd ? viewdirs : nullptr; a.vd_stride = 3; }
+        else { a.rays = rays; a.ray_stride = ray_ch; a.z_vals = z_vals; a.viewdirs = vd ? rays + 8 : nullptr; a.vd_stride = ray_ch; }
+        a.P = P; a.S = S; a.out = raw; a.out_ch = p.out_ch;
+        int rc = launch_train_f32_forward(p, a, m->d_tlayers, workspace, static_cast<hipStream_t>(stream));
+        return rc ? fail(rc, "exact-fp32 training forward launch failed") : NERF_AMD_OK;
+    }
     if (int rc0 = need_copy(m, precision == NERF_AMD_PREC_FP32_SPLIT ? NERF_AMD_COPY_SPLIT : NERF_AMD_COPY_BF16)) return rc0;
     if (R == 0) return NERF_AMD_OK;
     const bool split = precision == NERF_AMD_PREC_FP32_SPLIT;
@@ -368,9 +401,26 @@ int nerf_amd_field_backward(const nerf_amd_model *m, const float *g_raw, const f
     const bool vd = m->prog.arch.use_viewdirs != 0;
     if ((!pts && (ray_ch != (vd ? 11 : 8) || !rays || !z_vals)) || (pts && vd && !viewdirs))
         return fail(NERF_AMD_EINVAL, "backward needs the forward's inputs (pts + viewdirs, or rays [R,11] + z_vals; [R,8] without view branch)");
-    if (!train_precision_ok(precision) || !train_supported(m->prog)) return fail(NERF_AMD_EUNSUPPORTED, TRAIN_COVER);
+    const int path = train_path(m, precision);
+    if (!path) return fail(NERF_AMD_EUNSUPPORTED, TRAIN_COVER);
     if (n_tensors != (int)m->prog.tensors.size()) return fail(NERF_AMD_EINVAL, "wrong number of gradient tensors");
     if (n_points == 0) return NERF_AMD_OK;
+    if (path == 2) {                                   // exact fp32, any architecture (train_f32.hip)
+        if (g_pts || g_rays || g_viewdirs)
+            return fail(NERF_AMD_EUNSUPPORTED, "the exact-fp32 training path has no gradients with respect to points, rays or view directions (use NERF_AMD_PREC_FP32_SPLIT on an 8x256 model)");
+        if (int rc0 = need_copy(m, NERF_AMD_COPY_FP32_BWD)) return rc0;
+        if (!g_raw || !workspace || workspace_bytes < train_f32_workspace_bytes(m->prog, n_points))
+            return fail(NERF_AMD_EINVAL, "null pointer or workspace too small");
+        for (int i = 0; i < n_tensors; ++i)
+            if (!grad_weights[i] || !grad_biases[i]) return fail(NERF_AMD_EINVAL, "null gradient pointer");
+        const Program &p = m->prog;
+        MlpArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.layers = m->d_layers; a.n_layers = (int)p.layers.size(); a.lds_rows = p.lds_rows; a.out_ch = p.out_ch;
+        a.P = n_points; a.S = S; a.g_raw = g_raw;
+        int rc = launch_train_f32_backward(p, a, m->d_tlayers, m->stream_f32_t, workspace, grad_weights, grad_biases, static_cast<hipStream_t>(stream));
+        return rc ? fail(rc, "exact-fp32 backward launch failed") : NERF_AMD_OK;
+    }
     const bool split = precision == NERF_AMD_PREC_FP32_SPLIT;
     if (int rc0 = need_copy(m, split ? NERF_AMD_COPY_BWD_SPLIT : NERF_AMD_COPY_BWD)) return rc0;
     if (!g_raw || !workspace || workspace_bytes < train_workspace_bytes(m->prog, n_points, split))

@@ -99,7 +99,7 @@ int launch_pack(const Program &p, const FragDesc *d_frags, const TileDesc *d_til
                 uint16_t *stream_bf16, float *bias_bf16, float *stream_f32, float *bias_f32,
                 const FragDesc *d_frags16, const TileDesc *d_tiles16, uint16_t *stream_s16, float *bias_s16,
                 const FragDesc *d_frags_bwd, uint16_t *stream_bwd, const FragDesc *d_frags_split, uint16_t *stream_split,
-                const FragDesc *d_frags_bwd_split, uint16_t *stream_bwd_split, int copies, hipStream_t s);
+                const FragDesc *d_frags_bwd_split, uint16_t *stream_bwd_split, const TrainLayerF32 *d_tlayers, float *stream_f32_t, int copies, hipStream_t s);
 void pack_bf16_host(const Program &p, int shape, const float *const *w, const float *const *b, uint16_t *stream, float *bias);
 int launch_mlp_bf16_s16(const MlpArgs &a, int multires, int multires_views, int use_viewdirs,
                         int n_frags_used, int n_tiles, hipStream_t s);
@@ -109,6 +109,12 @@ int launch_mlp_bwd_s16(const MlpArgs &a, int multires, int multires_views, int u
 
 // backward.hip
 // split: the arrays of NERF_AMD_PREC_FP32_SPLIT training (hi and lo planes, loss-scale slots) instead of the bf16 ones
+// train_f32.hip: exact-fp32 training for any architecture (NERF_AMD_PREC_FP32): forward with saves, dX chain, dW / db
+bool train_f32_supported(const Program &p);
+int64_t train_f32_workspace_bytes(const Program &p, int64_t P);
+int launch_train_f32_forward(const Program &p, const MlpArgs &a, const TrainLayerF32 *d_tl, void *workspace, hipStream_t s);
+int launch_train_f32_backward(const Program &p, const MlpArgs &a, const TrainLayerF32 *d_tl, const float *stream_t, void *workspace,
+                              float *const *gw, float *const *gb, hipStream_t s);
 bool train_supported(const Program &p);
 int64_t train_workspace_bytes(const Program &p, int64_t P, bool split);
 void train_fill_args(const Program &p, int64_t P, void *workspace, MlpArgs *a, bool split);

@@ -99,10 +99,11 @@ struct PackJobs {
     const FragDesc *frags_bwd, *frags16, *frags, *frags_split, *frags_bwd_split;
     const TileDesc *tiles16, *tiles;
     const LayerF32 *layers;
+    const TrainLayerF32 *tlayers;
     const TensorDesc *tensors;
     uint16_t *stream_bwd, *stream_s16, *stream_bf16, *stream_split, *stream_bwd_split;
-    float *bias_s16, *bias_bf16, *stream_f32, *bias_f32;
-    int n_bwd, n16, n32, n_split, n_bwd_split, n_tiles16, n_tiles, n_layers;
+    float *bias_s16, *bias_bf16, *stream_f32, *bias_f32, *stream_f32_t;
+    int n_bwd, n16, n32, n_split, n_bwd_split, n_tiles16, n_tiles, n_layers, n_layers_t;
     int b_bias16, b_bias32;          // blocks of the two bias tables
 };
 constexpr int PACK_F32_BLOCKS = 32;  // per layer
@@ -153,6 +154,23 @@ __global__ __launch_bounds__(512) void pack_all_kernel(PackJobs J, PtrTable weig
     }
     b -= J.b_bias32;
     // fp32 stream: blocks of 256 values = one (tile, group) of a layer; a 512-thread block packs two at a time
+    if (b >= J.n_layers * PACK_F32_BLOCKS) {
+        // the transposed fp32 stream of train_f32.hip: tiles over the layer's INPUT features, k over its outputs
+        b -= J.n_layers * PACK_F32_BLOCKS;
+        const int layer = b / PACK_F32_BLOCKS, bx = b - layer * PACK_F32_BLOCKS;
+        if (layer >= J.n_layers_t) return;
+        const LayerF32 L = J.layers[layer];
+        const int tiles = (L.n_in + 31) >> 5, groups = (L.n_out + 7) >> 3;
+        const int half = threadIdx.x >> 8, tid = threadIdx.x & 255;
+        for (int blk = 2 * bx + half; blk < tiles * groups; blk += 2 * PACK_F32_BLOCKS) {
+            const int t = blk / groups, g = blk - t * groups;
+            const int lane = tid >> 2, i = tid & 3;
+            const int row = 32 * t + (lane & 31), col = 8 * g + 2 * i + (lane >> 5);      // row: input feature, col: output feature
+            const float v = (row < L.n_in && col < L.n_out) ? weights[L.tensor][(int64_t)col * L.n_in + row] : 0.0f;
+            J.stream_f32_t[J.tlayers[layer].frag_off_t + (int64_t)blk * 256 + tid] = v;
+        }
+        return;
+    }
     const int layer = b / PACK_F32_BLOCKS, bx = b - layer * PACK_F32_BLOCKS;
     if (layer >= J.n_layers) return;
     const LayerF32 L = J.layers[layer];
@@ -174,7 +192,8 @@ int launch_pack(const Program &p, const FragDesc *d_frags, const TileDesc *d_til
                 uint16_t *stream_bf16, float *bias_bf16, float *stream_f32, float *bias_f32,
                 const FragDesc *d_frags16, const TileDesc *d_tiles16, uint16_t *stream_s16, float *bias_s16,
                 const FragDesc *d_frags_bwd, uint16_t *stream_bwd, const FragDesc *d_frags_split, uint16_t *stream_split,
-                const FragDesc *d_frags_bwd_split, uint16_t *stream_bwd_split, int copies, hipStream_t s) {
+                const FragDesc *d_frags_bwd_split, uint16_t *stream_bwd_split, const TrainLayerF32 *d_tlayers, float *stream_f32_t,
+                int copies, hipStream_t s) {
     PackJobs J;
     J.frags_bwd_split = d_frags_bwd_split; J.stream_bwd_split = stream_bwd_split;
     J.frags_bwd = d_frags_bwd; J.frags16 = d_frags16; J.frags = d_frags; J.frags_split = d_frags_split;
@@ -192,9 +211,11 @@ int launch_pack(const Program &p, const FragDesc *d_frags, const TileDesc *d_til
     J.n_tiles16 = p.bf16_ok && (c_bf16 || c_split) ? (int)p.tiles16.size() : 0;       // the 16-row bias table serves both
     J.n_tiles = p.bf16_ok && c_bf16 ? (int)p.tiles.size() : 0;
     J.n_layers = (copies & NERF_AMD_COPY_FP32) ? (int)p.layers.size() : 0;
+    J.n_layers_t = (copies & NERF_AMD_COPY_FP32_BWD) && stream_f32_t ? (int)p.layers.size() : 0;
+    J.tlayers = d_tlayers; J.stream_f32_t = stream_f32_t;
     J.b_bias16 = (J.n_tiles16 * 16 + 511) / 512;
     J.b_bias32 = (J.n_tiles * 32 + 511) / 512;
-    const unsigned grid = (unsigned)(J.n_bwd + J.n16 + J.n32 + J.n_split + J.n_bwd_split + J.b_bias16 + J.b_bias32 + J.n_layers * PACK_F32_BLOCKS);
+    const unsigned grid = (unsigned)(J.n_bwd + J.n16 + J.n32 + J.n_split + J.n_bwd_split + J.b_bias16 + J.b_bias32 + (J.n_layers + J.n_layers_t) * PACK_F32_BLOCKS);
     if (grid == 0) return NERF_AMD_OK;
     hipLaunchKernelGGL(pack_all_kernel, dim3(grid), dim3(512), 0, s, J, d_w, d_b);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;

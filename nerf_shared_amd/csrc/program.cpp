@@ -1,6 +1,8 @@
 // program.cpp -- host-side construction of the fragment programs (see program.h).
 #include "program.h"
 
+#include <algorithm>
+
 namespace na {
 
 namespace {
@@ -72,6 +74,41 @@ int build_program(const nerf_amd_arch &a, Program &p, const char **err) {
         }
         p.f32_stream_floats = foff;
         p.f32_bias_floats = boff;
+        // ---- exact-fp32 training: workspace rows, transposed fragments, who accumulates
+        {
+            const int ic = p.input_ch;
+            int64_t toff = 0;
+            int rows = 0;
+            p.lds_rows_bwd = p.lds_rows + 32;
+            // the value a layer reads from the hidden rows is identified by the last layer that wrote them (-1: none)
+            int writer = -1;
+            std::vector<int> in_value(p.layers.size());
+            for (size_t l = 0; l < p.layers.size(); ++l) {
+                in_value[l] = writer;
+                if (p.layers[l].out_row >= 0) writer = (int)l;
+            }
+            for (size_t l = 0; l < p.layers.size(); ++l) {
+                const LayerF32 &L = p.layers[l];
+                TrainLayerF32 t;
+                t.frag_off_t = toff;
+                toff += (int64_t)((L.n_in + 31) / 32) * ((L.n_out + 7) / 8) * 256;
+                t.x_row = rows; rows += L.n_in;
+                t.g_row = rows; rows += L.n_out;
+                t.y_row = L.relu ? rows : -1;
+                if (L.relu) rows += L.n_out;
+                // hidden rows of the input: LDS rows [ic, ic + W) (what a previous layer produced), relative to in_row
+                const int a0 = std::max(L.in_row, ic), a1 = std::min(L.in_row + L.n_in, ic + W);
+                t.lo = a1 > a0 && in_value[l] >= 0 ? a0 - L.in_row : 0;
+                t.hi = a1 > a0 && in_value[l] >= 0 ? a1 - L.in_row : 0;
+                t.accumulate = 0;
+                for (size_t j = l + 1; j < p.layers.size(); ++j)     // processed before l in the backward order
+                    if (in_value[j] == in_value[l] && in_value[l] >= 0) t.accumulate = 1;
+                t.lds_g_row = L.out_row >= 0 ? L.out_row : p.lds_rows + L.out_col;
+                p.tlayers.push_back(t);
+            }
+            p.f32_stream_t_floats = toff;
+            p.train_f32_rows = rows;
+        }
     }
 
     // ---- bf16 fused program: canonical D=8, W=256, skips=[4]

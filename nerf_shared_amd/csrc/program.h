@@ -95,6 +95,18 @@ struct LayerF32 {
     int64_t bias_off;        // float offset of the bias (padded to 32*tiles)
 };
 
+// The exact-fp32 training path (train_f32.hip: any architecture the constructor accepts): what the backward needs to know
+// about layer l of the program beside its LayerF32.  Workspace arrays are [rows][pad64(P)] fp32, rows counted over the layers.
+struct TrainLayerF32 {
+    int64_t frag_off_t;      // float offset of the layer's TRANSPOSED fragments (tiles over n_in, k over n_out) in stream_f32_t
+    int32_t x_row;           // first workspace row of the saved input  X_l   [n_in][Pp]
+    int32_t g_row;           // first workspace row of dL/d(pre-activation)   [n_out][Pp]
+    int32_t y_row;           // first workspace row of the saved post-ReLU output [n_out][Pp], -1 without ReLU
+    int32_t lo, hi;          // rows [lo, hi) of the INPUT (relative to in_row) are hidden features: their gradient goes on
+    int32_t accumulate;      // 1: another consumer of the same input was processed earlier in the backward order: +=
+    int32_t lds_g_row;       // LDS row of this layer's output gradient in the backward kernel (heads: behind the forward's rows)
+};
+
 // Column of the reference embedding that slot (ks,h,j) of a FRAG_GEN segment holds, or -1.
 NA_HD constexpr inline int gen_col(int ks, int h, int j, int L) {
     int e = 8 * ks + j;
@@ -167,6 +179,11 @@ struct Program {
     std::vector<LayerF32> layers;
     int64_t f32_stream_floats = 0, f32_bias_floats = 0;
     int lds_rows = 0;                // rows of one ping-pong buffer
+    // exact-fp32 training (train_f32.hip)
+    std::vector<TrainLayerF32> tlayers;
+    int64_t f32_stream_t_floats = 0; // the transposed fragment stream
+    int train_f32_rows = 0;          // workspace rows in all
+    int lds_rows_bwd = 0;            // LDS rows of the backward kernel: lds_rows + 32 for the heads' output gradients
 };
 
 constexpr int STREAM_PAD_FRAGS = 192;   // the bf16 stream is zero-padded to a multiple of this (any block size <= 64)

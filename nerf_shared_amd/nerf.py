@@ -352,7 +352,8 @@ class NeRF(nn.Module):
                            "nerf_amd_model_create")
             self._handle, self._handle_device, self._packed_key = h, device, None
             self._finalizer = weakref.finalize(self, _destroy_handle, h)
-            self.__dict__['_trainable_kernels'] = bool(lib.nerf_amd_model_supports_training(h, _lib.PREC_BF16))
+            self.__dict__['_trainable_kernels'] = bool(lib.nerf_amd_model_supports_training(h, _lib.PREC_BF16))     # the fused 8x256 family
+            self.__dict__['_trainable_f32'] = bool(lib.nerf_amd_model_supports_training(h, _lib.PREC_FP32))       # any architecture, exact fp32
         return self._handle
 
     def _model_handle(self, device, copies=None):
@@ -410,23 +411,31 @@ class NeRF(nn.Module):
         self._ensure_handle(device)
         if self.__dict__['_trainable_kernels']:
             return "train", None
-        msg = ("backward() reached a result of the forward-only kernels: the HIP training kernels cover NeRF(D=8, W=256, skips=[4]) "
-               "with use_viewdirs=True and multires/multires_views 10/4 or 15/6, or use_viewdirs=False with multires 10 or 15 and "
-               "output_ch <= 16 (in every precision); this model is %s(D=%d, W=%d, skips=%s, use_viewdirs=%s, multires=%d, "
-               "multires_views=%d, output_ch=%d) in precision '%s'.  Gradients were requested when it was evaluated (grad mode on, a "
-               "parameter or input requiring grad), so the result was given this backward instead of none; there is no PyTorch fallback"
+        wants_input_grad = any(t is not None and t.requires_grad for t in inputs)
+        if self.__dict__['_trainable_f32'] and not wants_input_grad:
+            return "train", None           # any other architecture: the exact-fp32 training path (parameters only)
+        msg = ("backward() reached a result of the forward-only kernels: the fused HIP training kernels cover NeRF(D=8, W=256, "
+               "skips=[4]) with use_viewdirs=True and multires/multires_views 10/4 or 15/6, or use_viewdirs=False with multires 10 or "
+               "15 and output_ch <= 16 (in every precision); every other architecture trains its PARAMETERS on the exact-fp32 path, "
+               "which has no gradients with respect to points, rays or view directions.  This model is %s(D=%d, W=%d, skips=%s, "
+               "use_viewdirs=%s, multires=%d, multires_views=%d, output_ch=%d) in precision '%s'%s.  Gradients were requested when it "
+               "was evaluated (grad mode on, a parameter or input requiring grad), so the result was given this backward instead of "
+               "none; there is no PyTorch fallback"
                % (type(self).__name__, self.D, self.W, list(self.skips), self.use_viewdirs, self.multires,
-                  self.multires_views, self.output_ch, prec))
+                  self.multires_views, self.output_ch, prec, ", evaluated on inputs that require grad" if wants_input_grad else ""))
         return "defer", (anchor, msg)
 
     def _train_precision(self):
         """Arithmetic of the training kernels for this model's precision: 'bf16' trains in bf16; 'fp32_split' AND 'fp32'
         train on the split-precision kernels (fp16 operand pairs, three MFMAs per product -- forward, dX chain and weight
-        gradients; gradients agree with fp32 autograd to ~1e-6).  There is no exact-fp32 backward: an 'fp32' model's
-        training forward is the split-precision one (1e-5 from its exact inference forward on |raw| <= 20)."""
+        gradients; gradients agree with fp32 autograd to ~1e-6): an 'fp32' model of the fused family has the split-precision
+        training forward (1e-5 from its exact inference forward on |raw| <= 20).  Every other architecture trains on the
+        exact-fp32 path (csrc/train_f32.hip: fp32 MFMA rate, parameter gradients only)."""
         name = self.precision or _default_precision
         if name not in _PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(_PRECISIONS))
+        if not self.__dict__.get('_trainable_kernels', True):
+            return _lib.PREC_FP32          # not the fused family: the exact-fp32 training path, whatever the inference precision
         return _lib.PREC_BF16 if name == "bf16" else _lib.PREC_FP32_SPLIT
 
     def _wants_grad(self, device, *inputs):

@@ -864,13 +864,14 @@ def test_sample_counts_beyond_the_lds_are_refused_with_the_real_reason(dev):
         rgb.sum().backward()
 
 
-def test_gradient_requests_outside_the_training_kernels_raise(dev):
-    """main.py:103 calls loss.backward() on whatever render() returned: for a model the HIP training kernels do not cover
-    (other depths and widths, an output_linear model with a multires the kernels are not instantiated for -- in any
-    precision) a call made with gradients requested renders on the forward-only kernels -- as the reference would
-    render it, so inference written without torch.no_grad() works -- and returns results that DO carry autograd history:
-    a backward that raises NerfAmdError with the reason.  Nothing comes back silently without history, nothing trains
-    silently wrong."""
+def test_gradient_requests_outside_the_fused_training_kernels(dev):
+    """main.py:103 calls loss.backward() on whatever render() returned.  For a model the FUSED training kernels do not cover
+    (other depths and widths, an output_linear model with a multires they are not instantiated for -- in any precision) a
+    call made with gradients requested trains the PARAMETERS on the exact-fp32 path (csrc/train_f32.hip; round 4 -- it used
+    to raise): same values as plain inference, finite gradients for every parameter.  What that path does not have is a
+    gradient with respect to the rays: such a call renders on the forward-only kernels and returns results that DO carry
+    autograd history -- a backward that raises NerfAmdError with the reason.  Nothing comes back silently without history,
+    nothing trains silently wrong."""
     nerf, render_utils, utils = amd()
     from nerf_shared_amd._lib import NerfAmdError
     K = synth.lego_intrinsics(40, 40)
@@ -879,35 +880,47 @@ def test_gradient_requests_outside_the_training_kernels_raise(dev):
              ("no view branch, multires 6", dict(NOVD, multires=6), "bf16", False), ("D=4 W=128", small, "bf16", True)]
     for label, arch, prec, vd in cases:
         rr = render_utils.Renderer(**dict(BASE, N_samples=16, N_importance=16, use_viewdirs=vd))
+        torch.manual_seed(5)
         m = nerf.NeRF(**arch).to(dev)
         m.precision = prec
+        with torch.no_grad():                                          # lift the density: an empty volume has zero gradients
+            (m.alpha_linear.bias if vd else m.output_linear.bias[3:4]).add_(1.0)
         batch = utils.make_ray_batch(40, 40, K, synth.LEGO_C2W, 2.0, 6.0, vd, False, device=dev, n=64)
         assert all(p.requires_grad for p in m.parameters())
         with torch.no_grad():                                          # the reference values: plain inference
             want = rr.render_rays(batch, m, m)
         assert want["rgb_map"].shape == (64, 3) and not want["rgb_map"].requires_grad
-        pts = torch.zeros(4, 3, 3, device=dev)
+        pts = torch.rand(4, 3, 3, device=dev)
         calls = [lambda: rr.render_rays(batch, m, m)["rgb_map"],                      # grad mode on, parameters require grad
                  lambda: rr.render_batch(m, m, batch, chunk=32)["rgb_map"],
                  lambda: rr.render(40, 40, K, m, m, chunk=48, c2w=torch.from_numpy(synth.LEGO_C2W), retraw=False)[0],
                  lambda: m(pts, torch.ones(4, 3, device=dev) if vd else None)]
         for i, call in enumerate(calls):
+            m.zero_grad(set_to_none=True)
             out = call()
             assert out.requires_grad and out.grad_fn is not None, (label, i)          # history, not a bare tensor
             if i < 2:
-                assert torch.equal(out.detach(), want["rgb_map"]), (label, i)         # the same kernels, the same values
-            out.clamp_(0.0, 1.0)                                                      # results are no views: in-place ops work
-            with pytest.raises(NerfAmdError, match="backward\\(\\) reached a result of the forward-only kernels"):
-                out.sum().backward()
-            assert all(p.grad is None for p in m.parameters())
+                close(out.detach(), want["rgb_map"], atol=2e-6)                       # exact fp32 on both sides (these models render on the exact kernel)
+            out.sum().backward()
+            used = [p for n, p in m.named_parameters() if not (not vd and n.startswith("views_linears"))]
+            assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in used), (label, i)
+            assert float(m.pts_linears[0].weight.grad.abs().sum()) > 0, (label, i)
         m.requires_grad_(False)
         out = rr.render_rays(batch, m, m)                              # nothing requires grad: no history, no trap
         assert not out["rgb_map"].requires_grad
-        rays = batch.clone().requires_grad_(True)                      # ... unless the rays do (pose estimation)
+        rays = batch.clone().requires_grad_(True)                      # ... unless the rays do (pose estimation): not on this path
         out = rr.render_rays(rays, m, m)["rgb_map"]
         assert out.requires_grad
-        with pytest.raises(NerfAmdError, match="forward-only kernels"):
+        assert torch.equal(out.detach(), want["rgb_map"])              # the forward-only kernels, the same values
+        out.clamp_(0.0, 1.0)                                           # results are no views: in-place ops work
+        with pytest.raises(NerfAmdError, match="backward\\(\\) reached a result of the forward-only kernels"):
             out.sum().backward()
+        m.requires_grad_(True)                                         # rays AND parameters: the same refusal, nothing half-trained
+        m.zero_grad(set_to_none=True)
+        out = rr.render_rays(rays, m, m)["rgb_map"]
+        with pytest.raises(NerfAmdError, match="no gradients with respect to points, rays or view directions"):
+            out.sum().backward()
+        assert all(p.grad is None for p in m.parameters())
     r = render_utils.Renderer(**dict(BASE, N_samples=16, N_importance=16))
     assert r is not None
     # the covered models keep their history in every precision (bf16 kernels, or the split-precision ones for 'fp32_split'
