@@ -13,8 +13,8 @@
 //                                   go to the workspace as [rows][pad64(P)] fp32
 //   dX chain  f32_bwd_kernel        layers in reverse: g_pre(l) = relu'(y_l) g_out(l) -> workspace; g_in = W_l^T g_pre(l) on
 //                                   the transposed fragment stream; written over (or added to) the hidden rows of the input
-//   dW, db    f32_dw_kernel         dW_l = g_pre(l) X_l^T, 64 x 64 output blocks, the point axis split over workgroups,
-//             f32_dw_reduce_kernel  partial blocks summed in a fixed order (deterministic), db_l = row sums of g_pre(l)
+//   dW, db    f32_dw_kernel         [dW_l | db_l] = g_pre(l) [X_l ; 1]^T, 64 x 64 output blocks, the point axis split over workgroups,
+//             f32_dw_reduce_kernel  partial blocks summed in a fixed order (deterministic)
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
@@ -234,8 +234,9 @@ __global__ __launch_bounds__(512) void f32_bwd_kernel(TrainF32Args t) {
 // ------------------------------------------------------------------------------------------------------------------
 // dW_l = g_pre(l) X_l^T over the points; db_l = row sums of g_pre(l)
 // ------------------------------------------------------------------------------------------------------------------
-// One workgroup (4 waves, a 2 x 2 arrangement of 32 x 32 MFMA tiles): the 64 x 64 block (bo, bi) of dW over the points
-// [slice * chunk_pts, ...).  Rows of G (n_out) and X (n_in) past the layer's sizes read as zero.
+// One workgroup (4 waves, a 2 x 2 arrangement of 32 x 32 MFMA tiles): the 64 x 64 block (bo, bi) of [dW | db] over the points
+// [slice * chunk_pts, ...).  X has one more row than the layer has inputs, all ones: column n_in of the product is db (the
+// padding points' g_pre is zero).  Rows of G (n_out) and X past that read as zero.
 constexpr int DWF_KP = 32;           // points per staged chunk
 __global__ __launch_bounds__(256) void f32_dw_kernel(const float *G, const float *X, int n_out, int n_in, int64_t Pp, int64_t pts_per_slice,
                                                      int blocks_i, float *slab) {
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(256) void f32_dw_kernel(const float *G, const float
             const int r = i / DWF_KP, q = i % DWF_KP;
             const int ro = 64 * bo + r, rx = 64 * bi + r;
             sg[r][q] = (ro < n_out && p + q < pb) ? G[(int64_t)ro * Pp + p + q] : 0.0f;
-            sx[r][q] = (rx < n_in && p + q < pb) ? X[(int64_t)rx * Pp + p + q] : 0.0f;
+            sx[r][q] = p + q < pb ? (rx < n_in ? X[(int64_t)rx * Pp + p + q] : rx == n_in ? 1.0f : 0.0f) : 0.0f;     // row n_in: ones -> the bias gradient
         }
         __syncthreads();
 #pragma unroll
@@ -269,30 +270,16 @@ __global__ __launch_bounds__(256) void f32_dw_kernel(const float *G, const float
 }
 
 __global__ __launch_bounds__(256) void f32_dw_reduce_kernel(const float *slab, int n_slices, int n_blocks, int blocks_i, int n_out, int n_in,
-                                                            float *dW) {
+                                                            float *dW, float *db) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;        // element of the [n_blocks][64][64] result
     if (e >= (int64_t)n_blocks * 4096) return;
     const int b = (int)(e / 4096), r = (int)(e % 4096) / 64, c = (int)(e % 64);
     const int o = 64 * (b / blocks_i) + r, i = 64 * (b % blocks_i) + c;
-    if (o >= n_out || i >= n_in) return;
+    if (o >= n_out || i > n_in) return;
     float s = 0.0f;
-    for (int k = 0; k < n_slices; ++k) s += slab[((int64_t)k * n_blocks + b) * 4096 + r * 64 + c];
-    dW[(int64_t)o * n_in + i] = s;
-}
-
-// db[o] = sum_p G[o][p]: one block per row, fixed summation tree
-__global__ __launch_bounds__(256) void f32_db_kernel(const float *G, int64_t Pp, float *db) {
-    __shared__ float part[256];
-    const float *row = G + (int64_t)blockIdx.x * Pp;
-    float s = 0.0f;
-    for (int64_t p = threadIdx.x; p < Pp; p += 256) s += row[p];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) db[blockIdx.x] = part[0];
+    for (int k = 0; k < n_slices; ++k) s += slab[((int64_t)k * n_blocks + b) * 4096 + r * 64 + c];      // fixed order: deterministic
+    if (i < n_in) dW[(int64_t)o * n_in + i] = s;
+    else db[o] = s;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -317,11 +304,11 @@ bool pick_shape(const Program &p, Shape *s) {
     return s->tpw_f <= TF32_MAX_TPW && s->tpw_b <= TF32_MAX_TPW;
 }
 
-constexpr int64_t DW_SLICE_PTS = 4096;                     // points per weight-gradient workgroup
+constexpr int64_t DW_SLICE_PTS = 1024;                     // points per weight-gradient workgroup
 int64_t slab_floats(const Program &p, int64_t Pp) {
     const int64_t slices = (Pp + DW_SLICE_PTS - 1) / DW_SLICE_PTS;
     int64_t worst = 0;
-    for (const LayerF32 &L : p.layers) worst = std::max<int64_t>(worst, (int64_t)((L.n_out + 63) / 64) * ((L.n_in + 63) / 64));
+    for (const LayerF32 &L : p.layers) worst = std::max<int64_t>(worst, (int64_t)((L.n_out + 63) / 64) * ((L.n_in + 1 + 63) / 64));
     return slices * worst * 4096;
 }
 
@@ -392,11 +379,10 @@ int launch_train_f32_backward(const Program &p, const MlpArgs &a, const TrainLay
         const LayerF32 &L = p.layers[l];
         const TrainLayerF32 &T = p.tlayers[l];
         const float *G = t.ws + (int64_t)T.g_row * t.Pp, *X = t.ws + (int64_t)T.x_row * t.Pp;
-        const int blocks_o = (L.n_out + 63) / 64, blocks_i = (L.n_in + 63) / 64, nb = blocks_o * blocks_i;
+        const int blocks_o = (L.n_out + 63) / 64, blocks_i = (L.n_in + 1 + 63) / 64, nb = blocks_o * blocks_i;      // + 1: the ones row
         hipLaunchKernelGGL(f32_dw_kernel, dim3((unsigned)nb, (unsigned)slices), dim3(256), 0, s, G, X, L.n_out, L.n_in, t.Pp, DW_SLICE_PTS, blocks_i, slab);
         hipLaunchKernelGGL(f32_dw_reduce_kernel, dim3((unsigned)(((int64_t)nb * 4096 + 255) / 256)), dim3(256), 0, s, slab, (int)slices, nb, blocks_i,
-                           L.n_out, L.n_in, gw[L.tensor]);
-        hipLaunchKernelGGL(f32_db_kernel, dim3((unsigned)L.n_out), dim3(256), 0, s, G, t.Pp, gb[L.tensor]);
+                           L.n_out, L.n_in, gw[L.tensor], gb[L.tensor]);
     }
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }

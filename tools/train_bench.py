@@ -30,6 +30,9 @@ def main():
     ap.add_argument("--tuning", type=int, default=0, help="nerf_amd_set_tuning(0, value): 50 = round-1 weight-gradient kernel")
     ap.add_argument("--precision", choices=["bf16", "fp32_split", "fp32"], default="bf16",
                     help="arithmetic of the field and of its backward pass (fp32 trains on the split-precision kernels)")
+    ap.add_argument("--netdepth", type=int, default=8, help="anything but 8 x 256 with skip 4 trains on the exact-fp32 path (csrc/train_f32.hip)")
+    ap.add_argument("--netwidth", type=int, default=256)
+    ap.add_argument("--skip", type=int, default=4)
     ap.add_argument("--multires", type=int, default=10)
     ap.add_argument("--multires-views", type=int, default=4, help="15 / 6: configs/stonehenge.txt:18-19")
     ap.add_argument("--graph", action="store_true", help="utils.CapturedTrainStep: the step captured in a HIP graph and replayed")
@@ -38,11 +41,11 @@ def main():
     from nerf_shared_amd import _lib
     _lib.check(_lib.lib.nerf_amd_set_tuning(0, args.tuning), "set_tuning")
     dev = torch.device("cuda:0")
-    ARCH.update(multires=args.multires, multires_views=args.multires_views)
+    ARCH.update(multires=args.multires, multires_views=args.multires_views, D=args.netdepth, W=args.netwidth, skips=[args.skip])
     models = []
     for seed in (0, 10):
         m = nerf.NeRF(**ARCH)
-        m.load_state_dict(synth.torch_state_dict(seed, 1.0, **{**ARCH, "skips": (4,)}))
+        m.load_state_dict(synth.torch_state_dict(seed, 1.0, **{**ARCH, "skips": tuple(ARCH["skips"])}))
         m.precision = args.precision
         models.append(m.to(dev))
     r = render_utils.Renderer(perturb=1.0, N_importance=128, N_samples=64, use_viewdirs=True, white_bkgd=True,
