@@ -208,7 +208,7 @@ def test_render_rays_argument_batch_assembly(dev, use_viewdirs, ndc):
     assert torch.equal(fused, ref)
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp32_split"])
+@pytest.mark.parametrize("precision", ["bf16", "fp32_split", "fp32_small_architecture"])
 def test_captured_train_step_equals_the_eager_loop(dev, precision):
     """utils.CapturedTrainStep: the body of main.py:77-104 captured in a HIP graph and replayed -- with a new batch and the
     loop's learning-rate decay (main.py:108-112) between replays -- follows the same loop run eagerly: the same losses, the
@@ -216,6 +216,8 @@ def test_captured_train_step_equals_the_eager_loop(dev, precision):
     draws), and gradients are left in .grad after every call."""
     from nerf_shared_amd import nerf, optim, render_utils, synth, utils
     arch = dict(D=8, W=256, output_ch=5, skips=[4], use_viewdirs=True, multires=10, multires_views=4)
+    if precision == "fp32_small_architecture":             # netdepth 4, netwidth 128: the exact-fp32 training path (train_f32.hip)
+        arch, precision = dict(arch, D=4, W=128, skips=[2]), "fp32"
     cfg = dict(perturb=0.0, N_importance=32, N_samples=32, use_viewdirs=True, white_bkgd=True, raw_noise_std=0.0, near=2.0, far=6.0)
     K = synth.lego_intrinsics(400, 400)
     rng = np.random.default_rng(5)
@@ -230,7 +232,7 @@ def test_captured_train_step_equals_the_eager_loop(dev, precision):
         ms = []
         for seed in (0, 10):
             m = nerf.NeRF(**arch)
-            m.load_state_dict(synth.torch_state_dict(seed, 1.0, **{**arch, "skips": (4,)}))
+            m.load_state_dict(synth.torch_state_dict(seed, 1.0, **{**arch, "skips": tuple(arch["skips"])}))
             m.precision = precision
             ms.append(m.to(dev))
         return ms, optim.Adam(list(ms[0].parameters()) + list(ms[1].parameters()), lr=5e-4, betas=(0.9, 0.999))
