@@ -324,7 +324,7 @@ int nerf_amd_ndc_rays_backward(int32_t H, int32_t W, double focal, float near, c
 }
 
 namespace {
-const char *TRAIN_COVER = "fused training kernels cover D=8, W=256, skips=[4] with view branch (multires 10/4 or 15/6) or without (multires 10 or 15, output_ch <= 16), in NERF_AMD_PREC_BF16 or NERF_AMD_PREC_FP32_SPLIT; NERF_AMD_PREC_FP32 trains any architecture (no point / ray gradients)";
+const char *TRAIN_COVER = "fused training kernels cover D=8, W=256, skips=[4] with view branch (multires 10/4 or 15/6) or without (multires 10 or 15, output_ch <= 16), in NERF_AMD_PREC_BF16 or NERF_AMD_PREC_FP32_SPLIT; NERF_AMD_PREC_FP32 trains any architecture";
 // which training path a (model, precision) pair takes: 1 fused bf16 / split kernels, 2 the exact-fp32 path, 0 none
 int train_path(const nerf_amd_model *m, int precision) {
     if ((precision == NERF_AMD_PREC_BF16 || precision == NERF_AMD_PREC_FP32_SPLIT) && train_supported(m->prog)) return 1;
@@ -406,8 +406,6 @@ int nerf_amd_field_backward(const nerf_amd_model *m, const float *g_raw, const f
     if (n_tensors != (int)m->prog.tensors.size()) return fail(NERF_AMD_EINVAL, "wrong number of gradient tensors");
     if (n_points == 0) return NERF_AMD_OK;
     if (path == 2) {                                   // exact fp32, any architecture (train_f32.hip)
-        if (g_pts || g_rays || g_viewdirs)
-            return fail(NERF_AMD_EUNSUPPORTED, "the exact-fp32 training path has no gradients with respect to points, rays or view directions (use NERF_AMD_PREC_FP32_SPLIT on an 8x256 model)");
         if (int rc0 = need_copy(m, NERF_AMD_COPY_FP32_BWD)) return rc0;
         if (!g_raw || !workspace || workspace_bytes < train_f32_workspace_bytes(m->prog, n_points))
             return fail(NERF_AMD_EINVAL, "null pointer or workspace too small");
@@ -417,6 +415,11 @@ int nerf_amd_field_backward(const nerf_amd_model *m, const float *g_raw, const f
         MlpArgs a;
         std::memset(&a, 0, sizeof(a));
         a.layers = m->d_layers; a.n_layers = (int)p.layers.size(); a.lds_rows = p.lds_rows; a.out_ch = p.out_ch;
+        a.input_ch = p.input_ch; a.input_ch_views = p.input_ch_views; a.W = p.arch.W;
+        a.multires = p.arch.multires; a.multires_views = p.arch.multires_views; a.i_embed = p.arch.i_embed;
+        if (pts) { a.pts = pts; a.viewdirs = vd ? viewdirs : nullptr; a.vd_stride = 3; }
+        else { a.rays = rays; a.ray_stride = ray_ch; a.z_vals = z_vals; a.viewdirs = vd ? rays + 8 : nullptr; a.vd_stride = ray_ch; }
+        a.g_pts = g_pts; a.g_rays = g_rays; a.g_vd = vd ? g_viewdirs : nullptr;
         a.P = n_points; a.S = S; a.g_raw = g_raw;
         int rc = launch_train_f32_backward(p, a, m->d_tlayers, m->stream_f32_t, workspace, grad_weights, grad_biases, static_cast<hipStream_t>(stream));
         return rc ? fail(rc, "exact-fp32 backward launch failed") : NERF_AMD_OK;

@@ -6,8 +6,8 @@
 // the exact-fp32 kernel and raised from backward().  This is that kernel's structure carried through the backward pass
 // (nerf.py:110-134 under torch.autograd): v_mfma_f32_32x32x2_f32 everywhere, activations / gradients as LDS rows of 64 (or 32)
 // points, weights as fp32 fragments straight from L2 -- fp32 MFMA rate, i.e. 1/16 of the bf16 kernels: the any-architecture
-// fallback, not a tuned path.  No gradients with respect to points, rays or view directions here (nerf_amd_field_backward
-// refuses them for this precision).
+// fallback, not a tuned path.  Gradients with respect to points, rays and view directions (pose estimation) on request: the
+// chain then also carries the rows of the two encodings, and their derivative is taken at the end of the kernel.
 //
 //   forward   f32_fwd_save_kernel   mlp_fp32.hip's layer loop; every layer's input rows X_l and, for ReLU layers, output rows
 //                                   go to the workspace as [rows][pad64(P)] fp32
@@ -46,6 +46,7 @@ struct TrainF32Args {
     float *ws;                       // workspace [train_f32_rows][Pp]
     int64_t Pp;                      // pad64(P)
     int32_t lds_rows_bwd;
+    int32_t want_enc;                // backward: dL/d(encoding rows) too (someone asked for point / ray / view-direction gradients)
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -184,9 +185,14 @@ __global__ __launch_bounds__(512) void f32_bwd_kernel(TrainF32Args t) {
             t.ws[(int64_t)(T.g_row + r) * t.Pp + p0 + q] = v;
         }
         __syncthreads();
-        if (T.hi <= T.lo) continue;                            // nothing upstream of this layer's input is trainable
-        // ---- g_in = W^T g_pre for the 32-row tiles of the input that touch its hidden rows [lo, hi)
-        const int t_first = T.lo >> 5, t_last = (T.hi - 1) >> 5;
+        // rows of the input whose gradient goes on: its hidden rows [lo, hi) (what an earlier layer produced) and, when point /
+        // ray gradients are wanted, its encoding rows (LDS rows below input_ch or from input_ch + W on: always accumulated,
+        // two layers read the xyz encoding)
+        const int enc_lo = t.want_enc ? 0 : T.lo, enc_hi = t.want_enc ? L.n_in : T.hi;
+        const int r_lo = T.hi > T.lo ? (T.lo < enc_lo ? T.lo : enc_lo) : enc_lo, r_hi = T.hi > T.lo ? (T.hi > enc_hi ? T.hi : enc_hi) : enc_hi;
+        if (r_hi <= r_lo) continue;                            // nothing upstream of this layer's input wants a gradient
+        // ---- g_in = W^T g_pre for the 32-row tiles of the input that touch those rows
+        const int t_first = r_lo >> 5, t_last = (r_hi - 1) >> 5;
         const int groups = (L.n_out + 7) >> 3, groups_all = groups;
         const float *in = G + T.lds_g_row * PTS + pt;
         f32x16t acc[TPW][HALVES];
@@ -221,13 +227,46 @@ __global__ __launch_bounds__(512) void f32_bwd_kernel(TrainF32Args t) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int ri = 32 * tt + acc_row(r, h);            // row of the input
-                        if (ri < T.lo || ri >= T.hi) continue;
+                        if (ri >= L.n_in) continue;
+                        const bool hidden = ri >= T.lo && ri < T.hi;
+                        if (!hidden && !t.want_enc) continue;
                         float *dst = G + (L.in_row + ri) * PTS + 32 * c + pt;
-                        *dst = T.accumulate ? *dst + acc[u][c][r] : acc[u][c][r];
+                        *dst = (hidden && !T.accumulate) ? acc[u][c][r] : *dst + acc[u][c][r];
                     }
             }
         }
         __syncthreads();
+    }
+    if (!t.want_enc) return;
+    // ---- through the two encodings (nerf.py:32-41): d sin(2^f x) = 2^f cos, d cos = -2^f sin, identity columns 1; one thread
+    // per (point, coordinate, encoding); LDS rows [0, input_ch) hold dL/d(xyz encoding), [input_ch + W, ...) the directions'
+    for (int i = tid; i < 2 * 3 * PTS; i += 512) {
+        const int which = i / (3 * PTS), c = (i / PTS) % 3, q = i % PTS;
+        if (which == 1 && !a.viewdirs) continue;
+        const int64_t p = p0 + q;
+        if (p >= a.P) continue;
+        const int64_t ray = (int64_t)((uint32_t)p / (uint32_t)a.S);
+        float x, z = 0.0f;
+        if (which == 0) {
+            if (a.pts) x = a.pts[3 * p + c];
+            else { const float *r = a.rays + ray * a.ray_stride; z = a.z_vals[p]; x = mul_then_add(r[3 + c], z, r[c]); }
+        } else {
+            x = a.viewdirs[ray * a.vd_stride + c];
+        }
+        const int row0 = which == 0 ? 0 : a.input_ch + a.W;
+        const int Lf = a.i_embed == -1 ? 0 : (which == 0 ? a.multires : a.multires_views);
+        float g = G[(row0 + c) * PTS + q];                     // the raw coordinate's column
+        for (int f = 0; f < Lf; ++f) {
+            const float sc = __builtin_ldexpf(1.0f, f), arg = x * sc;
+            g += G[(row0 + 3 + 6 * f + c) * PTS + q] * (sc * cosf(arg));
+            g -= G[(row0 + 3 + 6 * f + 3 + c) * PTS + q] * (sc * sinf(arg));
+        }
+        if (which == 0) {
+            if (a.g_pts) a.g_pts[3 * p + c] = g;
+            if (a.g_rays) { atomicAdd(a.g_rays + ray * 6 + c, g); atomicAdd(a.g_rays + ray * 6 + 3 + c, g * z); }
+        } else if (a.g_vd) {
+            atomicAdd(a.g_vd + ray * 3 + c, g);
+        }
     }
 }
 
@@ -296,8 +335,7 @@ bool pick_shape(const Program &p, Shape *s) {
     int widest = 0, widest_b = 0;
     for (size_t l = 0; l < p.layers.size(); ++l) {
         widest = std::max(widest, (p.layers[l].n_out + 31) / 32);
-        const TrainLayerF32 &t = p.tlayers[l];
-        if (t.hi > t.lo) widest_b = std::max(widest_b, ((t.hi - 1) >> 5) - (t.lo >> 5) + 1);
+        widest_b = std::max(widest_b, (p.layers[l].n_in + 31) / 32);      // with encoding gradients the whole input is written
     }
     s->tpw_f = (widest + 7) / 8;
     s->tpw_b = std::max(1, (widest_b + 7) / 8);
@@ -342,6 +380,7 @@ int launch_train_f32_forward(const Program &p, const MlpArgs &a, const TrainLaye
     if (a.P >= (int64_t)1 << 31) return NERF_AMD_EINVAL;
     TrainF32Args t;
     t.a = a; t.tl = d_tl; t.stream_t = nullptr; t.ws = static_cast<float *>(workspace); t.Pp = pad64(a.P); t.lds_rows_bwd = p.lds_rows_bwd;
+    t.want_enc = 0;
     const int pts = 32 * sh.halves;
     const size_t lds = (size_t)p.lds_rows * pts * sizeof(float);
     const int64_t blocks = t.Pp / pts;
@@ -361,6 +400,7 @@ int launch_train_f32_backward(const Program &p, const MlpArgs &a, const TrainLay
     if (a.P <= 0) return NERF_AMD_OK;
     TrainF32Args t;
     t.a = a; t.tl = d_tl; t.stream_t = stream_t; t.ws = static_cast<float *>(workspace); t.Pp = pad64(a.P); t.lds_rows_bwd = p.lds_rows_bwd;
+    t.want_enc = (a.g_pts || a.g_rays || a.g_vd) ? 1 : 0;
     const int pts = 32 * sh.halves;
     const size_t lds = (size_t)p.lds_rows_bwd * pts * sizeof(float);
     const int64_t blocks = t.Pp / pts;

@@ -411,18 +411,15 @@ class NeRF(nn.Module):
         self._ensure_handle(device)
         if self.__dict__['_trainable_kernels']:
             return "train", None
-        wants_input_grad = any(t is not None and t.requires_grad for t in inputs)
-        if self.__dict__['_trainable_f32'] and not wants_input_grad:
-            return "train", None           # any other architecture: the exact-fp32 training path (parameters only)
-        msg = ("backward() reached a result of the forward-only kernels: the fused HIP training kernels cover NeRF(D=8, W=256, "
-               "skips=[4]) with use_viewdirs=True and multires/multires_views 10/4 or 15/6, or use_viewdirs=False with multires 10 or "
-               "15 and output_ch <= 16 (in every precision); every other architecture trains its PARAMETERS on the exact-fp32 path, "
-               "which has no gradients with respect to points, rays or view directions.  This model is %s(D=%d, W=%d, skips=%s, "
-               "use_viewdirs=%s, multires=%d, multires_views=%d, output_ch=%d) in precision '%s'%s.  Gradients were requested when it "
-               "was evaluated (grad mode on, a parameter or input requiring grad), so the result was given this backward instead of "
-               "none; there is no PyTorch fallback"
+        if self.__dict__['_trainable_f32']:
+            return "train", None           # any other architecture: the exact-fp32 training path (csrc/train_f32.hip)
+        msg = ("backward() reached a result of the forward-only kernels: this model is %s(D=%d, W=%d, skips=%s, use_viewdirs=%s, "
+               "multires=%d, multires_views=%d, output_ch=%d) in precision '%s', and neither the fused training kernels (NeRF(D=8, "
+               "W=256, skips=[4]), multires 10/4, 15/6, or 10 / 15 without view branch) nor the exact-fp32 training path (its "
+               "feature rows must fit the CU's LDS) cover it.  Gradients were requested when it was evaluated (grad mode on, a "
+               "parameter or input requiring grad), so the result was given this backward instead of none; there is no PyTorch fallback"
                % (type(self).__name__, self.D, self.W, list(self.skips), self.use_viewdirs, self.multires,
-                  self.multires_views, self.output_ch, prec, ", evaluated on inputs that require grad" if wants_input_grad else ""))
+                  self.multires_views, self.output_ch, prec))
         return "defer", (anchor, msg)
 
     def _train_precision(self):
@@ -430,7 +427,7 @@ class NeRF(nn.Module):
         train on the split-precision kernels (fp16 operand pairs, three MFMAs per product -- forward, dX chain and weight
         gradients; gradients agree with fp32 autograd to ~1e-6): an 'fp32' model of the fused family has the split-precision
         training forward (1e-5 from its exact inference forward on |raw| <= 20).  Every other architecture trains on the
-        exact-fp32 path (csrc/train_f32.hip: fp32 MFMA rate, parameter gradients only)."""
+        exact-fp32 path (csrc/train_f32.hip: fp32 MFMA rate)."""
         name = self.precision or _default_precision
         if name not in _PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(_PRECISIONS))

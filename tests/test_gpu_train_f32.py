@@ -128,15 +128,56 @@ def test_training_step_and_adam_on_a_small_architecture(dev):
     np.testing.assert_allclose(losses, ref, rtol=2e-3)
 
 
-def test_ray_gradients_are_refused_loudly(dev):
-    """The exact-fp32 path has no gradients with respect to rays: a backward that reaches them raises and says why."""
+@pytest.mark.parametrize("name", ["d4_w128_skip2", "d6_w96_skips13", "d8_w256_identity_embed", "d2_w64_noskip_novd"])
+def test_point_and_ray_gradients_of_any_architecture(dev, name):
+    """Pose estimation on a model outside the fused family (demo_est_rel_pose.py:87-98): dL/d(points, view directions) of the
+    field, and dL/d(rays_o, rays_d) through Renderer.render_rays with frozen networks, against fp32 autograd on the oracle
+    (fine pass on the run's own depths)."""
     from nerf_shared_amd import render_utils
-    arch = ARCHS["d4_w128_skip2"]
-    batch, target = _batch(16, 5)
-    r = render_utils.Renderer(**dict(BASE, N_samples=8, N_importance=8))
-    mc, _ = build(dev, 1, 1.0, arch)
-    mf, _ = build(dev, 2, 1.0, arch)
-    b = batch.to(dev).requires_grad_(True)
-    out = r.render_rays(b, mc, mf)
-    with pytest.raises(Exception, match="no gradients with respect to points, rays or view directions"):
-        out["rgb_map"].sum().backward()
+    from test_gpu_split_backward import oracle_two_pass
+    arch = ARCHS[name]
+    vdirs = arch["use_viewdirs"]
+    rng = np.random.default_rng(21)
+    pts = torch.from_numpy(rng.uniform(-2, 2, size=(40, 9, 3)).astype(np.float32))
+    vd = torch.from_numpy(rng.normal(size=(40, 3)).astype(np.float32)) if vdirs else None
+    out_ch = 4 if vdirs else arch["output_ch"]
+    coef = torch.from_numpy(rng.normal(size=(40, 9, out_ch)).astype(np.float32))
+    m, cpu = build(dev, 1, 2.0, arch)
+    m.requires_grad_(False)
+    frozen = {k: v.detach() for k, v in cpu.items()}
+    p_gpu = pts.to(dev).requires_grad_(True)
+    v_gpu = vd.to(dev).requires_grad_(True) if vdirs else None
+    (m(p_gpu, v_gpu) * coef.to(dev)).sum().backward()
+    p_cpu = pts.clone().requires_grad_(True)
+    v_cpu = vd.clone().requires_grad_(True) if vdirs else None
+    (O.nerf_forward(frozen, O.Arch(**arch), p_cpu, v_cpu) * coef).sum().backward()
+    e = rel_err(p_gpu.grad.cpu(), p_cpu.grad)
+    print(name, "dL/dpts rel-L2 %.2e" % e, ("dL/dviewdirs %.2e" % rel_err(v_gpu.grad.cpu(), v_cpu.grad)) if vdirs else "")
+    assert e < 2e-5 and (not vdirs or rel_err(v_gpu.grad.cpu(), v_cpu.grad) < 2e-5)
+    # rays through the renderer, both passes, parameters AND rays at once for the fine model
+    batch, target = _batch(48, 7)
+    if not vdirs:
+        batch = batch[:, :8].contiguous()
+    cfg = dict(BASE, N_samples=16, N_importance=24, use_viewdirs=vdirs)
+    r = render_utils.Renderer(**cfg)
+    mf, cf = build(dev, 11, 2.0, arch)
+
+    def assemble(o, d):
+        cols = [o, d, 2.0 * torch.ones_like(d[:, :1]), 6.0 * torch.ones_like(d[:, :1])]
+        if vdirs:
+            cols.append(d / torch.norm(d, dim=-1, keepdim=True))
+        return torch.cat(cols, -1)
+
+    ro = batch[:, 0:3].clone().to(dev).requires_grad_(True)
+    rd = (batch[:, 3:6] * 1.3).clone().to(dev).requires_grad_(True)
+    out = r.render_rays(assemble(ro, rd), m, mf, retweights=True)
+    t = target.to(dev)
+    (((out["rgb_map"] - t) ** 2).mean() + ((out["rgb0"] - t) ** 2).mean()).backward()
+    o = batch[:, 0:3].clone().requires_grad_(True)
+    d = (batch[:, 3:6] * 1.3).clone().requires_grad_(True)
+    rgb, rgb0 = oracle_two_pass(cfg, assemble(o, d), (frozen, O.Arch(**arch)), (cf, O.Arch(**arch)), out["z_vals"].detach().cpu())
+    (((rgb - target) ** 2).mean() + ((rgb0 - target) ** 2).mean()).backward()
+    eo, ed = rel_err(ro.grad.cpu(), o.grad), rel_err(rd.grad.cpu(), d.grad)
+    print(name, "dL/drays_o %.2e  dL/drays_d %.2e  fine parameters %.2e" % (eo, ed, check(mf, cf, 1e-3)))
+    assert eo < 1e-4 and ed < 1e-4
+    assert all(p.grad is None for p in m.parameters())
