@@ -21,6 +21,9 @@ ARCHS = {
     "d6_w96_skips13": dict(D=6, W=96, output_ch=4, skips=[1, 3], use_viewdirs=True, multires=8, multires_views=2),
     "d3_w320_skip0": dict(D=3, W=320, output_ch=3, skips=[0], use_viewdirs=False, multires=4, multires_views=4),
     "d8_w256_identity_embed": dict(D=8, W=256, output_ch=4, skips=[4], use_viewdirs=True, multires=10, multires_views=4, i_embed=-1),
+    # wide models: 32 points per workgroup (the rows of 64 would not fit LDS), several 32-row tiles per wave
+    "d2_w600_wide": dict(D=2, W=600, output_ch=4, skips=[], use_viewdirs=True, multires=10, multires_views=4),
+    "d2_w1024_widest": dict(D=2, W=1024, output_ch=4, skips=[0], use_viewdirs=True, multires=10, multires_views=4),
 }
 
 
