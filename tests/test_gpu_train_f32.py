@@ -184,3 +184,55 @@ def test_point_and_ray_gradients_of_any_architecture(dev, name):
     print(name, "dL/drays_o %.2e  dL/drays_d %.2e  fine parameters %.2e" % (eo, ed, check(mf, cf, 1e-3)))
     assert eo < 1e-4 and ed < 1e-4
     assert all(p.grad is None for p in m.parameters())
+
+
+@pytest.mark.parametrize("i", range(24))
+def test_random_architectures_train_on_the_exact_path(dev, i):
+    """The random networks of tests/test_gpu_fuzz.py::test_random_architectures_on_the_exact_kernel (depth 1..9, widths 2..777,
+    skips anywhere, identity embedding) under loss.backward(): parameter gradients -- and, every second case, the gradients with
+    respect to the points and view directions -- of a random linear functional of NeRF.forward against fp32 autograd on the
+    oracle (csrc/train_f32.hip: any architecture the constructor accepts)."""
+    import test_gpu_fuzz as F
+    import test_gpu_parity as P
+    arch = F.draw_arch(i)
+    rng = F._rng(17000, i)
+    shape = [(1, 1), (3, 5), (41, 7), (200, 13)][i % 4]
+    pts = torch.from_numpy(rng.uniform(-2, 2, size=shape + (3,)).astype(np.float32))
+    vd = None
+    if arch["use_viewdirs"]:
+        vd = torch.nn.functional.normalize(torch.from_numpy(rng.normal(size=(shape[0], 3)).astype(np.float32)), dim=-1)
+    sharpen = 2.0 if arch["W"] >= 31 else 1.0
+    sd, oarch = P.cpu_model(i, sharpen, **arch)
+    cpu = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    with_inputs = i % 2 == 1
+    p_cpu = pts.clone().requires_grad_(with_inputs)
+    v_cpu = vd.clone().requires_grad_(with_inputs) if vd is not None else None
+    ref = P.O.nerf_forward(cpu, oarch, p_cpu, v_cpu)
+    coef = torch.from_numpy(rng.normal(size=tuple(ref.shape)).astype(np.float32))
+    (ref * coef).sum().backward()
+    m = P.gpu_model(dev, i, sharpen, "fp32", **arch).requires_grad_(True)
+    p_gpu = pts.to(dev).requires_grad_(with_inputs)
+    v_gpu = vd.to(dev).requires_grad_(with_inputs) if vd is not None else None
+    out = m(p_gpu, v_gpu)
+    P.close(out, ref, atol=1e-4 * max(1.0, float(ref.abs().max())), rtol=1e-4)
+    (out * coef.to(dev)).sum().backward()
+
+    def same(tag, got, want):
+        if want is None:
+            assert got is None, (arch, tag)
+            return
+        assert got is not None and bool(torch.isfinite(got).all()), (arch, tag)
+        n = float(want.norm())
+        d = float((got.detach().cpu() - want).norm())
+        # (a ReLU within rounding of zero flips between the two fp32 evaluations -- about one unit per case is expected for the
+        # deep, wide, sharpened draws -- and ONE flipped unit moves a first-layer gradient by ~1 / sqrt(points x width): 1e-3 for
+        # 2600 points x 777 units (measured: case 23), a visible fraction for a handful of points and a width of 2 or 3.
+        # tests/test_gpu_train_f32.py holds the tight gates (1e-6) on draws without such a unit.)
+        assert d <= (5e-3 if arch["W"] >= 31 else 5e-2) * n + 1e-7, (arch, tag, d, n)
+
+    for name, p in m.named_parameters():
+        same(name, p.grad, cpu[name].grad)
+    if with_inputs:
+        same("pts", p_gpu.grad, p_cpu.grad)
+        if vd is not None:
+            same("viewdirs", v_gpu.grad, v_cpu.grad)
