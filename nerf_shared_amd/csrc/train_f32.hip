@@ -288,15 +288,29 @@ __global__ __launch_bounds__(256) void f32_dw_kernel(const float *G, const float
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     const int l32 = lane & 31, hh = lane >> 5;
+    // 64 rows x 32 points of each operand per step (coalesced: 32 consecutive points of a row per half wave), the next
+    // step's values fetched into registers while this step's are multiplied
+    float rg[8], rx[8];
+    auto fetch = [&](int64_t p) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = tid + 256 * j, r = i / DWF_KP, q = i % DWF_KP;
+            const int ro = 64 * bo + r, rxi = 64 * bi + r;
+            const bool in = p + q < pb;
+            rg[j] = (in && ro < n_out) ? G[(int64_t)ro * Pp + p + q] : 0.0f;
+            rx[j] = in ? (rxi < n_in ? X[(int64_t)rxi * Pp + p + q] : rxi == n_in ? 1.0f : 0.0f) : 0.0f;     // row n_in: ones -> the bias gradient
+        }
+    };
+    if (pa < pb) fetch(pa);
     for (int64_t p = pa; p < pb; p += DWF_KP) {
-        // stage 64 rows x 32 points of each operand (coalesced: 32 consecutive points of a row per half wave)
-        for (int i = tid; i < 64 * DWF_KP; i += 256) {
-            const int r = i / DWF_KP, q = i % DWF_KP;
-            const int ro = 64 * bo + r, rx = 64 * bi + r;
-            sg[r][q] = (ro < n_out && p + q < pb) ? G[(int64_t)ro * Pp + p + q] : 0.0f;
-            sx[r][q] = p + q < pb ? (rx < n_in ? X[(int64_t)rx * Pp + p + q] : rx == n_in ? 1.0f : 0.0f) : 0.0f;     // row n_in: ones -> the bias gradient
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = tid + 256 * j, r = i / DWF_KP, q = i % DWF_KP;
+            sg[r][q] = rg[j];
+            sx[r][q] = rx[j];
         }
         __syncthreads();
+        if (p + DWF_KP < pb) fetch(p + DWF_KP);
 #pragma unroll
         for (int k = 0; k < DWF_KP; k += 2)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sg[32 * wo + l32][k + hh], sx[32 * wi + l32][k + hh], acc, 0, 0, 0);
