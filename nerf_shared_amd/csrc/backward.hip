@@ -951,7 +951,10 @@ __global__ __launch_bounds__(512, 2) void dw_multi_kernel(DwMulti m) {
 #ifdef NERF_AMD_X_DW_STAMPS
     if (threadIdx.x == 0) {
         g_dw_stamps[4 * blockIdx.x] = wall_clock64();
-        g_dw_stamps[4 * blockIdx.x + 2] = (unsigned long long)j << 8 | (unsigned)J.shape;
+        unsigned xcc, hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        g_dw_stamps[4 * blockIdx.x + 2] = (unsigned long long)j << 8 | (unsigned)J.shape | (unsigned long long)(xcc & 15) << 32 | (unsigned long long)(hwid & 0xffff) << 40;
     }
 #endif
     switch (J.shape) {

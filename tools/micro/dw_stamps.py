@@ -65,7 +65,8 @@ def main():
     a = a[a[:, 0] != 0]
     t0 = a[:, 0].min()
     start, end = (a[:, 0] - t0) / 100.0, (a[:, 1] - t0) / 100.0
-    job, shape = a[:, 2] >> 8, a[:, 2] & 255
+    job, shape = (a[:, 2] >> 8) & 0xffffff, a[:, 2] & 255
+    xcc, hwid = (a[:, 2] >> 32) & 15, (a[:, 2] >> 40) & 0xffff
     first_chunk = np.where(a[:, 3] > 0, (a[:, 3] & 0xffffffff) / 100.0, np.nan)
     half = np.where(a[:, 3] > 0, (a[:, 3] >> 32) / 100.0, np.nan)
     n_chunks = args.rays * (args.coarse_only or (64 if args.rgb0 else 128 + 64)) // 32
@@ -75,6 +76,24 @@ def main():
         print(f"  product {j:2d} shape {shape[s][0]}  wgs {s.sum():3d}  start {start[s].min():6.1f}..{start[s].max():6.1f}  "
               f"end {end[s].min():6.1f}..{end[s].max():6.1f}  mean {end[s].mean():6.1f}  us/chunk {end[s].mean() / (n_chunks / s.sum()):.3f}  "
               f"first chunk at {np.nanmin(first_chunk[s]):5.1f}..{np.nanmax(first_chunk[s]):5.1f}  half way {np.nanmin(half[s]):6.1f}..{np.nanmax(half[s]):6.1f} (from own start)")
+
+
+    # the same ends by XCD (bf16 kernel only): is a product's slow workgroup always on the same die?
+    if xcc.any():
+        wide = shape == 0
+        print("  256 x 256 products, mean end by XCD:", ["%d: %.1f" % (x, end[wide & (xcc == x)].mean()) for x in range(8) if (wide & (xcc == x)).any()])
+        print("  all products, workgroups per XCD:", np.bincount(xcc, minlength=8).tolist())
+        # relative to the product's own mean
+        rel = np.zeros(len(a))
+        for j in np.unique(job):
+            sj = job == j
+            rel[sj] = end[sj] - end[sj].mean()
+        print("  end minus the product's mean, by XCD:", ["%d: %+.1f" % (x, rel[xcc == x].mean()) for x in range(8)])
+        se = (hwid >> 13) & 7      # gfx9 HW_ID: SE_ID bits 15:13, CU_ID 11:8, SH 12
+        print("  ... by shader engine (HW_ID 15:13):", ["%d: %+.1f" % (x, rel[se == x].mean()) for x in np.unique(se)])
+        order = np.argsort(rel)
+        print("  slowest 8: block / xcd / hw_id / end-mean", [(int(i), int(xcc[i]), hex(int(hwid[i])), round(float(rel[i]), 1)) for i in order[-8:]])
+        print("  fastest 8:", [(int(i), int(xcc[i]), hex(int(hwid[i])), round(float(rel[i]), 1)) for i in order[:8]])
 
 
 if __name__ == "__main__":
