@@ -116,6 +116,7 @@ int nerf_amd_model_create(const nerf_amd_arch *arch, int device, nerf_amd_model 
             e = hipMalloc(reinterpret_cast<void **>(&m->stream_bwd_split), p.frags_bwd_split.size() * 1024);
     }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->stream_f32), (size_t)p.f32_stream_floats * sizeof(float));
+    if (e == hipSuccess && tile_counters_init(device) != NERF_AMD_OK) e = hipErrorOutOfMemory;      // the field kernel's ticket counters
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->bias_f32), (size_t)p.f32_bias_floats * sizeof(float));
     if (e == hipSuccess && p.f32_stream_t_floats > 0)
         e = hipMalloc(reinterpret_cast<void **>(&m->stream_f32_t), (size_t)p.f32_stream_t_floats * sizeof(float));

@@ -35,6 +35,8 @@ struct MlpArgs {
     int32_t S;                     // samples per ray (ray index = p / S)
     int32_t out_ch;
     float *out;                    // [P, out_ch]
+    unsigned *tile_ctr;            // mlp_bf16_s16p_kernel: {next ticket, workgroups done} of this launch (tile_counter_slot), or NULL:
+                                   // tiles dealt blockIdx, blockIdx + gridDim, ... (the static deal)
     // training: every saved / gradient array below has pad_points(P) rows (the kernels store the rows of a
     // workgroup's padding points unconditionally, which keeps their store counts compile-time constants).
     // Activations saved by the forward for the backward pass, bf16, one row per point in
@@ -74,6 +76,10 @@ struct MlpArgs {
 // Rows of the training arrays: P rounded up to whole 256-point workgroups.
 constexpr int64_t pad_points(int64_t P) { return (P + 255) & ~(int64_t)255; }
 
+// A {ticket, done} pair for one launch of a kernel that deals its tiles dynamically (zero between launches: the last
+// workgroup to leave resets it).  Round robin over 1024 pairs per device, allocated by tile_counters_init.
+unsigned *tile_counter_slot(int device);
+int tile_counters_init(int device);
 extern std::atomic<int> g_variant;    // nerf_amd_set_tuning key 0 (A/B selection; relaxed loads in the launchers)
 bool mlp_bf16_supported(int multires, int multires_views, int use_viewdirs);
 int launch_mlp_bf16(const MlpArgs &a, int multires, int multires_views, int use_viewdirs,

@@ -508,6 +508,7 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16p_kernel(MlpArgs
     static_assert(2 * PT_SLOTS <= 32 && 3 + 2 * NSD <= 16, "the encodings must fit on the hooks they are given");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *bias_lds = reinterpret_cast<float *>(smem + C::RING_BYTES);
+    volatile uint32_t *ticket_lds = reinterpret_cast<volatile uint32_t *>(bias_lds + Lay::N_TILES * 16);     // the tile after next (dynamic deal)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -515,6 +516,14 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16p_kernel(MlpArgs
     const int64_t n_point_tiles = (a.P + WG_POINTS - 1) / WG_POINTS;
     int64_t tile = blockIdx.x;
     if (tile >= n_point_tiles) return;                     // whole workgroups only (the launcher never over-provisions)
+    // The tiles a workgroup walks.  Static deal (a.tile_ctr == NULL): blockIdx, blockIdx + gridDim, ...  Dynamic deal: the
+    // first two like that, every later one a TICKET from the launch's counter -- the eight dies do not hold the same clock
+    // at the power cap (tools/micro/field_wg_ends.py: identical cycles per tile on every XCD, workgroups of the fastest die
+    // out 6-8 % of the launch before those of the slowest), and a tile's result does not depend on who computes it.  The
+    // ticket for the tile AFTER next is taken by wave 0 while the next tile's coordinates are loaded (the index of the next
+    // tile is needed that early), handed to the other waves through one LDS word, and read at the end of the iteration.
+    int64_t tile_n = tile + gridDim.x;
+    const bool dynamic = a.tile_ctr != nullptr;
     C c;
     c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     c.lag = __builtin_amdgcn_readfirstlane(c.wave >= C::WAVES / 2 ? 1 : 0);
@@ -591,15 +600,57 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16p_kernel(MlpArgs
     pipeline_prologue<NB>(c);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // bias table stores, before the first barrier publishes them
 
+    // ---- the dynamic deal's two steps, both on hook slots of layer 6 (wave 0 acts, the branch is inside the asm: to the
+    // compiler the hooks stay straight-line code, see issue_block).  take_ticket: one lane's atomic add with return, issued
+    // right in front of the next tile's first coordinate load -- the vmcnt wait the compiler places for THAT load, two hook
+    // slots later, covers the older atomic too (returns are in order), so the ticket costs no wait of its own.
+    unsigned ticket = 0;
+    const unsigned ticket_lds_addr = (unsigned)(uintptr_t)ticket_lds;
+    const int tk_sel = __builtin_amdgcn_readfirstlane(dynamic ? c.wave : 1);      // 0: this wave takes and publishes the tickets
+    auto take_ticket = [&]() {
+        unsigned long long save;
+        const unsigned one = 1u;
+        asm volatile("s_cmp_lg_u32 %[w], 0\n\t"
+                     "s_cbranch_scc1 .Lskip_tk_%=\n\t"
+                     "s_mov_b64 %[sv], exec\n\t"
+                     "s_mov_b64 exec, 1\n\t"
+                     "global_atomic_add %[r], %[p], %[o], off sc0\n\t"
+                     "s_mov_b64 exec, %[sv]\n"
+                     ".Lskip_tk_%=:"
+                     : [r] "+v"(ticket), [sv] "=&s"(save)
+                     : [w] "s"(tk_sel), [p] "v"(a.tile_ctr), [o] "v"(one)
+                     : "memory", "scc");
+    };
+    // publish_ticket: behind the point the loaded coordinates were consumed at (the asm's input ties it to them, so the
+    // compiler's wait for the load precedes it): tile index = 2 gridDim + ticket into the LDS word; the other waves read it at
+    // the end of the iteration, many block syncs later.
+    auto publish_ticket = [&]() {
+        asm volatile("" : "+v"(ticket) : "v"(ld[0]));
+        unsigned ts, tv;
+        asm volatile("s_cmp_lg_u32 %[w], 0\n\t"
+                     "s_cbranch_scc1 .Lskip_tw_%=\n\t"
+                     "v_readfirstlane_b32 %[t], %[tk]\n\t"
+                     "s_add_u32 %[t], %[t], %[b]\n\t"
+                     "v_mov_b32 %[tv], %[t]\n\t"
+                     "ds_write_b32 %[ad], %[tv]\n\t"
+                     "s_waitcnt lgkmcnt(0)\n"
+                     ".Lskip_tw_%=:"
+                     : [t] "=&s"(ts), [tv] "=&v"(tv)
+                     : [w] "s"(tk_sel), [tk] "v"(ticket), [b] "s"(2u * gridDim.x), [ad] "v"(ticket_lds_addr)
+                     : "memory", "scc");
+    };
+
     EncX ex;
     EncD ed;
     auto prepare = [&](auto slot_) {         // slot 0..31 of layers 6 + 7
         constexpr int slot = slot_, cc = slot / PT_SLOTS, r = slot % PT_SLOTS;
         if constexpr (cc < 2) {
             if constexpr (r == SLOT_LOAD) {
-                issue_loads(c.has_next ? tile + gridDim.x : tile, cc);      // nothing follows: reload this tile (never used)
+                if constexpr (cc == 0) take_ticket();
+                issue_loads(c.has_next ? tile_n : tile, cc);                // nothing follows: reload this tile (never used)
             } else if constexpr (r == SLOT_PTS) {
                 make_point();
+                if constexpr (cc == 0) publish_ticket();
             } else if constexpr (r >= SLOT_ENC && r < SLOT_ENC + NSX) {
                 constexpr int st = r - SLOT_ENC;
                 if constexpr (st == 0) ex.begin(xsn[0], xsn[1], xsn[2], q >> 1, q & 1);
@@ -643,7 +694,7 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16p_kernel(MlpArgs
         t_prev = t_now;
     }
 #endif
-    c.has_next = tile + gridDim.x < n_point_tiles;
+    c.has_next = tile_n < n_point_tiles;
     // opaque per-iteration copies of the stream pointers: otherwise the DMA source addresses of the body are
     // loop-invariant, get hoisted in front of the loop and cost ~300 VGPRs
     asm volatile("" : "+v"(c.gstream));
@@ -692,7 +743,8 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16p_kernel(MlpArgs
         });
     }
     if (!c.has_next) break;
-    tile += gridDim.x;
+    tile = tile_n;
+    tile_n = dynamic ? (int64_t)*ticket_lds : tile + gridDim.x;
     if constexpr (SHIFT != 0) {              // the next tile's block b lives in the slot this tile's block b + NB had
         uint32_t sl[C::NS], su[C::NS];
 #pragma unroll
@@ -701,7 +753,41 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16p_kernel(MlpArgs
         for (int i = 0; i < C::NS; ++i) { c.slot_lane[i] = sl[i]; c.slot_u32[i] = su[i]; }
     }
     }
+#ifdef NERF_AMD_STAMPS
+    if (a.stamps && lane == 0) {             // diagnostic build: when this wave left the kernel (100 MHz clock) and on which XCD
+        unsigned long long *o = a.stamps + ((size_t)blockIdx.x * C::WAVES + c.wave) * 4;
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        o[0] = wall_clock64();
+        o[2] = xcc & 15;
+    }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // no LDS-DMA may outlive the workgroup
+    if (dynamic && tid == 0) {                                 // the last workgroup out leaves the pair zero for its next launch
+        if (atomicAdd(a.tile_ctr + 1, 1u) == gridDim.x - 1) { a.tile_ctr[0] = 0u; a.tile_ctr[1] = 0u; }
+    }
+}
+
+// ---- {ticket, done} pairs of the dynamic deal
+namespace {
+constexpr int TILE_CTR_SLOTS = 1024;
+unsigned *g_tile_ctr[16] = {};
+std::atomic<unsigned> g_tile_ctr_next{0};
+}  // namespace
+
+int tile_counters_init(int device) {
+    if (device < 0 || device >= 16) return NERF_AMD_EINVAL;
+    if (g_tile_ctr[device]) return NERF_AMD_OK;
+    unsigned *p = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&p), TILE_CTR_SLOTS * 2 * sizeof(unsigned)) != hipSuccess) return NERF_AMD_EHIP;
+    if (hipMemset(p, 0, TILE_CTR_SLOTS * 2 * sizeof(unsigned)) != hipSuccess) { (void)hipFree(p); return NERF_AMD_EHIP; }
+    g_tile_ctr[device] = p;
+    return NERF_AMD_OK;
+}
+
+unsigned *tile_counter_slot(int device) {
+    if (device < 0 || device >= 16 || !g_tile_ctr[device]) return nullptr;
+    return g_tile_ctr[device] + 2 * (g_tile_ctr_next.fetch_add(1, std::memory_order_relaxed) % TILE_CTR_SLOTS);
 }
 
 template <int LX, int LD, bool VD, class C>
@@ -709,21 +795,22 @@ static int launch_wg16p(const MlpArgs &a, int n_frags_used, int n_tiles, hipStre
     constexpr int WG_THREADS = C::WAVES * 64, WG_POINTS = C::WAVES * 32;
     using Lay = Layout16<LX, LD, VD>;
     if (n_frags_used != Lay::F_END || n_tiles != Lay::N_TILES) return NERF_AMD_EINVAL;
-    const size_t lds = C::RING_BYTES + (size_t)Lay::N_TILES * 16 * sizeof(float);
+    const size_t lds = C::RING_BYTES + (size_t)Lay::N_TILES * 16 * sizeof(float) + 16;      // + the ticket word
     static DynamicLdsOptIn opt_in;
     if (opt_in.ensure(reinterpret_cast<const void *>(mlp_bf16_s16p_kernel<LX, LD, VD, C>), lds) != hipSuccess) return NERF_AMD_EHIP;
     int64_t groups = (a.P + WG_POINTS - 1) / WG_POINTS;
     if (groups <= 0) return NERF_AMD_OK;
     if (a.P >= (int64_t)1 << 31) return NERF_AMD_EINVAL;
     const int n_cu = device_cu_count();      // one workgroup per CU walks the tiles
+    const bool deal = groups > 2 * (int64_t)n_cu && g_variant != 42;      // more than two tiles per workgroup: dealt by ticket (A/B 42: static)
     if (groups > n_cu) groups = n_cu;
-#ifdef NERF_AMD_STAMPS
     MlpArgs a2 = a;
+    int dev = 0;
+    a2.tile_ctr = deal && hipGetDevice(&dev) == hipSuccess ? tile_counter_slot(dev) : nullptr;
+#ifdef NERF_AMD_STAMPS
     a2.stamps = g_stamp_buf;
-    hipLaunchKernelGGL((mlp_bf16_s16p_kernel<LX, LD, VD, C>), dim3((unsigned)groups), dim3(WG_THREADS), lds, s, a2);
-    return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 #endif
-    hipLaunchKernelGGL((mlp_bf16_s16p_kernel<LX, LD, VD, C>), dim3((unsigned)groups), dim3(WG_THREADS), lds, s, a);
+    hipLaunchKernelGGL((mlp_bf16_s16p_kernel<LX, LD, VD, C>), dim3((unsigned)groups), dim3(WG_THREADS), lds, s, a2);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
 
