@@ -321,8 +321,14 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16_kernel(MlpArgs 
     // A workgroup walks 256-point tiles blockIdx.x, blockIdx.x + gridDim.x, ...: with one workgroup per CU
     // (the launcher's choice for large P) the dispatch of a fresh workgroup per tile disappears.
     const int64_t n_point_tiles = (a.P + WG_POINTS - 1) / WG_POINTS;
+    // (a.tile_ctr != NULL: every tile after the first is a ticket from the launch's counter, see mlp_bf16_s16p_kernel; here
+    // the atomic is taken at the top of a tile and consumed behind the tile's own end-of-tile drain)
+    volatile uint32_t *ticket_lds = reinterpret_cast<volatile uint32_t *>(bias_lds + Lay::N_TILES * 16);
+    const bool dynamic = a.tile_ctr != nullptr;
 #pragma unroll 1
-    for (int64_t tile = blockIdx.x; tile < n_point_tiles; tile += gridDim.x) {
+    for (int64_t tile = blockIdx.x; tile < n_point_tiles;) {
+    unsigned ticket = 0;
+    if (dynamic && tid == 0) ticket = atomicAdd(a.tile_ctr, 1u);
     STAMP(t0);
     // opaque per-iteration copy of the stream pointer: otherwise the 148 DMA source addresses of the body are
     // loop-invariant, get hoisted in front of the loop and cost ~300 VGPRs
@@ -459,7 +465,9 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16_kernel(MlpArgs 
     }
     STAMP(t2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // no LDS-DMA may outlive the tile (or the workgroup)
+    if (dynamic && tid == 0) *ticket_lds = gridDim.x + ticket;
     __syncthreads();                                           // every wave is done with the ring before it is refilled
+    tile = dynamic ? (int64_t)*ticket_lds : tile + gridDim.x;
 #ifdef NERF_AMD_STAMPS
     if (a.stamps && lane == 0) {
         const unsigned long long t3 = __builtin_amdgcn_s_memtime();
@@ -467,6 +475,9 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16_kernel(MlpArgs 
         o[0] += t1 - t0; o[1] += t2 - t1; o[2] += t3 - t2; o[3] += 1;
     }
 #endif
+    }
+    if (dynamic && tid == 0) {                                 // the last workgroup out leaves the pair zero for its next launch
+        if (atomicAdd(a.tile_ctr + 1, 1u) == gridDim.x - 1) { a.tile_ctr[0] = 0u; a.tile_ctr[1] = 0u; }
     }
 }
 
@@ -819,24 +830,26 @@ static int launch_wg16(const MlpArgs &a, int n_frags_used, int n_tiles, hipStrea
     constexpr int WG_THREADS = C::WAVES * 64, WG_POINTS = C::WAVES * 32;
     using Lay = Layout16<LX, LD, VD>;
     if (n_frags_used != Lay::F_END || n_tiles != Lay::N_TILES) return NERF_AMD_EINVAL;
-    const size_t lds = C::RING_BYTES + (size_t)Lay::N_TILES * 16 * sizeof(float);
+    const size_t lds = C::RING_BYTES + (size_t)Lay::N_TILES * 16 * sizeof(float) + 16;      // + the ticket word
     static DynamicLdsOptIn opt_in;         // per kernel instantiation, tracks every device (launch_util.h)
     if (opt_in.ensure(reinterpret_cast<const void *>(mlp_bf16_s16_kernel<LX, LD, VD, C, SAVE>), lds) != hipSuccess)
         return NERF_AMD_EHIP;
     int64_t groups = (a.P + WG_POINTS - 1) / WG_POINTS;
     if (groups <= 0) return NERF_AMD_OK;
     if (a.P >= (int64_t)1 << 31) return NERF_AMD_EINVAL;
+    bool deal = false;
     if (g_variant != 31) {                 // one workgroup per CU walks the tiles (+1 %: no per-tile dispatch); 31 = A/B off
         const int n_wg = device_cu_count() * (8 / C::WAVES);     // 4-wave workgroups: two per CU
+        deal = groups > 2 * (int64_t)n_wg && g_variant != 42;    // ... and takes them by ticket (A/B 42: blockIdx + k gridDim)
         if (groups > n_wg) groups = n_wg;
     }
-#ifdef NERF_AMD_STAMPS
     MlpArgs a2 = a;
+    int dev = 0;
+    a2.tile_ctr = deal && hipGetDevice(&dev) == hipSuccess ? tile_counter_slot(dev) : nullptr;
+#ifdef NERF_AMD_STAMPS
     a2.stamps = g_stamp_buf;
-    hipLaunchKernelGGL((mlp_bf16_s16_kernel<LX, LD, VD, C, SAVE>), dim3((unsigned)groups), dim3(WG_THREADS), lds, s, a2);
-    return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 #endif
-    hipLaunchKernelGGL((mlp_bf16_s16_kernel<LX, LD, VD, C, SAVE>), dim3((unsigned)groups), dim3(WG_THREADS), lds, s, a);
+    hipLaunchKernelGGL((mlp_bf16_s16_kernel<LX, LD, VD, C, SAVE>), dim3((unsigned)groups), dim3(WG_THREADS), lds, s, a2);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
 

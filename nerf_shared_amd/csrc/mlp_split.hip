@@ -238,8 +238,15 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_split_kernel(MlpArgs a) 
 
     // one workgroup per CU walks the 128-point tiles blockIdx.x, blockIdx.x + gridDim.x, ...
     const int64_t n_point_tiles = (a.P + WG_POINTS - 1) / WG_POINTS;
+    // (a.tile_ctr != NULL: every tile after the first is a ticket from the launch's counter -- the dies do not hold the same
+    // clock at the power cap, mlp_bf16_s16.hip mlp_bf16_s16p_kernel; the atomic is taken at the top of a tile and consumed
+    // behind the tile's own end-of-tile drain, so it costs no wait)
+    volatile uint32_t *ticket_lds = reinterpret_cast<volatile uint32_t *>(bias_lds + Lay::N_TILES * 16);
+    const bool dynamic = a.tile_ctr != nullptr;
 #pragma unroll 1
-    for (int64_t tile = blockIdx.x; tile < n_point_tiles; tile += gridDim.x) {
+    for (int64_t tile = blockIdx.x; tile < n_point_tiles;) {
+    unsigned ticket = 0;
+    if (dynamic && tid == 0) ticket = atomicAdd(a.tile_ctr, 1u);
     // opaque per-iteration copy of the stream pointer (the DMA source addresses must not be hoisted out of the loop)
     asm volatile("" : "+v"(c.gstream));
     pipeline_prologue<NB>(c);
@@ -339,7 +346,12 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_split_kernel(MlpArgs a) 
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // no LDS-DMA may outlive the tile (or the workgroup)
+    if (dynamic && tid == 0) *ticket_lds = gridDim.x + ticket;
     __syncthreads();                                           // every wave is done with the ring before it is refilled
+    tile = dynamic ? (int64_t)*ticket_lds : tile + gridDim.x;
+    }
+    if (dynamic && tid == 0) {                                 // the last workgroup out leaves the pair zero for its next launch
+        if (atomicAdd(a.tile_ctr + 1, 1u) == gridDim.x - 1) { a.tile_ctr[0] = 0u; a.tile_ctr[1] = 0u; }
     }
 }
 
@@ -348,15 +360,19 @@ static int launch_split(const MlpArgs &a, int n_frags_used, int n_tiles, hipStre
     constexpr int WG_THREADS = C::WAVES * 64, WG_POINTS = C::WAVES * 16;
     using Lay = LayoutSplit<LX, LD, VD>;
     if (n_frags_used != Lay::F_END || n_tiles != Lay::N_TILES) return NERF_AMD_EINVAL;
-    const size_t lds = C::RING_BYTES + (size_t)Lay::N_TILES * 16 * sizeof(float);
+    const size_t lds = C::RING_BYTES + (size_t)Lay::N_TILES * 16 * sizeof(float) + 16;      // + the ticket word
     static DynamicLdsOptIn opt_in;         // per kernel instantiation, tracks every device (launch_util.h)
     if (opt_in.ensure(reinterpret_cast<const void *>(mlp_split_kernel<LX, LD, VD, C, SAVE>), lds) != hipSuccess) return NERF_AMD_EHIP;
     int64_t groups = (a.P + WG_POINTS - 1) / WG_POINTS;
     if (groups <= 0) return NERF_AMD_OK;
     if (a.P >= (int64_t)1 << 31) return NERF_AMD_EINVAL;
     const int n_wg = device_cu_count();      // one workgroup per CU walks the tiles
+    const bool deal = groups > 2 * (int64_t)n_wg && g_variant != 42;      // dealt by ticket (A/B 42: blockIdx + k gridDim)
     if (groups > n_wg) groups = n_wg;
-    hipLaunchKernelGGL((mlp_split_kernel<LX, LD, VD, C, SAVE>), dim3((unsigned)groups), dim3(WG_THREADS), lds, s, a);
+    MlpArgs a2 = a;
+    int dev = 0;
+    a2.tile_ctr = deal && hipGetDevice(&dev) == hipSuccess ? tile_counter_slot(dev) : nullptr;
+    hipLaunchKernelGGL((mlp_split_kernel<LX, LD, VD, C, SAVE>), dim3((unsigned)groups), dim3(WG_THREADS), lds, s, a2);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }
 
