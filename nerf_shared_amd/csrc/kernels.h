@@ -79,6 +79,9 @@ constexpr int64_t pad_points(int64_t P) { return (P + 255) & ~(int64_t)255; }
 // A {ticket, done} pair for one launch of a kernel that deals its tiles dynamically (zero between launches: the last
 // workgroup to leave resets it).  Round robin over 1024 pairs per device, allocated by tile_counters_init.
 unsigned *tile_counter_slot(int device);
+// ... for a launch on stream s, or NULL (= the static deal) when the deal is off or s is being captured into a graph: a
+// captured launch would bake its pair into every replay, and a replay may run beside an eager launch that drew the same pair
+unsigned *tile_counter_for(bool deal, hipStream_t s);
 int tile_counters_init(int device);
 extern std::atomic<int> g_variant;    // nerf_amd_set_tuning key 0 (A/B selection; relaxed loads in the launchers)
 bool mlp_bf16_supported(int multires, int multires_views, int use_viewdirs);

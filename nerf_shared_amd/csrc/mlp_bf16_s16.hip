@@ -801,6 +801,14 @@ unsigned *tile_counter_slot(int device) {
     return g_tile_ctr[device] + 2 * (g_tile_ctr_next.fetch_add(1, std::memory_order_relaxed) % TILE_CTR_SLOTS);
 }
 
+unsigned *tile_counter_for(bool deal, hipStream_t s) {
+    if (!deal) return nullptr;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
+    int dev = 0;
+    return hipGetDevice(&dev) == hipSuccess ? tile_counter_slot(dev) : nullptr;
+}
+
 template <int LX, int LD, bool VD, class C>
 static int launch_wg16p(const MlpArgs &a, int n_frags_used, int n_tiles, hipStream_t s) {
     constexpr int WG_THREADS = C::WAVES * 64, WG_POINTS = C::WAVES * 32;
@@ -816,8 +824,7 @@ static int launch_wg16p(const MlpArgs &a, int n_frags_used, int n_tiles, hipStre
     const bool deal = groups > 2 * (int64_t)n_cu && g_variant != 42;      // more than two tiles per workgroup: dealt by ticket (A/B 42: static)
     if (groups > n_cu) groups = n_cu;
     MlpArgs a2 = a;
-    int dev = 0;
-    a2.tile_ctr = deal && hipGetDevice(&dev) == hipSuccess ? tile_counter_slot(dev) : nullptr;
+    a2.tile_ctr = tile_counter_for(deal, s);
 #ifdef NERF_AMD_STAMPS
     a2.stamps = g_stamp_buf;
 #endif
@@ -844,8 +851,7 @@ static int launch_wg16(const MlpArgs &a, int n_frags_used, int n_tiles, hipStrea
         if (groups > n_wg) groups = n_wg;
     }
     MlpArgs a2 = a;
-    int dev = 0;
-    a2.tile_ctr = deal && hipGetDevice(&dev) == hipSuccess ? tile_counter_slot(dev) : nullptr;
+    a2.tile_ctr = tile_counter_for(deal, s);
 #ifdef NERF_AMD_STAMPS
     a2.stamps = g_stamp_buf;
 #endif

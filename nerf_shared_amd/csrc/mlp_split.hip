@@ -370,8 +370,7 @@ static int launch_split(const MlpArgs &a, int n_frags_used, int n_tiles, hipStre
     const bool deal = groups > 2 * (int64_t)n_wg && g_variant != 42;      // dealt by ticket (A/B 42: blockIdx + k gridDim)
     if (groups > n_wg) groups = n_wg;
     MlpArgs a2 = a;
-    int dev = 0;
-    a2.tile_ctr = deal && hipGetDevice(&dev) == hipSuccess ? tile_counter_slot(dev) : nullptr;
+    a2.tile_ctr = tile_counter_for(deal, s);
     hipLaunchKernelGGL((mlp_split_kernel<LX, LD, VD, C, SAVE>), dim3((unsigned)groups), dim3(WG_THREADS), lds, s, a2);
     return hipGetLastError() == hipSuccess ? NERF_AMD_OK : NERF_AMD_EHIP;
 }

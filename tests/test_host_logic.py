@@ -324,7 +324,9 @@ def test_field_kernel_keeps_its_weight_read_ahead(tmp_path):
                        ("mlp_bf16_s16_kernelILi10ELi4ELb1ENS_3CtxILi8ELi16ELi4ELi8ELi2ELi0ELi1ELi0ENS_8NoLedgerEEELb1", 74)):
         for lag in (0, 2):                    # the two DMA issue phases
             st = check_vmcnt.check(asm, tag, verbose=False, lag=lag)
-            assert st["kernels"] == 1 and st["ok"] and st["syncs"] == syncs and st["dma_pieces"] == 2 * syncs, (tag, lag, st)
+            # (+ 1: the end-of-tile drain, `s_waitcnt vmcnt(0)`, where it sits right in front of the barrier that publishes the
+            # next tile's ticket -- a wait for everything, which the replay accepts like any other sync)
+            assert st["kernels"] == 1 and st["ok"] and st["syncs"] - syncs in (0, 1) and st["dma_pieces"] == 2 * syncs, (tag, lag, st)
             assert not check_vmcnt.check(asm, tag, verbose=False, lag=lag, slack=3)["ok"]      # the checker can fail
 
 
