@@ -323,7 +323,7 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16_kernel(MlpArgs 
     const int64_t n_point_tiles = (a.P + WG_POINTS - 1) / WG_POINTS;
     // (a.tile_ctr != NULL: every tile after the first is a ticket from the launch's counter, see mlp_bf16_s16p_kernel; here
     // the atomic is taken at the top of a tile and consumed behind the tile's own end-of-tile drain)
-    volatile uint32_t *ticket_lds = reinterpret_cast<volatile uint32_t *>(bias_lds + Lay::N_TILES * 16);
+    lds_u32_t *ticket_lds = (lds_u32_t *)(uintptr_t)(uint32_t)(uintptr_t)(bias_lds + Lay::N_TILES * 16);
     const bool dynamic = a.tile_ctr != nullptr;
 #pragma unroll 1
     for (int64_t tile = blockIdx.x; tile < n_point_tiles;) {
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_bf16_s16p_kernel(MlpArgs
     static_assert(2 * PT_SLOTS <= 32 && 3 + 2 * NSD <= 16, "the encodings must fit on the hooks they are given");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *bias_lds = reinterpret_cast<float *>(smem + C::RING_BYTES);
-    volatile uint32_t *ticket_lds = reinterpret_cast<volatile uint32_t *>(bias_lds + Lay::N_TILES * 16);     // the tile after next (dynamic deal)
+    lds_u32_t *ticket_lds = (lds_u32_t *)(uintptr_t)(uint32_t)(uintptr_t)(bias_lds + Lay::N_TILES * 16);     // the tile after next (dynamic deal)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;

@@ -64,6 +64,19 @@ int launch_embed(const float *x, int64_t n, int multires, float *out, hipStream_
 // never overwritten, so both concats of the reference are a different first row.
 constexpr int F32_MAX_TILES_PER_WAVE = 4;            // n_out <= 8 * 4 * 32 = 1024
 
+#ifdef NERF_AMD_STAMPS
+// tools/micro/f32_xcd_ends.py: when the first workgroup on each XCD started and the last one ended (100 MHz clock)
+__device__ unsigned long long g_f32_xcd[2 * 8];
+extern "C" int nerf_amd_x_f32_xcd(unsigned long long *out, int reset) {
+    if (reset) {
+        unsigned long long init[16];
+        for (int i = 0; i < 8; ++i) { init[2 * i] = ~0ull; init[2 * i + 1] = 0ull; }
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_f32_xcd), init, sizeof(init)) == hipSuccess ? 0 : -1;
+    }
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_f32_xcd), sizeof(g_f32_xcd)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 // TPW: 32-row output tiles per wave (n_out <= 8 * 32 * TPW): the accumulators of all of a wave's tiles stay in registers from
 // the compute phase to the write-back, so the instantiation for W <= 256 holds 32 of them instead of 128.
 template <int TPW, int HALVES>
@@ -74,6 +87,12 @@ __global__ __launch_bounds__(512) void mlp_f32_kernel(MlpArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pt = lane & 31, h = lane >> 5;
 
+#ifdef NERF_AMD_STAMPS
+    unsigned xcc_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+    xcc_id &= 7;
+    if (tid == 0) atomicMin(&g_f32_xcd[2 * xcc_id], wall_clock64());
+#endif
     for (int i = tid; i < rows * PTS; i += 512) act[i] = 0.0f;
     __syncthreads();
 
@@ -235,6 +254,9 @@ __global__ __launch_bounds__(512) void mlp_f32_kernel(MlpArgs a) {
         }
         __syncthreads();
     }
+#ifdef NERF_AMD_STAMPS
+    if (tid == 0) atomicMax(&g_f32_xcd[2 * xcc_id + 1], wall_clock64());
+#endif
 }
 
 int launch_mlp_f32(const MlpArgs &a, hipStream_t s) {

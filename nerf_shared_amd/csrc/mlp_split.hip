@@ -241,7 +241,7 @@ __global__ __launch_bounds__(C::WAVES * 64, 2) void mlp_split_kernel(MlpArgs a) 
     // (a.tile_ctr != NULL: every tile after the first is a ticket from the launch's counter -- the dies do not hold the same
     // clock at the power cap, mlp_bf16_s16.hip mlp_bf16_s16p_kernel; the atomic is taken at the top of a tile and consumed
     // behind the tile's own end-of-tile drain, so it costs no wait)
-    volatile uint32_t *ticket_lds = reinterpret_cast<volatile uint32_t *>(bias_lds + Lay::N_TILES * 16);
+    lds_u32_t *ticket_lds = (lds_u32_t *)(uintptr_t)(uint32_t)(uintptr_t)(bias_lds + Lay::N_TILES * 16);
     const bool dynamic = a.tile_ctr != nullptr;
 #pragma unroll 1
     for (int64_t tile = blockIdx.x; tile < n_point_tiles;) {

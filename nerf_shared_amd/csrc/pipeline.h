@@ -99,6 +99,7 @@ __device__ __forceinline__ __attribute__((ext_vector_type(4))) unsigned make_rsr
 }
 
 typedef __attribute__((address_space(3))) const bf16x8 lds_frag_t;
+typedef __attribute__((address_space(3))) volatile uint32_t lds_u32_t;      // an LDS word addressed as LDS (no generic-pointer cast)
 
 // LDS-DMA of this wave's share of stream block BB into its ring slot.  SRC >= 0: block SRC of the NEXT tile's
 // stream goes into the slot that block BB of the through-numbered stream owns (CONTINUOUS).
