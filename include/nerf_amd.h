@@ -89,7 +89,7 @@ int  nerf_amd_model_create(const nerf_amd_arch *arch, int device, nerf_amd_model
 int  nerf_amd_model_update(nerf_amd_model *m, const float *const *weights, const float *const *biases,
                            int n_tensors, void *stream);
 /*
- * The same for some of the packed copies only (a training step in one precision needs two of the five; re-packing all
+ * The same for some of the packed copies only (a training step in one precision needs two of the six; re-packing all
  * of them after every optimizer step is 22 us per model of a 1.6-ms step).  `copies`: bit-or of NERF_AMD_COPY_*.
  * `others_current` != 0: the parameters are the ones the OTHER copies were packed from (a copy is being added for the
  * same weights) -- they stay valid; 0: the parameters changed, the other copies become stale.  Every entry point
@@ -191,6 +191,12 @@ int nerf_amd_raw2outputs_backward(const float *raw, int32_t raw_ch, const float 
  *                             weight-gradient products an fp16 (hi, lo) pair, three MFMAs per product, fp32 accumulation;
  *                             dL/draw is scaled by a power of two taken from its own maximum (csrc/split.h) and the scale
  *                             comes off exactly at the end.  Gradients agree with fp32 autograd to ~1e-6 relative.
+ *   NERF_AMD_PREC_FP32        exact fp32 (v_mfma_f32_32x32x2_f32 everywhere, csrc/train_f32.hip) for ANY architecture
+ *                             nerf_amd_model_create accepts -- what the reference's netdepth / netwidth / skips flags build
+ *                             (config_parser.py:18-25); the same gradients (parameters, points / rays, view directions)
+ *                             within 1e-6 of fp32 autograd, at the fp32 MFMA rate: the fallback for models outside the
+ *                             family above, not a tuned path.  nerf_amd_model_supports_training(m, precision) says which
+ *                             precisions a model trains in.
  *   forward_train : the fused forward (explicit pts + viewdirs, or rays + z_vals with pts = o + d z) that also saves every
  *                   layer's activations in `workspace` (nerf_amd_train_workspace bytes, 256-B aligned)
  *   backward      : dL/draw [P,4] -> gradients of every nn.Linear weight [out,in] and bias [out]
