@@ -835,9 +835,18 @@ int nerf_amd_render_batch(const nerf_amd_render_cfg *cfg, const nerf_amd_model *
         H(hipEventRecord(ec[k], main_s), "hipEventRecord");
     };
     if (two_pass) {
-        // main:  C0 C1 F0 C2 F1 C3 F2 ...        side:  M0  M1+Fin0  M2+Fin1 ... Fin(n-1)
+        // main:  C0 C1 C2 C3 ...     fine:  F0 F1 F2 ...        side:  M0  M1+Fin0  M2+Fin1 ... Fin(n-1)
         // M = coarse compositing + resampling (needs C), Fin = final compositing (needs F), both per-ray kernels that run
-        // beside the next field kernel instead of between two of them.
+        // beside the next field kernel instead of between two of them.  The fine-pass field kernels have a stream of their
+        // own (round 4): F(k) needs M(k), not C(k+1), and with both in flight the workgroups of the one fill the CUs the
+        // other's last tiles leave free (the kernels deal their tiles by ticket, so it does not matter how the dispatcher
+        // splits the chip between them).  A/B 43: the fine pass on the caller's stream behind C(k+1), as before.
+        hipStream_t fine_s = main_s;
+        hipStream_t lanes2[2];
+        if (g_variant != 43 && lane_streams(device, 2, lanes2) == NERF_AMD_OK) {
+            fine_s = lanes2[1];
+            H(hipStreamWaitEvent(fine_s, start, 0), "hipStreamWaitEvent");
+        }
         coarse_field(0);
         for (int64_t k = 0; k < n && !rc; ++k) {
             if (k + 1 < n) coarse_field(k + 1);
@@ -845,9 +854,9 @@ int nerf_amd_render_batch(const nerf_amd_render_cfg *cfg, const nerf_amd_model *
             if (k > 0) H(hipStreamWaitEvent(side, ef[k - 1], 0), "hipStreamWaitEvent");
             if (!rc) rc = stage_mid(plans[k], k > 0 ? &plans[k - 1] : nullptr, side);
             H(hipEventRecord(em[k], side), "hipEventRecord");
-            H(hipStreamWaitEvent(main_s, em[k], 0), "hipStreamWaitEvent");
-            if (!rc) rc = stage_field(plans[k], true, main_s);
-            H(hipEventRecord(ef[k], main_s), "hipEventRecord");
+            H(hipStreamWaitEvent(fine_s, em[k], 0), "hipStreamWaitEvent");
+            if (!rc) rc = stage_field(plans[k], true, fine_s);
+            H(hipEventRecord(ef[k], fine_s), "hipEventRecord");
         }
         H(hipStreamWaitEvent(side, ef[n - 1], 0), "hipStreamWaitEvent");
         if (!rc) rc = stage_final(plans[n - 1], side);
