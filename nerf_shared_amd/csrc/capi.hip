@@ -835,15 +835,16 @@ int nerf_amd_render_batch(const nerf_amd_render_cfg *cfg, const nerf_amd_model *
         H(hipEventRecord(ec[k], main_s), "hipEventRecord");
     };
     if (two_pass) {
-        // main:  C0 C1 C2 C3 ...     fine:  F0 F1 F2 ...        side:  M0  M1+Fin0  M2+Fin1 ... Fin(n-1)
+        // main:  C0 C1 F0 C2 F1 C3 F2 ...        side:  M0  M1+Fin0  M2+Fin1 ... Fin(n-1)
         // M = coarse compositing + resampling (needs C), Fin = final compositing (needs F), both per-ray kernels that run
-        // beside the next field kernel instead of between two of them.  The fine-pass field kernels have a stream of their
-        // own (round 4): F(k) needs M(k), not C(k+1), and with both in flight the workgroups of the one fill the CUs the
-        // other's last tiles leave free (the kernels deal their tiles by ticket, so it does not matter how the dispatcher
-        // splits the chip between them).  A/B 43: the fine pass on the caller's stream behind C(k+1), as before.
+        // beside the next field kernel instead of between two of them.  A/B 44 (round 4): the fine-pass field kernels on a
+        // stream of their own -- F(k) needs M(k), not C(k+1), and with both in flight the workgroups of the one fill the CUs
+        // the other's last tiles leave free: 0.4 % faster per view (tools/micro/view_ab.py), bit-identical.  Not the default:
+        // with two field kernels resident at once a launch's duration -- what the roofline is read from, in bench.py's events
+        // and in rocprofv3's kernel stats alike -- no longer says what the kernel does.
         hipStream_t fine_s = main_s;
         hipStream_t lanes2[2];
-        if (g_variant != 43 && lane_streams(device, 2, lanes2) == NERF_AMD_OK) {
+        if (g_variant == 44 && lane_streams(device, 2, lanes2) == NERF_AMD_OK) {
             fine_s = lanes2[1];
             H(hipStreamWaitEvent(fine_s, start, 0), "hipStreamWaitEvent");
         }

@@ -2,7 +2,7 @@
 """Same-process A/B of whole-view renders (the bench's workload: 400x400, 64+128, 8x256 with view branch) under two
 values of nerf_amd_set_tuning(0, .): interleaved rounds, bit-identical outputs required.
 
-    python tools/micro/view_ab.py 0 43        # 43: the fine-pass field kernels on the caller's stream, as before round 4
+    python tools/micro/view_ab.py 0 44 42     # 44: the fine-pass field kernels on a stream of their own; 42: static tile deal
 """
 import os
 import statistics
@@ -18,7 +18,7 @@ ARCH = dict(D=8, W=256, output_ch=5, skips=[4], use_viewdirs=True, multires=10, 
 
 
 def main():
-    variants = [int(v) for v in sys.argv[1:]] or [0, 43]
+    variants = [int(v) for v in sys.argv[1:]] or [0, 44]
     dev = torch.device("cuda:0")
     ms = []
     for seed in (1, 19):
