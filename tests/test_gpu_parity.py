@@ -161,7 +161,7 @@ def attributed_close(cfg, batch_cpu, coarse_cpu, fine_cpu, got, ref_maps=None, p
         maps = {"rgb_map": ref_maps["rgb_map"], "acc_map": ref_maps["acc_map"], "z_vals": ref_maps.get("z_vals", ref["z_vals"])}
     att = PC.attribute(ocfg, batch_cpu, coarse_cpu, fine_cpu, got, ref=ref, pytest=pytest_flag, ref_maps=maps)
     summary = {k: v for k, v in att.items() if not k.startswith("_")}
-    assert att["unexplained"] == 0, (label, summary)
+    assert att["unexplained"] == 0, (label, att["unexplained_rays"], summary)      # (ray, how far it moved, its worst sample's displacement in ulp)
     assert att["staged_raw_max"] < 2e-4 and att["staged_rgb_max"] < 1e-5 and att["staged_acc_max"] < 1e-5, (label, summary)
     assert att["frac_gt_1e-3"] <= ATTR_FRAC_BIG, (label, summary)
     close(got["weights"], att["_staged_weights"], atol=1e-6, rtol=1e-4)

@@ -94,10 +94,13 @@ def attribute(cfg, batch, coarse, fine, got, ref=None, pytest=False, tol=2e-4, r
       staged      the build's raw equals the oracle's field evaluated ON THE BUILD'S OWN DEPTHS within the stage tolerance,
                   and its maps equal the oracle's compositing of the build's own raw: `staged_*` maxima over ALL rays;
       displaced   what moved against the reference (max |rgb, acc difference| > tol) must have a cause in the reference's own
-                  conditioning: (a) a fine sample whose depth differs from the reference's by more than 4 ulp -- sample_pdf
-                  (utils.py:105-113) turns last-bit differences of the coarse weights into moved samples, and the field is
-                  evaluated at 2^9 x the depth -- or (b) a last sample with |sigma| below the stage tolerance and transmittance
-                  left (dists[-1] = 1e10 makes its alpha a step function, render_utils.py:257);
+                  conditioning: (a) its depths -- sample_pdf (utils.py:105-113) turns last-bit differences of the coarse
+                  weights into moved samples, and the field is evaluated at 2^9 x the depth.  Either a fine sample differs
+                  from the reference's by more than 4 ulp, or THE ORACLE ITSELF, given the build's depths, moves at least
+                  half as far from the reference as the build did (`d_depth`: a sharpened field turns 3 ulp of depth into
+                  3e-4 of colour; found by the round-4 sweep with new seeds) -- or (b) a last sample with |sigma| below the
+                  stage tolerance and transmittance left (dists[-1] = 1e10 makes its alpha a step function,
+                  render_utils.py:257);
       unexplained rays that moved with neither: must be 0.
     """
     if ref is None:
@@ -117,13 +120,8 @@ def attribute(cfg, batch, coarse, fine, got, ref=None, pytest=False, tol=2e-4, r
     displaced = (dz > 4.0 * np.spacing(np.abs(z_ref32)).astype(np.float64)).any(-1)
     cond_b = (np.abs(f64(ref["sigma_last"])) < sigma_thresh) & (f64(ref["t_last"]) > t_thresh)
     moved, moved_big = d > tol, d > big
-    out = {"rays": int(d.shape[0]), "max_abs": float(d.max()), "median_abs": float(np.median(d)),
-           "frac_gt_tol": float(moved.mean()), "frac_gt_1e-3": float(moved_big.mean()),
-           "frac_displaced": float(displaced.mean()), "frac_last_flip_prone": float(cond_b.mean()),
-           "unexplained": int((moved & ~displaced & ~cond_b).sum()),
-           "max_abs_undisplaced": float(d[~displaced & ~cond_b].max()) if (~displaced & ~cond_b).any() else 0.0,
-           "z_displacement_max": float(dz.max())}
-    # ---- staged: the oracle's fine pass on the build's own depths, the oracle's compositing of the build's own raw
+    # ---- staged: the oracle's fine pass on the build's own depths, the oracle's compositing of the build's own raw -- and the
+    # oracle's compositing of ITS OWN raw on those depths: what the depths alone do to the maps
     with torch.no_grad():
         z = got["z_vals"].detach().cpu()
         pts = batch[:, None, 0:3] + batch[:, None, 3:6] * z[..., None]
@@ -131,12 +129,26 @@ def attribute(cfg, batch, coarse, fine, got, ref=None, pytest=False, tol=2e-4, r
         raw_o = O.nerf_forward(net[0], net[1], pts, batch[:, -3:] if batch.shape[-1] > 8 else None)
         noise1 = (O.pytest_uniform(list(z.shape)) * cfg.raw_noise_std) if (pytest and cfg.raw_noise_std > 0.0) else None
         rgb_o, disp_o, acc_o, w_o, _ = O.raw2outputs(got["raw"].detach().cpu(), z, batch[:, 3:6], cfg.white_bkgd, noise1)
+        rgb_f, _, acc_f, _, _ = O.raw2outputs(raw_o, z, batch[:, 3:6], cfg.white_bkgd, noise1)
+    d_depth = np.abs(f64(rgb_f) - r_rgb).max(-1) / (1.0 + rtol / tol * np.abs(r_rgb).max(-1))
+    d_depth = np.maximum(d_depth, np.abs(f64(acc_f) - f64(maps["acc_map"])) / (1.0 + rtol / tol * np.abs(f64(maps["acc_map"]))))
+    by_depth = displaced | (d_depth >= 0.5 * d)
+    out = {"rays": int(d.shape[0]), "max_abs": float(d.max()), "median_abs": float(np.median(d)),
+           "frac_gt_tol": float(moved.mean()), "frac_gt_1e-3": float(moved_big.mean()),
+           "frac_displaced": float(displaced.mean()), "frac_last_flip_prone": float(cond_b.mean()),
+           "unexplained": int((moved & ~by_depth & ~cond_b).sum()),
+           "max_abs_undisplaced": float(d[~by_depth & ~cond_b].max()) if (~by_depth & ~cond_b).any() else 0.0,
+           "z_displacement_max": float(dz.max())}
     raw_g = got["raw"].detach().cpu()
     out["_staged_disp"], out["_staged_acc"], out["_staged_weights"] = disp_o, acc_o, w_o
     out["staged_raw_max"] = float(((raw_g - raw_o).abs() / (1.0 + raw_o.abs())).max())
     out["staged_rgb_max"] = float((got["rgb_map"].detach().cpu() - rgb_o).abs().max())
     out["staged_acc_max"] = float((got["acc_map"].detach().cpu() - acc_o).abs().max())
     out["_d"], out["_displaced"] = d, displaced
+    # the rays the caller will ask about first: how far they moved, and by how many ulp their worst sample is displaced
+    bad = np.nonzero(moved & ~by_depth & ~cond_b)[0]
+    ulp = (dz / np.spacing(np.abs(z_ref32)).astype(np.float64)).max(-1)
+    out["unexplained_rays"] = [(int(i), float(d[i]), float(ulp[i])) for i in bad[:8]]
     return out
 
 
