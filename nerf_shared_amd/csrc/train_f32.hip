@@ -356,9 +356,14 @@ bool pick_shape(const Program &p, Shape *s) {
     return s->tpw_f <= TF32_MAX_TPW && s->tpw_b <= TF32_MAX_TPW;
 }
 
-constexpr int64_t DW_SLICE_PTS = 1024;                     // points per weight-gradient workgroup
+// points per weight-gradient workgroup: 1024, more when the point axis would otherwise need more slices than a grid has rows
+int64_t dw_slice_pts(int64_t Pp) {
+    int64_t pts = 1024;
+    while ((Pp + pts - 1) / pts > 32768) pts *= 2;
+    return pts;
+}
 int64_t slab_floats(const Program &p, int64_t Pp) {
-    const int64_t slices = (Pp + DW_SLICE_PTS - 1) / DW_SLICE_PTS;
+    const int64_t slices = (Pp + dw_slice_pts(Pp) - 1) / dw_slice_pts(Pp);
     int64_t worst = 0;
     for (const LayerF32 &L : p.layers) worst = std::max<int64_t>(worst, (int64_t)((L.n_out + 63) / 64) * ((L.n_in + 1 + 63) / 64));
     return slices * worst * 4096;
@@ -428,13 +433,13 @@ int launch_train_f32_backward(const Program &p, const MlpArgs &a, const TrainLay
     if (rc) return rc;
     // ---- weight and bias gradients, layer by layer (the slab is re-used: everything is in stream order)
     float *slab = t.ws + (int64_t)p.train_f32_rows * t.Pp;
-    const int64_t slices = (t.Pp + DW_SLICE_PTS - 1) / DW_SLICE_PTS;
+    const int64_t slice_pts = dw_slice_pts(t.Pp), slices = (t.Pp + slice_pts - 1) / slice_pts;
     for (size_t l = 0; l < p.layers.size(); ++l) {
         const LayerF32 &L = p.layers[l];
         const TrainLayerF32 &T = p.tlayers[l];
         const float *G = t.ws + (int64_t)T.g_row * t.Pp, *X = t.ws + (int64_t)T.x_row * t.Pp;
         const int blocks_o = (L.n_out + 63) / 64, blocks_i = (L.n_in + 1 + 63) / 64, nb = blocks_o * blocks_i;      // + 1: the ones row
-        hipLaunchKernelGGL(f32_dw_kernel, dim3((unsigned)nb, (unsigned)slices), dim3(256), 0, s, G, X, L.n_out, L.n_in, t.Pp, DW_SLICE_PTS, blocks_i, slab);
+        hipLaunchKernelGGL(f32_dw_kernel, dim3((unsigned)nb, (unsigned)slices), dim3(256), 0, s, G, X, L.n_out, L.n_in, t.Pp, slice_pts, blocks_i, slab);
         hipLaunchKernelGGL(f32_dw_reduce_kernel, dim3((unsigned)(((int64_t)nb * 4096 + 255) / 256)), dim3(256), 0, s, slab, (int)slices, nb, blocks_i,
                            L.n_out, L.n_in, gw[L.tensor], gb[L.tensor]);
     }
